@@ -1,0 +1,16 @@
+"""TEST INFRASTRUCTURE — NOT PRODUCT CODE.
+
+CPU (NumPy) restatement of the optbayesexpt hot path, used only as the
+*checker* by ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py``.  Nothing under ``optbayesexpt_amd/`` may import this
+package: the product path is the HIP library and fails loudly without it.
+
+Parity status: PINNED.  ``tests/golden/make_golden.py`` imports the real
+reference (``/root/reference``, optbayesexpt 1.2.0) in the build container,
+runs seeded trajectories and writes the ``tests/golden/*.npz`` fixtures;
+``tests/test_oracle_golden.py`` checks this restatement against every one of
+them, and against the literal expectations of the reference's own unit tests
+(``tests/test_particlepdf.py``, ``tests/test_optbayesexpt.py``,
+``tests/test_zinference.py::test_infer``).
+"""
+from .obe_oracle import *  # noqa: F401,F403

@@ -1,0 +1,120 @@
+"""Replay helpers shared by the oracle tests (CPU) and the HIP parity tests (GPU).
+
+A golden trajectory (tests/golden/traj_*.npz, produced from the real reference by
+tests/golden/make_golden.py) is re-run through an implementation with the same
+method surface as the reference classes, feeding it the recorded measurement values,
+and every recorded output is compared:
+
+* draw indices, resample indices, chosen setting index, resample flags: exact;
+* utility, weights, moments, particles after a resample: relative tolerance ``rtol``
+  (1e-10 for the HIP path — BASELINE.json north_star — tighter for the oracle).
+"""
+import json
+import os
+import warnings
+
+import numpy as np
+from numpy.testing import assert_allclose, assert_array_equal
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+TRAJECTORIES = ["lorentz3_opt", "lorentz3_scale_choke", "lorentz3_good",
+                "line_noiseparam", "coil_2ch_noise", "rabi_2set", "multilorentz7_noise"]
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+    fx = {k: z[k] for k in z.files}
+    if "meta" in fx:
+        fx["meta"] = json.loads(str(fx["meta"]))
+    return fx
+
+
+def load_traj(name):
+    return load(f"traj_{name}.npz")
+
+
+def setting_values(fx):
+    return tuple(fx[f"setval_{k}"] for k in range(fx["meta"]["n_setdims"]))
+
+
+def construct(fx, base_cls, noise_cls, model, extra=None):
+    meta = fx["meta"]
+    ctor = dict(meta["ctor"])
+    if "noise_parameter_index" in ctor and isinstance(ctor["noise_parameter_index"], list):
+        ctor["noise_parameter_index"] = tuple(ctor["noise_parameter_index"])
+    ctor.update(extra or {})
+    cls = base_cls if meta["cls"] == "base" else noise_cls
+    cons = tuple(float(c) for c in fx["cons"])
+    obe = cls(model, setting_values(fx), fx["prior"].copy(), cons, **ctor)
+    obe.rng = np.random.default_rng(meta["seed"])        # seeding recipe, SURVEY §8c
+    return obe
+
+
+def close(actual, desired, rtol, what, scale=None):
+    """Relative comparison with an absolute floor tied to the array's own scale, so
+    that entries that are (near) zero by cancellation do not demand impossible
+    relative accuracy."""
+    desired = np.asarray(desired, dtype=np.float64)
+    ref_scale = np.max(np.abs(desired)) if scale is None else scale
+    assert_allclose(np.asarray(actual, dtype=np.float64), desired, rtol=rtol,
+                    atol=rtol * 1e-3 * ref_scale, err_msg=what)
+
+
+def replay(fx, obe, rtol, get_draw_idx=None, get_utility=None, check_moments=True):
+    """Drive ``obe`` through the recorded cycles.  ``get_draw_idx(obe)`` returns the
+    particle indices of the most recent utility draw (implementation-specific
+    accessor); ``get_utility(obe)`` the most recent utility vector."""
+    meta = fx["meta"]
+    C = meta["n_channels"]
+    n_cycles = meta["n_cycles"]
+    w_at = {int(c): i for i, c in enumerate(fx["w_cycles"])}
+    p_at = {int(c): i for i, c in enumerate(fx["p_cycles"])}
+    stats = dict(cycles=0, resamples=0)
+    for cyc in range(n_cycles):
+        if meta["selection"] == "opt":
+            x = obe.opt_setting()
+            if get_utility is not None:
+                close(get_utility(obe), fx["utility"][cyc], rtol, f"utility, cycle {cyc}")
+        else:
+            x = obe.good_setting(meta["pickiness"])
+        if get_draw_idx is not None:
+            assert_array_equal(np.asarray(get_draw_idx(obe)), fx["draw_idx"][cyc],
+                               err_msg=f"draw indices, cycle {cyc}")
+        assert int(obe.last_setting_index) == int(fx["chosen_index"][cyc]), \
+            f"chosen setting index, cycle {cyc}"
+        assert_array_equal(np.asarray(x, dtype=np.float64),
+                           np.asarray(obe.allsettings)[:, int(fx["chosen_index"][cyc])])
+        y = fx["y_meas"][cyc]
+        if meta["cls"] == "base":
+            s = meta["sigma_meas"]
+            rec = (x, tuple(y) if C > 1 else float(y[0]), tuple([s] * C) if C > 1 else s)
+        else:
+            rec = (x, tuple(y) if C > 1 else float(y[0]))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            obe.pdf_update(rec)
+        assert bool(obe.just_resampled) == bool(fx["resampled"][cyc]), f"resample flag, cycle {cyc}"
+        stats["resamples"] += int(obe.just_resampled)
+        if cyc in w_at:
+            close(obe.particle_weights, fx["w_snaps"][w_at[cyc]], rtol, f"weights, cycle {cyc}")
+        if cyc in p_at:
+            snap = fx["p_snaps"][p_at[cyc]]
+            got = np.asarray(obe.particles, dtype=np.float64)
+            for d in range(snap.shape[0]):
+                close(got[d], snap[d], rtol, f"particles[{d}] after resample, cycle {cyc}")
+        if check_moments:
+            close(obe.mean(), fx["mean"][cyc], rtol, f"mean, cycle {cyc}",
+                  scale=np.max(np.abs(fx["mean"][cyc]) + fx["std"][cyc]))
+            sd = fx["std"][cyc]
+            # std() is the one-pass <x^2> - <x>^2 (particlepdf.py:209-214): its
+            # attainable accuracy is ~eps * <x^2> / var relative, whatever the
+            # summation order, so that term is added to the tolerance.
+            tol = rtol * sd + 64 * 2.3e-16 * fx["mean"][cyc] ** 2 / np.maximum(sd, 1e-300)
+            err = np.abs(np.asarray(obe.std()) - sd)
+            assert np.all(err <= tol), f"std, cycle {cyc}: err {err} tol {tol}"
+            close(obe.covariance(), fx["cov"][cyc], rtol, f"covariance, cycle {cyc}")
+        close(np.sum(np.asarray(obe.particle_weights) ** 2), fx["sum_w2"][cyc], rtol,
+              f"sum w^2, cycle {cyc}")
+        stats["cycles"] += 1
+    return stats

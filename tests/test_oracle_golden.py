@@ -1,0 +1,163 @@
+"""Pins the oracle (oracle/obe_oracle.py) against (1) golden vectors produced by the
+real reference (tests/golden/make_golden.py) and (2) the literal expectations of the
+reference's own unit tests for this path.  CPU only."""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose, assert_array_equal
+
+import _replay
+import oracle
+from oracle import models
+
+ORACLE_MODELS = {
+    "lorentzian": models.lorentzian,
+    "multi_lorentzian_7": models.multi_lorentzian(7),
+    "line_mb": models.line_mb,
+    "rabi": models.rabi,
+    "coil": models.coil,
+}
+
+# The oracle uses the same NumPy primitives as the reference, so it is held to a
+# much tighter tolerance than the 1e-10 the HIP path is allowed.
+ORACLE_RTOL = 1e-13
+
+
+@pytest.mark.parametrize("name", _replay.TRAJECTORIES)
+def test_trajectory_matches_reference(name):
+    fx = _replay.load_traj(name)
+    obe = _replay.construct(fx, oracle.OracleOptBayesExpt,
+                            oracle.OracleOptBayesExptNoiseParameter,
+                            ORACLE_MODELS[fx["meta"]["model"]])
+    stats = _replay.replay(fx, obe, ORACLE_RTOL,
+                           get_draw_idx=lambda o: o.last_draw_indices,
+                           get_utility=lambda o: o.last_utility)
+    assert stats["cycles"] == fx["meta"]["n_cycles"]
+    assert stats["resamples"] == int(np.sum(fx["resampled"])) >= 5
+
+
+def test_unit_cases():
+    u = _replay.load("unit_cases.npz")
+    for d in (1, 3, 10):
+        x, w = u[f"mom{d}_x"], u[f"mom{d}_w"]
+        assert_allclose(oracle.weighted_mean(x, w), u[f"mom{d}_mean"], rtol=1e-14)
+        cov = oracle.weighted_covariance(x, w)
+        assert cov.shape == (d, d)
+        assert_allclose(cov, u[f"mom{d}_cov"], rtol=1e-13, atol=1e-13 * np.abs(u[f"mom{d}_cov"]).max())
+        assert_allclose(oracle.weighted_std(x, w), u[f"mom{d}_std"], rtol=1e-13)
+    for tag, scale in (("s0", False), ("s1", True)):
+        pdf = oracle.OracleParticlePDF(u[f"rs_{tag}_x"].copy(), scale=scale)
+        pdf.particle_weights = u[f"rs_{tag}_w"].copy()
+        pdf.rng = np.random.default_rng(4242)
+        draws = pdf.randdraw(30)
+        assert_array_equal(pdf.last_draw_indices, u[f"rs_{tag}_draw_idx"])
+        assert_array_equal(draws, u[f"rs_{tag}_draws"])
+        pdf.resample()
+        assert_array_equal(pdf.last_draw_indices, u[f"rs_{tag}_resample_idx"])
+        assert_allclose(pdf.particles, u[f"rs_{tag}_particles"], rtol=1e-14)
+        assert_array_equal(pdf.particle_weights, u[f"rs_{tag}_weights"])
+    with np.errstate(all="ignore"):
+        assert_array_equal(oracle.normalized_product(u["bu_w"], u["bu_lik"]), u["bu_out"])
+        assert_array_equal(oracle.normalized_product(u["bu_w"], np.zeros_like(u["bu_w"])),
+                           u["bu_zero_out"])
+    assert not np.any(u["bu_zero_out"])
+    assert np.isinf(oracle.effective_particles(u["bu_zero_out"]))
+
+
+def test_full_sweep_matches_reference_limit():
+    """weighted-variance sweep == reference with every particle drawn,
+    at uniform weights."""
+    f = _replay.load("full_sweep_uniform.npz")
+    cases = [("lor", models.lorentzian, (f["fs_lor_x"],), (0.1,)),
+             ("ml7", models.multi_lorentzian(7), (f["fs_lor_x"],), (0.1,)),
+             ("coil", models.coil, (f["fs_coil_w"],), ()),
+             ("rabi", models.rabi, (f["fs_rabi_s0"], f["fs_rabi_s1"]), (100000.0, 0.01, 2.0))]
+    for tag, fn, sv, cons in cases:
+        prior = f[f"fs_{tag}_prior"]
+        n = prior.shape[1]
+        yvar = oracle.yvar_full_sweep(fn, oracle.flatten_settings(sv), prior,
+                                      np.full(n, 1.0 / n), cons, chunk=300)
+        ref = f[f"fs_{tag}_yvar"]
+        assert yvar.shape == ref.shape
+        assert_allclose(yvar, ref, rtol=1e-11, atol=1e-13 * ref.max(), err_msg=tag)
+
+
+# ---- the reference's own unit-test expectations, restated against the oracle ----
+
+def _toy_pdf():
+    return oracle.OracleParticlePDF((np.array([0, 1, 2, 3]), np.array([1, 3, 2, 4])))
+
+
+def test_reference_particlepdf_literals():
+    """reference tests/test_particlepdf.py:17-152."""
+    pdf = _toy_pdf()
+    assert (pdf.n_dims, pdf.n_particles) == (2, 4)
+    assert_array_equal(pdf.particle_weights, [.25, .25, .25, .25])
+    assert pdf.just_resampled is False
+    assert_array_equal(pdf.mean(), (1.5, 2.5))
+    assert_allclose(pdf.covariance(), [[5 / 3, 4 / 3], [4 / 3, 5 / 3]])
+    assert_array_equal(pdf.std(), np.sqrt(np.array([1, 1]) * 5.0 / 4.0))
+    samples = np.arange(15).reshape((3, 5))
+    pdf.set_pdf(samples)
+    assert (pdf.n_dims, pdf.n_particles) == (3, 5)
+    assert_array_equal(pdf.particle_weights, np.ones(5) / 5.0)
+    pdf.set_pdf(samples, weights=np.array([1, 2, 3, 4, 5]))
+    assert_array_equal(pdf.particle_weights, np.array([1, 2, 3, 4, 5]) / 15)
+    with pytest.raises(ValueError):
+        pdf.set_pdf(samples, weights=np.ones(4))
+    pdf = _toy_pdf()
+    pdf.tuning_parameters["auto_resample"] = False
+    lik = np.array([.5, 1.5, 1.5, .5])
+    pdf.bayesian_update(lik)
+    assert_array_equal(pdf.particle_weights, lik / np.sum(lik))
+    pdf = _toy_pdf()
+    pdf.particle_weights = np.array([0, .5, .5, 0])
+    pdf.resample()
+    assert pdf.particles.shape == (2, 4)
+    assert_array_equal(pdf.particle_weights, [.25, .25, .25, .25])
+    pdf = _toy_pdf()
+    pdf.particle_weights = np.array([.1, .4, .4, .1])
+    pdf.resample_test()
+    assert pdf.just_resampled is False
+    pdf.particle_weights = np.array([0, .75, .25, 0])
+    pdf.resample_test()
+    assert pdf.just_resampled is True
+
+
+def test_reference_optbayesexpt_literals():
+    """reference tests/test_optbayesexpt.py:21-69."""
+    pars = (np.array([0, 1, 2, 3]), np.array([1, 3, 2, 4]))
+    obe = oracle.OracleOptBayesExpt(models.line_ab, (np.array([0, 1, 2]),), pars, ())
+    assert_array_equal(obe.allsettings, (np.array([0, 1, 2]),))
+    assert_array_equal(obe.parameters, pars)
+    assert_array_equal(obe.eval_over_all_parameters((1,)), [[1, 4, 4, 7]])
+    assert_array_equal(obe.eval_over_all_settings([1, 3]), [[1, 4, 7]])
+    ymodel = np.array(((1, 4, 4, 7),))
+    assert_array_equal(obe.likelihood(ymodel, ((1,), (5.0,), 1.0)),
+                       np.exp(-(ymodel - 5.0) ** 2 / 2)[0])
+    lkl = np.exp(-(np.array((1, 4, 4, 7)) - 5.0) ** 2 / 2)
+    obe.pdf_update(((1,), 5.0, 1.0))
+    assert_array_equal(obe.particle_weights, lkl / np.sum(lkl))
+
+
+def test_reference_infer():
+    """reference tests/test_zinference.py:89-108 (analytic posterior, 1e-15) and the
+    reference's own output for it (fixture)."""
+    u = _replay.load("unit_cases.npz")
+    xs = u["infer_x"]
+    n = len(xs)
+    obe = oracle.OracleOptBayesExpt(models.first_parameter, (0,), (xs, np.ones(n)), (0,))
+    obe.tuning_parameters["resample_threshold"] = 0
+    obe.pdf_update(((), 1.0, 1.0))
+    known = np.exp(-(1.0 - xs) ** 2 / 2) / np.sqrt(2 * np.pi)
+    known /= np.sum(known)
+    assert_allclose(obe.particle_weights, known, atol=1e-15, rtol=1e-15)
+    assert_array_equal(obe.particle_weights, u["infer_w"])
+
+
+def test_likelihood_two_channel_choke():
+    u = _replay.load("unit_cases.npz")
+    n = u["lk_ym"].shape[1]
+    obe = oracle.OracleOptBayesExpt(models.coil, (np.logspace(4, 6, 5),),
+                                    np.ones((4, n)), (), choke=0.6, n_channels=2)
+    got = obe.likelihood(u["lk_ym"], ((1.0,), (0.3, -0.2), (1.5, 0.7)))
+    assert_allclose(got, u["lk_out"], rtol=1e-15)
