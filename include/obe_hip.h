@@ -1,0 +1,237 @@
+/*
+ * obe_hip.h — C ABI of libobe_hip.so: the MI355X (gfx950) hot path of optbayesexpt.
+ *
+ * The reference (usnistgov/optbayesexpt 1.2.0) is pure Python + NumPy and has no
+ * FFI of its own, so every entry point below names the reference *method* whose
+ * arithmetic it replaces (paths relative to the reference root).  INTEGRATION.md
+ * shows the ctypes stubs a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - All arithmetic is IEEE float64; indices are int64.
+ *  - Every pointer named d_* is a DEVICE pointer owned by the caller (the Python
+ *    host side allocates them as torch tensors); the library never allocates or
+ *    frees device memory.  h_* are HOST pointers.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All
+ *    kernels are enqueued on it; functions that return host scalars say so and
+ *    synchronise that stream themselves.
+ *  - Return value: 0 = success, otherwise a hipError_t (or -1 for an argument
+ *    error); obe_last_error() describes the most recent failure on this thread.
+ *  - No exceptions cross the ABI.  A handle-free, re-entrant design: all state
+ *    lives in caller-owned buffers; calls on different streams are independent.
+ *  - Particles are stored SoA: row i of `d_particles` (parameter i of every
+ *    particle) starts at d_particles + i * ld_p   (particlepdf.py:101-105).
+ *    Settings likewise: row k of `d_settings` at d_settings + k * ld_s
+ *    (obe_base.py:174-176, meshgrid 'ij' flattened).
+ */
+#ifndef OBE_HIP_H
+#define OBE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OBE_ABI_VERSION 1
+#define OBE_MAX_CONSTS 8
+#define OBE_MAX_CHANNELS 4
+#define OBE_MAX_SETDIMS 4
+#define OBE_MAX_DIMS 16
+
+/* ---- device model registry (replaces the Python `model_function` callable,
+ *      obe_base.py:50-72, for the model families the reference's demos use) ---- */
+enum obe_model_id {
+    OBE_MODEL_LORENTZ = 1,      /* y = b + sum_k a/(((x-x0_k)/d)^2+1); aux = #peaks K (1..8);
+                                   params x0_1..x0_K, a, b [, extras]; const d.
+                                   K=1: demos/find_peak/sequentialLorentzian.py:53-75,
+                                   demos/sweeper/sweeper.py:42-64                     */
+    OBE_MODEL_LINE_AB = 2,      /* y = p0 + p1*x          tests/test_optbayesexpt.py:11-14 */
+    OBE_MODEL_LINE_MB = 3,      /* y = p0*x + p1          demos/line_plus_noise/line_plus_noise.py:36-53 */
+    OBE_MODEL_FIRST_PARAM = 4,  /* y = p0                 tests/test_zinference.py:21-26 */
+    OBE_MODEL_RABI = 5,         /* demos/pipulse/pipulse.py:18-49; 2 settings, 2 params, 3 consts */
+    OBE_MODEL_COIL = 6          /* demos/lockin/lockin_of_coil.py:63-102; 2 channels */
+};
+
+typedef struct obe_model {
+    int32_t id;          /* enum obe_model_id */
+    int32_t aux;         /* model-specific integer (number of Lorentzian peaks) */
+    int32_t n_params;    /* D: rows of the particle array (may exceed what the model reads) */
+    int32_t n_setdims;   /* S */
+    int32_t n_channels;  /* C */
+    int32_t n_consts;
+    double consts[OBE_MAX_CONSTS];
+} obe_model;
+
+/* Checks id/aux/n_* consistency; fills n_setdims/n_channels if they are 0. */
+int obe_model_validate(obe_model* m);
+
+/* ---- library ---- */
+int obe_abi_version(void);
+const char* obe_last_error(void);
+/* Name, CU count and memory of the current device; returns 0 if a gfx950 device is current. */
+int obe_device_info(char* name, int name_len, int* n_cu, int64_t* hbm_bytes);
+
+/* Scratch (device) bytes any call below may need for these sizes. */
+int64_t obe_workspace_bytes(int64_t n_particles, int64_t n_settings, int32_t n_channels, int32_t n_dims);
+
+/* ---- K2: Bayes update  (obe_base.py:385-394 eval_over_all_parameters + likelihood +
+ *      particlepdf.py:136-139 _normalized_product + :243-244 N_eff) ------------------
+ * Fused: y = model(setting; particle), L = prod_ch exp(-((y-y_meas)/sigma)^2/2)/sigma,
+ * [L = L^choke], t = nan_to_num(w*L), w' = nan_to_num(t/sum t), in place in d_weights.
+ * sigma per channel: h_sigma[ch] (known noise, obe_base.py:451-456) when
+ * h_noise_rows == NULL, otherwise row h_noise_rows[ch] of the particle array
+ * (OptBayesExptNoiseParameter.likelihood, obe_noiseparam.py:109-115).
+ * n_lik_channels = number of channels entering the product (zip truncation,
+ * obe_base.py:453-455).  choke: NaN = none (obe_base.py:458-459).
+ * h_out[0] = sum t, h_out[1] = sum nan_to_num(w'^2)  (host; stream is synchronised). */
+int obe_bayes_update_model(const obe_model* m,
+                           const double* d_particles, int64_t ld_p, int64_t n_particles,
+                           double* d_weights,
+                           const double* h_setting, const double* h_y_meas,
+                           const double* h_sigma, const int32_t* h_noise_rows,
+                           int32_t n_lik_channels, double choke,
+                           void* d_ws, int64_t ws_bytes, double* h_out, void* stream);
+
+/* Same update from precomputed model outputs d_y (C, N_p) row-major, ld_y between
+ * channels  (pdf_update(..., y_model_data), obe_base.py:384-385). */
+int obe_bayes_update_y(const double* d_y, int64_t ld_y, int32_t n_channels,
+                       const double* d_particles, int64_t ld_p, int64_t n_particles,
+                       double* d_weights, const double* h_y_meas,
+                       const double* h_sigma, const int32_t* h_noise_rows,
+                       int32_t n_lik_channels, double choke,
+                       void* d_ws, int64_t ws_bytes, double* h_out, void* stream);
+
+/* ParticlePDF.bayesian_update(likelihood) with a caller-supplied likelihood array
+ * (particlepdf.py:216-234). */
+int obe_bayes_update_lik(const double* d_lik, int64_t n_particles, double* d_weights,
+                         void* d_ws, int64_t ws_bytes, double* h_out, void* stream);
+
+/* OptBayesExpt.likelihood(y_model, record) as an array (obe_base.py:418-461). */
+int obe_likelihood_y(const double* d_y, int64_t ld_y, int32_t n_channels,
+                     const double* d_particles, int64_t ld_p, int64_t n_particles,
+                     const double* h_y_meas, const double* h_sigma,
+                     const int32_t* h_noise_rows, int32_t n_lik_channels, double choke,
+                     double* d_lik_out, void* stream);
+
+/* h_out[0] = sum nan_to_num(w^2) (resample_test, particlepdf.py:243-244), h_out[1] = sum w. */
+int obe_weight_sums(const double* d_weights, int64_t n_particles,
+                    void* d_ws, int64_t ws_bytes, double* h_out, void* stream);
+
+/* ---- model evaluation wrappers (obe_base.py:298-338) ---- */
+/* d_y_out (C, N_p): model(one setting; all particles). */
+int obe_eval_over_particles(const obe_model* m, const double* d_particles, int64_t ld_p,
+                            int64_t n_particles, const double* h_setting,
+                            double* d_y_out, int64_t ld_y, void* stream);
+/* d_y_out (C, N_s): model(all settings; one parameter set h_params[D]). */
+int obe_eval_over_settings(const obe_model* m, const double* d_settings, int64_t ld_s,
+                           int64_t n_settings, const double* h_params,
+                           double* d_y_out, int64_t ld_y, void* stream);
+
+/* ---- K3: weighted moments (particlepdf.py:173-214) ----
+ * d_out layout (doubles): [0]=sum w, [1]=sum w^2, [2..2+D) mean (np.average),
+ * [2+D..2+2D) m1 = sum w x, [2+2D..2+3D) m2 = sum w x^2, [2+3D..2+4D) std,
+ * then (if want_cov) D*D covariance (np.cov aweights, ddof=1 form).  Stays on the
+ * device (other kernels consume it); copied to h_out too when h_out != NULL (sync). */
+int64_t obe_moments_len(int32_t n_dims);
+int obe_moments(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t n_particles,
+                const double* d_weights, int32_t want_cov,
+                double* d_out, double* h_out, void* d_ws, int64_t ws_bytes, void* stream);
+
+/* ---- K4: multinomial resampling (particlepdf.py:260-345) ----
+ * CDF of Generator.choice: cumsum(w) / cumsum(w)[-1].  strict_order != 0 reproduces
+ * np.cumsum's serial rounding bit for bit (slow, one wavefront); 0 = parallel
+ * blocked scan (same value to ~1e-13, indices identical unless a uniform falls
+ * inside that gap).  h_total (nullable) receives sum(w) (sync). */
+int obe_weight_cdf(const double* d_weights, int64_t n_particles, int32_t strict_order,
+                   double* d_cdf, double* h_total, void* d_ws, int64_t ws_bytes, void* stream);
+/* idx[j] = #{i : cdf[i] <= u[j]}  (searchsorted side='right'), int64. */
+int obe_cdf_search(const double* d_cdf, int64_t n, const double* d_uniforms, int64_t n_draws,
+                   int64_t* d_idx_out, void* stream);
+/* randdraw gather: d_out (D, n_draws) = particles[:, idx]  (particlepdf.py:332-343). */
+int obe_gather_columns(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t n_particles,
+                       const int64_t* d_idx, int64_t n_draws,
+                       double* d_out, int64_t ld_out, void* stream);
+/* resample(): new[i,p] = old[i, idx[p]] + sum_j z[p,j] F[i,j]   (F = u*sqrt(s) of the
+ * SVD of (1-a^2) cov, h_factor row-major D*D; z = standard normals (N, D) row-major);
+ * if scale: new = new*a + mean[i]*(1-a)   (particlepdf.py:296-305).  Then weights = 1/N. */
+int obe_resample_particles(const double* d_old, int64_t ld_old, int32_t n_dims, int64_t n_particles,
+                           const int64_t* d_idx, const double* d_normals,
+                           const double* h_factor, const double* h_mean,
+                           double a_param, int32_t scale,
+                           double* d_new, int64_t ld_new, double* d_weights, void* stream);
+
+/* ---- K6: OptBayesExptNoiseParameter extras ----
+ * enforce_parameter_constraints (obe_noiseparam.py:57-79): zero the weight of every
+ * particle whose row h_rows[k] <= 0 for any k, renormalise if anything changed.
+ * *h_changed = number of particles zeroed (sync). */
+int obe_mask_nonpositive(const double* d_particles, int64_t ld_p, int64_t n_particles,
+                         const int32_t* h_rows, int32_t n_rows, double* d_weights,
+                         int64_t* h_changed, void* d_ws, int64_t ws_bytes, void* stream);
+
+/* yvar_noise_model (obe_noiseparam.py:122-136): d_out[c] = weighted mean of
+ * (particle row h_rows[c])^2, read from the K3 block: m2[row] / sum w.  No sync. */
+int obe_noise_var_from_moments(const double* d_moments, int32_t n_dims, const int32_t* h_rows,
+                               int32_t n_rows, double* d_out, void* stream);
+
+/* ---- good_setting (obe_base.py:781-784): p = nan_to_num(u ** exponent); p /= sum(p) ---- */
+int obe_power_normalize(const double* d_u, int64_t n, double exponent, double* d_p_out,
+                        void* d_ws, int64_t ws_bytes, void* stream);
+
+/* ---- K1 + K5: utility sweep and argmax (obe_base.py:463-489, 628-655, 733-756) ----
+ * Evaluates the model over settings [s_begin, s_begin + n_settings) x draws and
+ * reduces to the per-setting variance of the model output, per channel.
+ *   d_draw_idx == NULL : full sweep — every particle is a draw, weighted variance
+ *                        sum_p w_p (y - ybar)^2 / sum_p w_p     
+ *   d_draw_idx != NULL : reference semantics — the n_draws listed particles, unweighted
+ *                        ddof=0 variance (np.var over utility_y_space, obe_base.py:488)
+ * d_moments: output of obe_moments for the same particles/weights (mean parameters are
+ * used as the variance shift, sum w as the normaliser).
+ * Then utility[s] = sum_c yvar[c,s] / noise_var[c(,s)] / cost[(s)]   (obe_base.py:650-655)
+ * with d_noise_var (C) if noise_ld == 0 else (C, n_settings) rows noise_ld apart, and
+ * cost = cost_scalar if d_cost == NULL else d_cost[s]; and the first-maximum argmax
+ * (np.argmax, obe_base.py:748): h_best[0] = value, h_best_idx[0] = index relative to
+ * s_begin (sync) when h_best != NULL.  d_yvar (C, n_settings) and d_utility
+ * (n_settings) stay on the device. */
+int obe_sweep_utility(const obe_model* m,
+                      const double* d_settings, int64_t ld_s, int64_t n_settings,
+                      const double* d_particles, int64_t ld_p, int64_t n_particles,
+                      const double* d_weights, const int64_t* d_draw_idx, int64_t n_draws,
+                      const double* d_moments,
+                      const double* d_noise_var, int64_t noise_ld,
+                      const double* d_cost, double cost_scalar,
+                      double* d_yvar, double* d_utility,
+                      double* h_best, int64_t* h_best_idx,
+                      void* d_ws, int64_t ws_bytes, void* stream);
+
+/* Variance over the draw axis of a caller-filled y-space (N_d, C, N_s) — the
+ * np.var(utility_y_space, axis=0) of obe_base.py:488 for host-callable models. */
+int obe_yspace_variance(const double* d_yspace, int64_t n_draws, int32_t n_channels,
+                        int64_t n_settings, double* d_yvar, void* stream);
+/* utility + argmax from an existing yvar (same conventions as obe_sweep_utility). */
+int obe_utility_argmax(const double* d_yvar, int32_t n_channels, int64_t n_settings,
+                       const double* d_noise_var, int64_t noise_ld,
+                       const double* d_cost, double cost_scalar,
+                       double* d_utility, double* h_best, int64_t* h_best_idx,
+                       void* d_ws, int64_t ws_bytes, void* stream);
+/* first-maximum argmax of an arbitrary device vector (np.argmax semantics incl. NaN). */
+int obe_argmax(const double* d_v, int64_t n, double* h_best, int64_t* h_best_idx,
+               void* d_ws, int64_t ws_bytes, void* stream);
+
+/* ---- timing on the launch stream (bench.py roofline leg) ---- */
+int obe_timer_create(void** timer);
+int obe_timer_start(void* timer, void* stream);
+int obe_timer_stop(void* timer, void* stream, float* ms);   /* records, syncs, returns elapsed */
+int obe_timer_destroy(void* timer);
+/* Launches only the dominant sweep kernel `iters` times between two events on `stream`
+ * and returns the average per-launch duration in ms (bench.py roofline.achieved). */
+int obe_sweep_kernel_time(const obe_model* m,
+                          const double* d_settings, int64_t ld_s, int64_t n_settings,
+                          const double* d_particles, int64_t ld_p, int64_t n_particles,
+                          const double* d_weights, const double* d_moments,
+                          void* d_ws, int64_t ws_bytes, int32_t iters, float* h_ms_avg,
+                          void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OBE_HIP_H */

@@ -1,0 +1,152 @@
+"""ctypes binding of libobe_hip.so (the C ABI declared in include/obe_hip.h).
+
+There is no CPU fallback: if the shared library is missing or cannot be loaded the
+import of the product classes fails with an explicit error.  PyTorch is imported first
+so that the process ends up with a single HIP runtime (torch bundles libamdhip64.so.7,
+the library's NEEDED entry resolves to the already-loaded copy).
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libobe_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "obe_hip.h")
+
+OBE_MAX_CONSTS = 8
+OBE_MAX_CHANNELS = 4
+OBE_MAX_SETDIMS = 4
+OBE_MAX_DIMS = 16
+
+c_void_p, c_int, c_int32, c_int64, c_double = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int32,
+                                               ctypes.c_int64, ctypes.c_double)
+
+
+class ObeHipError(RuntimeError):
+    """A libobe_hip call returned a non-zero status."""
+
+
+class ObeModelStruct(ctypes.Structure):
+    """Mirror of ``struct obe_model`` (include/obe_hip.h)."""
+    _fields_ = [("id", c_int32), ("aux", c_int32), ("n_params", c_int32),
+                ("n_setdims", c_int32), ("n_channels", c_int32), ("n_consts", c_int32),
+                ("consts", c_double * OBE_MAX_CONSTS)]
+
+
+def declared_symbols(header_path=HEADER_PATH):
+    """Every function name the header declares (used by the symbol-export test)."""
+    text = open(header_path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(obe_[a-z0-9_]+)\s*\(", text)))
+
+
+_P = c_void_p   # any pointer (device or host) is passed as an integer address
+
+_SIGNATURES = {
+    "obe_abi_version": (c_int, []),
+    "obe_last_error": (ctypes.c_char_p, []),
+    "obe_model_validate": (c_int, [ctypes.POINTER(ObeModelStruct)]),
+    "obe_device_info": (c_int, [ctypes.c_char_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int64)]),
+    "obe_workspace_bytes": (c_int64, [c_int64, c_int64, c_int32, c_int32]),
+    "obe_bayes_update_model": (c_int, [ctypes.POINTER(ObeModelStruct), _P, c_int64, c_int64, _P, _P, _P, _P, _P,
+                                       c_int32, c_double, _P, c_int64, _P, _P]),
+    "obe_bayes_update_y": (c_int, [_P, c_int64, c_int32, _P, c_int64, c_int64, _P, _P, _P, _P, c_int32,
+                                   c_double, _P, c_int64, _P, _P]),
+    "obe_bayes_update_lik": (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P]),
+    "obe_likelihood_y": (c_int, [_P, c_int64, c_int32, _P, c_int64, c_int64, _P, _P, _P, c_int32, c_double,
+                                 _P, _P]),
+    "obe_weight_sums": (c_int, [_P, c_int64, _P, c_int64, _P, _P]),
+    "obe_eval_over_particles": (c_int, [ctypes.POINTER(ObeModelStruct), _P, c_int64, c_int64, _P, _P, c_int64, _P]),
+    "obe_eval_over_settings": (c_int, [ctypes.POINTER(ObeModelStruct), _P, c_int64, c_int64, _P, _P, c_int64, _P]),
+    "obe_moments_len": (c_int64, [c_int32]),
+    "obe_moments": (c_int, [_P, c_int64, c_int32, c_int64, _P, c_int32, _P, _P, _P, c_int64, _P]),
+    "obe_weight_cdf": (c_int, [_P, c_int64, c_int32, _P, _P, _P, c_int64, _P]),
+    "obe_cdf_search": (c_int, [_P, c_int64, _P, c_int64, _P, _P]),
+    "obe_gather_columns": (c_int, [_P, c_int64, c_int32, c_int64, _P, c_int64, _P, c_int64, _P]),
+    "obe_resample_particles": (c_int, [_P, c_int64, c_int32, c_int64, _P, _P, _P, _P, c_double, c_int32,
+                                       _P, c_int64, _P, _P]),
+    "obe_mask_nonpositive": (c_int, [_P, c_int64, c_int64, _P, c_int32, _P, _P, _P, c_int64, _P]),
+    "obe_noise_var_from_moments": (c_int, [_P, c_int32, _P, c_int32, _P, _P]),
+    "obe_power_normalize": (c_int, [_P, c_int64, c_double, _P, _P, c_int64, _P]),
+    "obe_sweep_utility": (c_int, [ctypes.POINTER(ObeModelStruct), _P, c_int64, c_int64, _P, c_int64, c_int64,
+                                  _P, _P, c_int64, _P, _P, c_int64, _P, c_double, _P, _P, _P, _P, _P,
+                                  c_int64, _P]),
+    "obe_yspace_variance": (c_int, [_P, c_int64, c_int32, c_int64, _P, _P]),
+    "obe_utility_argmax": (c_int, [_P, c_int32, c_int64, _P, c_int64, _P, c_double, _P, _P, _P, _P, c_int64, _P]),
+    "obe_argmax": (c_int, [_P, c_int64, _P, _P, _P, c_int64, _P]),
+    "obe_timer_create": (c_int, [ctypes.POINTER(c_void_p)]),
+    "obe_timer_start": (c_int, [_P, _P]),
+    "obe_timer_stop": (c_int, [_P, _P, ctypes.POINTER(ctypes.c_float)]),
+    "obe_timer_destroy": (c_int, [_P]),
+    "obe_sweep_kernel_time": (c_int, [ctypes.POINTER(ObeModelStruct), _P, c_int64, c_int64, _P, c_int64, c_int64,
+                                      _P, _P, _P, c_int64, c_int32, ctypes.POINTER(ctypes.c_float), _P]),
+}
+
+
+class HipLib:
+    """Loaded library with typed entry points; ``call(name, *args)`` raises on error."""
+
+    def __init__(self, path=LIB_PATH):
+        if not os.path.exists(path):
+            raise ImportError(
+                f"{path} not found: the HIP library has not been built.  Run "
+                "`python -m optbayesexpt_amd.build` (needs hipcc).  optbayesexpt_amd has "
+                "no CPU fallback.")
+        import torch  # noqa: F401  (loads the HIP runtime the library will bind to)
+        self.path = path
+        self.cdll = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        for name, (restype, argtypes) in _SIGNATURES.items():
+            fn = getattr(self.cdll, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        abi = self.cdll.obe_abi_version()
+        if abi != 1:
+            raise ImportError(f"libobe_hip ABI {abi} does not match this package (1)")
+
+    def last_error(self):
+        msg = self.cdll.obe_last_error()
+        return msg.decode() if msg else ""
+
+    def call(self, name, *args):
+        rc = getattr(self.cdll, name)(*args)
+        if rc != 0:
+            raise ObeHipError(f"{name} failed (status {rc}): {self.last_error()}")
+        return rc
+
+    def workspace_bytes(self, n_particles, n_settings, n_channels, n_dims):
+        return int(self.cdll.obe_workspace_bytes(n_particles, n_settings, n_channels, n_dims))
+
+    def moments_len(self, n_dims):
+        return int(self.cdll.obe_moments_len(n_dims))
+
+    def device_info(self):
+        buf = ctypes.create_string_buffer(256)
+        ncu, mem = c_int(0), c_int64(0)
+        rc = self.cdll.obe_device_info(buf, 256, ctypes.byref(ncu), ctypes.byref(mem))
+        return dict(name=buf.value.decode(), n_cu=ncu.value, hbm_bytes=mem.value, is_gfx950=(rc == 0))
+
+
+_LIB = None
+
+
+def load():
+    """The process-wide library instance (loaded on first use)."""
+    global _LIB
+    if _LIB is None:
+        _LIB = HipLib()
+    return _LIB
+
+
+def host_ptr(arr):
+    """Address of a C-contiguous NumPy array (kept alive by the caller)."""
+    return arr.ctypes.data_as(c_void_p)
+
+
+def f64(values, n=None):
+    """Small host array of float64 for by-value style arguments."""
+    a = np.ascontiguousarray(np.asarray(values, dtype=np.float64).reshape(-1))
+    if n is not None and a.size != n:
+        raise ValueError(f"expected {n} values, got {a.size}")
+    return a

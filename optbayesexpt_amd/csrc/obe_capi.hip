@@ -1,0 +1,118 @@
+// Library-level entry points: error reporting, model validation, device query, timers.
+#include <cstdio>
+#include <cstring>
+
+#include "obe_common.h"
+#include "obe_models.h"
+
+namespace obe {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+int fail(hipError_t e, const char* what) {
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return static_cast<int>(e);
+}
+
+int bad_arg(const char* what) {
+    g_last_error = what;
+    return -1;
+}
+
+struct ModelInfo {
+    int n_setdims, n_channels, n_read, n_consts;
+};
+
+}  // namespace obe
+
+using namespace obe;
+
+extern "C" {
+
+int obe_abi_version(void) { return OBE_ABI_VERSION; }
+
+const char* obe_last_error(void) { return g_last_error.c_str(); }
+
+int obe_model_validate(obe_model* m) {
+    if (!m) return bad_arg("model is NULL");
+    ModelInfo info{};
+    int rc = dispatch_model(*m, [&](auto M) -> int {
+        using Model = decltype(M);
+        info.n_setdims = Model::NS;
+        info.n_channels = Model::NC;
+        info.n_read = Model::NREAD;
+        return 0;
+    });
+    if (rc) return rc;
+    switch (m->id) {
+        case OBE_MODEL_LORENTZ: info.n_consts = 1; break;
+        case OBE_MODEL_RABI: info.n_consts = 3; break;
+        default: info.n_consts = 0; break;
+    }
+    if (m->n_setdims == 0) m->n_setdims = info.n_setdims;
+    if (m->n_channels == 0) m->n_channels = info.n_channels;
+    if (m->n_setdims != info.n_setdims) return bad_arg("model: n_setdims does not match the model");
+    if (m->n_channels != info.n_channels) return bad_arg("model: n_channels does not match the model");
+    if (m->n_params < info.n_read || m->n_params > OBE_MAX_DIMS) return bad_arg("model: n_params out of range for the model");
+    if (m->n_consts < info.n_consts || m->n_consts > OBE_MAX_CONSTS) return bad_arg("model: too few constants");
+    return 0;
+}
+
+int obe_device_info(char* name, int name_len, int* n_cu, int64_t* hbm_bytes) {
+    int dev = 0;
+    OBE_HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    OBE_HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    if (name && name_len > 0) {
+        std::snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (n_cu) *n_cu = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = static_cast<int64_t>(prop.totalGlobalMem);
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return bad_arg("current device is not gfx950");
+    return 0;
+}
+
+struct ObeTimer {
+    hipEvent_t e0, e1;
+};
+
+int obe_timer_create(void** timer) {
+    if (!timer) return bad_arg("timer is NULL");
+    ObeTimer* t = new ObeTimer;
+    hipError_t e = hipEventCreate(&t->e0);
+    if (e == hipSuccess) e = hipEventCreate(&t->e1);
+    if (e != hipSuccess) {
+        delete t;
+        return fail(e, "hipEventCreate");
+    }
+    *timer = t;
+    return 0;
+}
+
+int obe_timer_start(void* timer, void* stream) {
+    if (!timer) return bad_arg("timer is NULL");
+    OBE_HIP_TRY(hipEventRecord(static_cast<ObeTimer*>(timer)->e0, as_stream(stream)));
+    return 0;
+}
+
+int obe_timer_stop(void* timer, void* stream, float* ms) {
+    if (!timer || !ms) return bad_arg("timer/ms is NULL");
+    ObeTimer* t = static_cast<ObeTimer*>(timer);
+    OBE_HIP_TRY(hipEventRecord(t->e1, as_stream(stream)));
+    OBE_HIP_TRY(hipEventSynchronize(t->e1));
+    OBE_HIP_TRY(hipEventElapsedTime(ms, t->e0, t->e1));
+    return 0;
+}
+
+int obe_timer_destroy(void* timer) {
+    if (!timer) return 0;
+    ObeTimer* t = static_cast<ObeTimer*>(timer);
+    (void)hipEventDestroy(t->e0);
+    (void)hipEventDestroy(t->e1);
+    delete t;
+    return 0;
+}
+
+}  // extern "C"

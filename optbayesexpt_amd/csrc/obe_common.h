@@ -1,0 +1,113 @@
+// Shared device helpers for libobe_hip (gfx950 only).
+//
+// Build flags matter here: the library is compiled with -ffp-contract=off so that the
+// parity-critical streams (Bayes update, moments, resample) perform exactly the
+// NumPy sequence of correctly-rounded operations, while the flop-bound sweep kernel
+// asks for its FMAs explicitly with fma().
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/obe_hip.h"
+
+namespace obe {
+
+constexpr int kWave = 64;          // CDNA wavefront
+constexpr int kBlock = 256;        // 4 waves: one per SIMD of a CU
+constexpr int kMaxBlocks = 2048;   // 256 CUs x 8: grid cap for streaming kernels
+constexpr double kDblMax = 1.7976931348623157e308;
+
+void set_error(const std::string& msg);
+int fail(hipError_t e, const char* what);
+int bad_arg(const char* what);
+
+#define OBE_HIP_TRY(expr)                                   \
+    do {                                                    \
+        hipError_t e_ = (expr);                             \
+        if (e_ != hipSuccess) return ::obe::fail(e_, #expr); \
+    } while (0)
+
+#define OBE_CHECK_LAUNCH(name)                                  \
+    do {                                                        \
+        hipError_t e_ = hipGetLastError();                      \
+        if (e_ != hipSuccess) return ::obe::fail(e_, name);     \
+    } while (0)
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int stream_blocks(int64_t n, int per_block) {
+    int64_t b = (n + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > kMaxBlocks) b = kMaxBlocks;
+    return static_cast<int>(b);
+}
+
+// np.nan_to_num defaults: NaN -> 0, +inf -> DBL_MAX, -inf -> -DBL_MAX
+__device__ __forceinline__ double nan_to_num(double v) {
+    if (v != v) return 0.0;
+    if (v > kDblMax) return kDblMax;
+    if (v < -kDblMax) return -kDblMax;
+    return v;
+}
+
+// ---- reductions: wave shuffle, then 4 partials through LDS; fixed order => deterministic
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
+    return v;   // lane 0 holds the sum
+}
+
+// Sum of v over the block; valid in thread 0.  `red` = kBlock/kWave doubles of LDS.
+__device__ __forceinline__ double block_sum(double v, double* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < (int)(blockDim.x / kWave); ++i) s += red[i];
+    }
+    return s;
+}
+
+// Sum over the block, result broadcast to every thread.
+__device__ __forceinline__ double block_sum_all(double v, double* red) {
+    double s = block_sum(v, red);
+    __syncthreads();
+    if (threadIdx.x == 0) red[0] = s;
+    __syncthreads();
+    return red[0];
+}
+
+// Deterministic sum of a small device array by one block (every thread gets it).
+__device__ __forceinline__ double block_sum_array(const double* a, int n, double* red) {
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) v += a[i];
+    return block_sum_all(v, red);
+}
+
+// Strided view of one particle's parameters: th(i) = particles[i*ld + p].
+struct ParamRef {
+    const double* base;
+    int64_t ld;
+    __device__ __forceinline__ double operator()(int i) const { return base[(int64_t)i * ld]; }
+};
+
+// (value, index) with np.argmax ordering: NaN beats everything, then larger value,
+// ties -> lower index.
+struct Best {
+    double v;
+    int64_t i;
+};
+__device__ __forceinline__ bool better(const Best& a, const Best& b) {
+    const bool an = a.v != a.v, bn = b.v != b.v;
+    if (an != bn) return an;
+    if (an && bn) return a.i < b.i;
+    if (a.v != b.v) return a.v > b.v;
+    return a.i < b.i;
+}
+
+}  // namespace obe

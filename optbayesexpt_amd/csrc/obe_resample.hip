@@ -1,0 +1,262 @@
+// K4 — multinomial resampling of the particle cloud (particlepdf.py:260-345).
+//
+//   cdf    device prefix sum of the weights, normalised by its last element — the CDF
+//          that numpy's Generator.choice(p=w) builds (cumsum; cdf /= cdf[-1]).
+//          Blocked reduce-then-scan: 8 B read (block sums) + 8 B read + 8 B write per
+//          particle.  A strict mode replays np.cumsum's serial rounding on one
+//          wavefront for bit-identical CDFs.
+//   search searchsorted(cdf, u, side='right') per draw: binary search, ~log2(N)
+//          L2-resident probes.
+//   gather new[i,p] = old[i, idx[p]] + z[p,:] . F[i,:]  (+ optional contraction to the
+//          mean): random 8 B reads, coalesced writes.
+#include "obe_common.h"
+
+namespace obe {
+
+constexpr int kScanItems = 8;                         // contiguous weights per thread
+constexpr int kScanTile = kBlock * kScanItems;        // 2048 weights per block
+
+// Inclusive scan of one 2048-element tile held as 8 contiguous items per thread.
+// Returns the tile total in every thread.  The same routine is used by the block-sum
+// pass and by the final pass, so both see bit-identical values.
+__device__ __forceinline__ double tile_scan(double (&v)[kScanItems], double* lds /* kBlock/kWave */) {
+#pragma unroll
+    for (int k = 1; k < kScanItems; ++k) v[k] = v[k - 1] + v[k];
+    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+    // inclusive scan of the thread totals across the wave
+    double incl = v[kScanItems - 1];
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const double up = __shfl_up(incl, o, kWave);
+        if (lane >= o) incl = up + incl;
+    }
+    __syncthreads();
+    if (lane == kWave - 1) lds[wid] = incl;
+    __syncthreads();
+    double wave_off = 0.0, total = 0.0;
+#pragma unroll
+    for (int i = 0; i < kBlock / kWave; ++i) {
+        if (i < wid) wave_off += lds[i];
+        total += lds[i];
+    }
+    // exclusive prefix of this thread = inclusive prefix of its left neighbour
+    const double prev = __shfl_up(incl, 1, kWave);
+    const double thread_off = wave_off + (lane == 0 ? 0.0 : prev);
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) v[k] = thread_off + v[k];
+    return total;
+}
+
+__device__ __forceinline__ void load_tile(const double* __restrict__ w, int64_t n, int64_t base,
+                                          double (&v)[kScanItems]) {
+    const int64_t i0 = base + (int64_t)threadIdx.x * kScanItems;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) v[k] = (i0 + k < n) ? w[i0 + k] : 0.0;
+}
+
+__global__ __launch_bounds__(kBlock) void scan_block_sums(const double* __restrict__ w, int64_t n,
+                                                          double* __restrict__ block_sums) {
+    __shared__ double lds[kBlock / kWave];
+    double v[kScanItems];
+    load_tile(w, n, (int64_t)blockIdx.x * kScanTile, v);
+    const double total = tile_scan(v, lds);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// Exclusive scan of the block sums, serial in block order (nb is N/2048: 512 at 1M
+// particles), written in place; scalars[0] = total = offset[last] + sum[last].
+__global__ void scan_offsets(double* __restrict__ block_sums, int64_t nb, double* __restrict__ scalars) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double run = 0.0;
+    for (int64_t b = 0; b < nb; ++b) {
+        const double s = block_sums[b];
+        block_sums[b] = run;
+        run = run + s;
+    }
+    scalars[0] = run;
+}
+
+__global__ __launch_bounds__(kBlock) void scan_write_cdf(const double* __restrict__ w, int64_t n,
+                                                         const double* __restrict__ block_off,
+                                                         const double* __restrict__ scalars,
+                                                         double* __restrict__ cdf) {
+    __shared__ double lds[kBlock / kWave];
+    double v[kScanItems];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile;
+    load_tile(w, n, base, v);
+    tile_scan(v, lds);
+    const double off = block_off[blockIdx.x];
+    const double total = scalars[0];
+    const int64_t i0 = base + (int64_t)threadIdx.x * kScanItems;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        const int64_t i = i0 + k;
+        if (i < n) cdf[i] = (i == n - 1) ? 1.0 : (off + v[k]) / total;   // cdf[-1]/cdf[-1] == 1
+    }
+}
+
+__device__ __forceinline__ double readlane_f64(double x, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// Strict mode: c_i = fl(c_{i-1} + w_i) in index order, exactly np.cumsum.  One
+// wavefront: a coalesced 64-wide load, then 64 dependent adds fed by v_readlane.
+__global__ __launch_bounds__(kWave) void cdf_strict_kernel(const double* __restrict__ w, int64_t n,
+                                                           double* __restrict__ cdf,
+                                                           double* __restrict__ scalars) {
+    const int lane = threadIdx.x;
+    double run = 0.0;
+    for (int64_t base = 0; base < n; base += kWave) {
+        const int64_t i = base + lane;
+        const double x = (i < n) ? w[i] : 0.0;
+        double mine = 0.0;
+#pragma unroll
+        for (int k = 0; k < kWave; ++k) {
+            run = run + readlane_f64(x, k);
+            if (lane == k) mine = run;
+        }
+        if (i < n) cdf[i] = mine;
+    }
+    if (lane == 0) scalars[0] = run;
+    __threadfence_block();
+    for (int64_t base = 0; base < n; base += kWave) {
+        const int64_t i = base + lane;
+        if (i < n) cdf[i] = cdf[i] / run;
+    }
+}
+
+// idx = first i with cdf[i] > u   (searchsorted side='right')
+__global__ __launch_bounds__(kBlock) void cdf_search_kernel(const double* __restrict__ cdf, int64_t n,
+                                                            const double* __restrict__ u, int64_t nd,
+                                                            int64_t* __restrict__ idx) {
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < nd; j += (int64_t)gridDim.x * kBlock) {
+        const double uj = u[j];
+        int64_t lo = 0, hi = n;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (cdf[mid] <= uj) lo = mid + 1;
+            else hi = mid;
+        }
+        idx[j] = lo;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void gather_columns_kernel(const double* __restrict__ x, int64_t ld, int d,
+                                                                int64_t n_src, const int64_t* __restrict__ idx,
+                                                                int64_t nd, double* __restrict__ out, int64_t ld_out) {
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < nd; j += (int64_t)gridDim.x * kBlock) {
+        int64_t src = idx[j];
+        src = src < 0 ? 0 : (src >= n_src ? n_src - 1 : src);
+        for (int i = 0; i < d; ++i) out[(int64_t)i * ld_out + j] = x[(int64_t)i * ld + src];
+    }
+}
+
+struct NudgeArgs {
+    double factor[OBE_MAX_DIMS * OBE_MAX_DIMS];   // F row-major (D x D)
+    double mean[OBE_MAX_DIMS];
+    double a, one_minus_a, uniform_w;
+    int d, scale;
+};
+
+__global__ __launch_bounds__(kBlock) void resample_kernel(NudgeArgs na, const double* __restrict__ old, int64_t ld_old,
+                                                          int64_t n, const int64_t* __restrict__ idx,
+                                                          const double* __restrict__ z, double* __restrict__ out,
+                                                          int64_t ld_new, double* __restrict__ weights) {
+    const int d = na.d;
+    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (int64_t)gridDim.x * kBlock) {
+        int64_t src = idx[p];
+        src = src < 0 ? 0 : (src >= n ? n - 1 : src);
+        for (int i = 0; i < d; ++i) {
+            // (z @ F.T)[p, i]: FMA chain from zero in j order — bit-identical to the
+            // dgemm NumPy's multivariate_normal uses (checked against numpy 2.2.6/OpenBLAS)
+            double acc = 0.0;
+            for (int j = 0; j < d; ++j) acc = fma(z[p * d + j], na.factor[i * d + j], acc);
+            double v = old[(int64_t)i * ld_old + src] + acc;
+            if (na.scale) {
+                const double va = v * na.a;
+                const double mc = na.mean[i] * na.one_minus_a;
+                v = va + mc;
+            }
+            out[(int64_t)i * ld_new + p] = v;
+        }
+        weights[p] = na.uniform_w;
+    }
+}
+
+}  // namespace obe
+
+using namespace obe;
+
+extern "C" {
+
+int obe_weight_cdf(const double* d_weights, int64_t n_particles, int32_t strict_order, double* d_cdf,
+                   double* h_total, void* d_ws, int64_t ws_bytes, void* stream) {
+    if (!d_weights || !d_cdf || n_particles <= 0) return bad_arg("obe_weight_cdf: bad pointer/size");
+    const int64_t nb = (n_particles + kScanTile - 1) / kScanTile;
+    const int64_t need = (nb + 8) * (int64_t)sizeof(double);
+    if (!d_ws || ws_bytes < need) return bad_arg("obe_weight_cdf: workspace too small");
+    double* scalars = static_cast<double*>(d_ws);
+    double* block_sums = scalars + 8;
+    hipStream_t st = as_stream(stream);
+    if (strict_order) {
+        cdf_strict_kernel<<<1, kWave, 0, st>>>(d_weights, n_particles, d_cdf, scalars);
+        OBE_CHECK_LAUNCH("cdf_strict_kernel");
+    } else {
+        scan_block_sums<<<(unsigned)nb, kBlock, 0, st>>>(d_weights, n_particles, block_sums);
+        OBE_CHECK_LAUNCH("scan_block_sums");
+        scan_offsets<<<1, kWave, 0, st>>>(block_sums, nb, scalars);
+        OBE_CHECK_LAUNCH("scan_offsets");
+        scan_write_cdf<<<(unsigned)nb, kBlock, 0, st>>>(d_weights, n_particles, block_sums, scalars, d_cdf);
+        OBE_CHECK_LAUNCH("scan_write_cdf");
+    }
+    if (h_total) {
+        OBE_HIP_TRY(hipMemcpyAsync(h_total, scalars, sizeof(double), hipMemcpyDeviceToHost, st));
+        OBE_HIP_TRY(hipStreamSynchronize(st));
+    }
+    return 0;
+}
+
+int obe_cdf_search(const double* d_cdf, int64_t n, const double* d_uniforms, int64_t n_draws, int64_t* d_idx_out,
+                   void* stream) {
+    if (!d_cdf || !d_uniforms || !d_idx_out || n <= 0 || n_draws <= 0) return bad_arg("obe_cdf_search: bad pointer/size");
+    cdf_search_kernel<<<stream_blocks(n_draws, kBlock), kBlock, 0, as_stream(stream)>>>(d_cdf, n, d_uniforms, n_draws,
+                                                                                         d_idx_out);
+    OBE_CHECK_LAUNCH("cdf_search_kernel");
+    return 0;
+}
+
+int obe_gather_columns(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t n_particles,
+                       const int64_t* d_idx, int64_t n_draws, double* d_out, int64_t ld_out, void* stream) {
+    if (!d_particles || !d_idx || !d_out || n_draws <= 0 || n_dims < 1 || n_particles <= 0)
+        return bad_arg("obe_gather_columns: bad pointer/size");
+    gather_columns_kernel<<<stream_blocks(n_draws, kBlock), kBlock, 0, as_stream(stream)>>>(
+        d_particles, ld_p, n_dims, n_particles, d_idx, n_draws, d_out, ld_out);
+    OBE_CHECK_LAUNCH("gather_columns_kernel");
+    return 0;
+}
+
+int obe_resample_particles(const double* d_old, int64_t ld_old, int32_t n_dims, int64_t n_particles,
+                           const int64_t* d_idx, const double* d_normals, const double* h_factor,
+                           const double* h_mean, double a_param, int32_t scale, double* d_new, int64_t ld_new,
+                           double* d_weights, void* stream) {
+    if (!d_old || !d_idx || !d_normals || !h_factor || !h_mean || !d_new || !d_weights || n_particles <= 0)
+        return bad_arg("obe_resample_particles: bad pointer/size");
+    if (n_dims < 1 || n_dims > OBE_MAX_DIMS) return bad_arg("obe_resample_particles: n_dims must be 1..16");
+    if (d_old == d_new) return bad_arg("obe_resample_particles: in-place gather is not supported");
+    NudgeArgs na{};
+    na.d = n_dims;
+    na.scale = scale;
+    na.a = a_param;
+    na.one_minus_a = 1 - a_param;
+    na.uniform_w = 1.0 / (double)n_particles;
+    for (int i = 0; i < n_dims * n_dims; ++i) na.factor[i] = h_factor[i];
+    for (int i = 0; i < n_dims; ++i) na.mean[i] = h_mean[i];
+    resample_kernel<<<stream_blocks(n_particles, kBlock), kBlock, 0, as_stream(stream)>>>(
+        na, d_old, ld_old, n_particles, d_idx, d_normals, d_new, ld_new, d_weights);
+    OBE_CHECK_LAUNCH("resample_kernel");
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,487 @@
+// K1 + K5 — the utility sweep: model evaluated over the settings x draws grid, reduced to
+// the per-setting variance of the predicted output, then utility and argmax
+// (obe_base.py:463-489 yvar_from_parameter_draws, :628-655 utility_variance,
+// :733-756 opt_setting).
+//
+// Mapping (gfx950):
+//   * lane <-> setting.  Each thread owns SPT settings in registers (prepared setting,
+//     shift, and the two running moments per channel); nothing is reduced across lanes
+//     inside the loop.
+//   * the particle axis is streamed: a workgroup stages a tile of particles with
+//     coalesced loads of the (D+1) SoA rows, packs each particle once (per-particle
+//     divisions hoisted out of the grid) into an AoS LDS tile, and every lane then
+//     reads the same LDS address (broadcast, conflict-free) per particle.
+//   * grid = setting tiles (x) x particle chunks (y): at 65 536 settings there are only
+//     64 setting tiles of 1024, so the particle axis is split to fill 256 CUs; chunk
+//     partial moments share one shift per setting, so they simply add (finalize pass).
+//   * arithmetic: FP64 VALU only (no contraction over a shared operand => no MFMA).
+//     The roof is the FP64 vector rate, not HBM: compulsory traffic is
+//     8(D+1)N_p + 8 S N_s bytes for N_s*N_p evaluations.
+//
+// Variance numerics: moments are accumulated about a per-setting shift
+// c_s = model(x_s; mean parameters), so  var = (S2 - S1^2/W)/W  does not cancel
+// catastrophically (np.var is two-pass; the shift plays the role of its first pass).
+#include <cstring>
+
+#include "obe_common.h"
+#include "obe_models.h"
+
+namespace obe {
+
+constexpr int kSweepLdsDoubles = 4096;   // 32 KiB tile per workgroup -> 4-5 workgroups per CU
+constexpr int kMaxChunks = 256;
+
+struct SweepPlan {
+    int spt;           // settings per thread
+    int tiles_x;       // setting tiles
+    int nchunks;       // particle chunks (grid.y)
+    int64_t chunk;     // draws per chunk
+};
+
+static SweepPlan plan_sweep(int64_t ns, int64_t nd) {
+    SweepPlan p;
+    p.spt = ns >= 4096 ? 4 : (ns >= 1024 ? 2 : 1);
+    p.tiles_x = static_cast<int>((ns + (int64_t)kBlock * p.spt - 1) / ((int64_t)kBlock * p.spt));
+    int64_t want = (1024 + p.tiles_x - 1) / p.tiles_x;       // ~4 workgroups per CU in total
+    int64_t cap = std::min<int64_t>(kMaxChunks, (nd + 255) / 256);
+    if (cap < 1) cap = 1;
+    p.nchunks = static_cast<int>(std::max<int64_t>(1, std::min(want, cap)));
+    p.chunk = (nd + p.nchunks - 1) / p.nchunks;
+    p.chunk = (p.chunk + 63) / 64 * 64;
+    p.nchunks = static_cast<int>((nd + p.chunk - 1) / p.chunk);
+    return p;
+}
+
+static int64_t sweep_ws_doubles(int64_t ns, int64_t nd, int nc) {
+    const SweepPlan p = plan_sweep(ns, nd);
+    return 2 * (int64_t)p.nchunks * nc * ns      // partial S1, S2
+           + 2 * (int64_t)kMaxBlocks + 16;        // argmax partials + scalars
+}
+
+struct SweepArgs {
+    obe_model m;
+    const double* settings;
+    int64_t ld_s, ns;
+    const double* particles;
+    int64_t ld_p;
+    const double* weights;
+    const int64_t* draw_idx;   // NULL: all particles, weighted
+    int64_t nd;                // draws (== n_particles in full mode)
+    int64_t n_particles;
+    double uniform_w;          // 1/nd in draws mode
+    const double* moments;     // obe_moments output: mean parameters at +2
+    int64_t chunk;
+    int tile;                  // particles per LDS tile
+    double* part1;
+    double* part2;
+};
+
+template <class M, int SPT>
+__global__ __launch_bounds__(kBlock) void sweep_kernel(SweepArgs a) {
+    constexpr int NC = M::NC, NXS = M::NXS, NPK = M::NPK;
+    constexpr int NPKW = (NPK + 1 + 1) & ~1;   // packed particle + weight, padded to 16 B
+    extern __shared__ __attribute__((aligned(16))) double tile[];
+
+    double xs[SPT][NXS], cs[SPT][NC], s1[SPT][NC], s2[SPT][NC];
+    const double* __restrict__ thbar = a.moments + 2;   // weighted-mean parameters (K3 output)
+
+    {   // prepared settings and the per-setting shift
+        double pkbar[NPK];
+        M::pack(ParamRef{thbar, 1}, thbar, a.m, pkbar);
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) {
+            int64_t s = ((int64_t)blockIdx.x * SPT + j) * kBlock + threadIdx.x;
+            if (s >= a.ns) s = a.ns - 1;
+            double x[M::NS];
+#pragma unroll
+            for (int k = 0; k < M::NS; ++k) x[k] = a.settings[(int64_t)k * a.ld_s + s];
+            M::prep_setting(x, a.m, xs[j]);
+            model_eval_fast<M>(xs[j], pkbar, a.m, cs[j]);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) s1[j][c] = s2[j][c] = 0.0;
+        }
+    }
+
+    const int64_t p_begin = (int64_t)blockIdx.y * a.chunk;
+    const int64_t p_end = p_begin + a.chunk < a.nd ? p_begin + a.chunk : a.nd;
+    for (int64_t t0 = p_begin; t0 < p_end; t0 += a.tile) {
+        const int n = static_cast<int>(p_end - t0 < a.tile ? p_end - t0 : a.tile);
+        __syncthreads();   // previous tile fully consumed
+        for (int i = threadIdx.x; i < n; i += kBlock) {
+            const int64_t p = t0 + i;
+            int64_t src = p;
+            double w;
+            if (a.draw_idx) {
+                src = a.draw_idx[p];
+                src = src < 0 ? 0 : (src >= a.n_particles ? a.n_particles - 1 : src);
+                w = a.uniform_w;
+            } else {
+                w = a.weights[p];
+            }
+            double pk[NPK];
+            M::pack(ParamRef{a.particles + src, a.ld_p}, thbar, a.m, pk);
+#pragma unroll
+            for (int k = 0; k < NPK; ++k) tile[i * NPKW + k] = pk[k];
+            tile[i * NPKW + NPK] = w;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int i = 0; i < n; ++i) {
+            double pk[NPK];
+#pragma unroll
+            for (int k = 0; k < NPK; ++k) pk[k] = tile[i * NPKW + k];   // same address in every lane: LDS broadcast
+            const double w = tile[i * NPKW + NPK];
+#pragma unroll
+            for (int j = 0; j < SPT; ++j) {
+                double y[NC];
+                model_eval_fast<M>(xs[j], pk, a.m, y);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const double u = y[c] - cs[j][c];
+                    const double wu = w * u;
+                    s1[j][c] += wu;
+                    s2[j][c] = fma(wu, u, s2[j][c]);
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) {
+        const int64_t s = ((int64_t)blockIdx.x * SPT + j) * kBlock + threadIdx.x;
+        if (s < a.ns) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int64_t o = ((int64_t)blockIdx.y * NC + c) * a.ns + s;
+                a.part1[o] = s1[j][c];
+                a.part2[o] = s2[j][c];
+            }
+        }
+    }
+}
+
+struct UtilArgs {
+    const double* noise_var;
+    int64_t noise_ld;     // 0: one value per channel
+    const double* cost;   // NULL: scalar
+    double cost_scalar;
+};
+
+__device__ __forceinline__ double utility_of(const double* var, int nc, int64_t s, const UtilArgs& u) {
+    // np.sum(var_p / var_n, axis=0) / cost   (obe_base.py:654-655)
+    double acc = 0.0;
+    for (int c = 0; c < nc; ++c) {
+        const double nv = u.noise_ld ? u.noise_var[(int64_t)c * u.noise_ld + s] : u.noise_var[c];
+        acc = acc + var[c] / nv;
+    }
+    return acc / (u.cost ? u.cost[s] : u.cost_scalar);
+}
+
+__device__ __forceinline__ void block_argmax(Best b, double* bv, int64_t* bi) {
+    __shared__ double sv[kBlock];
+    __shared__ int64_t si[kBlock];
+    sv[threadIdx.x] = b.v;
+    si[threadIdx.x] = b.i;
+    __syncthreads();
+    for (int o = kBlock / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            Best x{sv[threadIdx.x], si[threadIdx.x]}, y{sv[threadIdx.x + o], si[threadIdx.x + o]};
+            if (better(y, x)) {
+                sv[threadIdx.x] = y.v;
+                si[threadIdx.x] = y.i;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        bv[blockIdx.x] = sv[0];
+        bi[blockIdx.x] = si[0];
+    }
+}
+
+// folds the chunk partials -> yvar, utility; per-block first-max
+__global__ __launch_bounds__(kBlock) void sweep_finalize(const double* __restrict__ part1,
+                                                         const double* __restrict__ part2, int nchunks, int nc,
+                                                         int64_t ns, const double* __restrict__ moments,
+                                                         int full_mode, UtilArgs ua, double* __restrict__ yvar,
+                                                         double* __restrict__ utility, double* __restrict__ bv,
+                                                         int64_t* __restrict__ bi) {
+    const double W = full_mode ? moments[0] : 1.0;
+    Best best{-INFINITY, INT64_MAX};
+    for (int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x; s < ns; s += (int64_t)gridDim.x * kBlock) {
+        double var[OBE_MAX_CHANNELS];
+        for (int c = 0; c < nc; ++c) {
+            double a1 = 0.0, a2 = 0.0;
+            for (int k = 0; k < nchunks; ++k) {
+                const int64_t o = ((int64_t)k * nc + c) * ns + s;
+                a1 += part1[o];
+                a2 += part2[o];
+            }
+            const double mu = a1 / W;
+            double v = (a2 - a1 * mu) / W;
+            v = v > 0.0 ? v : 0.0;
+            var[c] = v;
+            yvar[(int64_t)c * ns + s] = v;
+        }
+        const double u = utility_of(var, nc, s, ua);
+        utility[s] = u;
+        Best cand{u, s};
+        if (better(cand, best)) best = cand;
+    }
+    block_argmax(best, bv, bi);
+}
+
+__global__ __launch_bounds__(kBlock) void utility_kernel(const double* __restrict__ yvar, int nc, int64_t ns,
+                                                         UtilArgs ua, double* __restrict__ utility,
+                                                         double* __restrict__ bv, int64_t* __restrict__ bi) {
+    Best best{-INFINITY, INT64_MAX};
+    for (int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x; s < ns; s += (int64_t)gridDim.x * kBlock) {
+        double var[OBE_MAX_CHANNELS];
+        for (int c = 0; c < nc; ++c) var[c] = yvar[(int64_t)c * ns + s];
+        const double u = utility_of(var, nc, s, ua);
+        utility[s] = u;
+        Best cand{u, s};
+        if (better(cand, best)) best = cand;
+    }
+    block_argmax(best, bv, bi);
+}
+
+__global__ __launch_bounds__(kBlock) void argmax_kernel(const double* __restrict__ v, int64_t n,
+                                                        double* __restrict__ bv, int64_t* __restrict__ bi) {
+    Best best{-INFINITY, INT64_MAX};
+    for (int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x; s < n; s += (int64_t)gridDim.x * kBlock) {
+        Best cand{v[s], s};
+        if (better(cand, best)) best = cand;
+    }
+    block_argmax(best, bv, bi);
+}
+
+// one block: first-max over the block partials -> scalars {value, index (as int64 bits)}
+__global__ __launch_bounds__(kBlock) void argmax_fold(const double* __restrict__ bv, const int64_t* __restrict__ bi,
+                                                      int nb, double* __restrict__ out_v,
+                                                      int64_t* __restrict__ out_i) {
+    Best best{-INFINITY, INT64_MAX};
+    for (int b = threadIdx.x; b < nb; b += kBlock) {
+        Best cand{bv[b], bi[b]};
+        if (better(cand, best)) best = cand;
+    }
+    block_argmax(best, out_v, out_i);   // gridDim.x == 1 -> writes element 0
+}
+
+// np.var(utility_y_space, axis=0): two-pass over the (small) draw axis
+__global__ __launch_bounds__(kBlock) void yspace_var_kernel(const double* __restrict__ ysp, int64_t nd,
+                                                            int64_t row /* C*Ns */, double* __restrict__ yvar) {
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < row; e += (int64_t)gridDim.x * kBlock) {
+        double sum = 0.0;
+        for (int64_t d = 0; d < nd; ++d) sum += ysp[d * row + e];
+        const double mean = sum / (double)nd;
+        double acc = 0.0;
+        for (int64_t d = 0; d < nd; ++d) {
+            const double dv = ysp[d * row + e] - mean;
+            acc += dv * dv;
+        }
+        yvar[e] = acc / (double)nd;
+    }
+}
+
+struct SweepWs {
+    double* part1;
+    double* part2;
+    double* bv;
+    int64_t* bi;
+    double* out_v;
+    int64_t* out_i;
+};
+
+static int carve_sweep_ws(void* d_ws, int64_t ws_bytes, int64_t part_doubles, SweepWs& w) {
+    const int64_t need = (2 * part_doubles + 2 * (int64_t)kMaxBlocks + 16) * sizeof(double);
+    if (!d_ws || ws_bytes < need) return bad_arg("sweep workspace too small");
+    double* base = static_cast<double*>(d_ws);
+    w.out_v = base;                                     // [0]
+    w.out_i = reinterpret_cast<int64_t*>(base + 8);     // [8]
+    w.bv = base + 16;
+    w.bi = reinterpret_cast<int64_t*>(base + 16 + kMaxBlocks);
+    w.part1 = base + 16 + 2 * kMaxBlocks;
+    w.part2 = w.part1 + part_doubles;
+    return 0;
+}
+
+static int read_best(const SweepWs& w, double* h_best, int64_t* h_best_idx, hipStream_t st) {
+    if (!h_best && !h_best_idx) return 0;
+    double tmp[9];
+    OBE_HIP_TRY(hipMemcpyAsync(tmp, w.out_v, 9 * sizeof(double), hipMemcpyDeviceToHost, st));
+    OBE_HIP_TRY(hipStreamSynchronize(st));
+    if (h_best) *h_best = tmp[0];
+    if (h_best_idx) memcpy(h_best_idx, &tmp[8], sizeof(int64_t));
+    return 0;
+}
+
+template <class M>
+static int launch_sweep(const SweepPlan& p, SweepArgs& a, hipStream_t st) {
+    constexpr int NPKW = (M::NPK + 2) & ~1;
+    int tile = kSweepLdsDoubles / NPKW;
+    tile = tile / 64 * 64;
+    a.tile = tile;
+    const size_t lds = (size_t)tile * NPKW * sizeof(double);
+    dim3 grid(p.tiles_x, p.nchunks);
+    switch (p.spt) {
+        case 4: sweep_kernel<M, 4><<<grid, kBlock, lds, st>>>(a); break;
+        case 2: sweep_kernel<M, 2><<<grid, kBlock, lds, st>>>(a); break;
+        default: sweep_kernel<M, 1><<<grid, kBlock, lds, st>>>(a); break;
+    }
+    OBE_CHECK_LAUNCH("sweep_kernel");
+    return 0;
+}
+
+static int prepare_sweep(const obe_model* m, obe_model& mm, const double* d_settings, int64_t ld_s, int64_t ns,
+                         const double* d_particles, int64_t ld_p, int64_t np, const double* d_weights,
+                         const int64_t* d_draw_idx, int64_t n_draws, const double* d_moments, void* d_ws,
+                         int64_t ws_bytes, SweepPlan& plan, SweepArgs& a, SweepWs& w) {
+    if (!m || !d_settings || !d_particles || !d_moments || ns <= 0 || np <= 0) return bad_arg("sweep: bad pointer/size");
+    if (!d_draw_idx && !d_weights) return bad_arg("sweep: full mode needs weights");
+    mm = *m;
+    if (int rc = obe_model_validate(&mm)) return rc;
+    const int64_t nd = d_draw_idx ? n_draws : np;
+    if (nd <= 0) return bad_arg("sweep: n_draws must be positive");
+    plan = plan_sweep(ns, nd);
+    const int64_t part = (int64_t)plan.nchunks * mm.n_channels * ns;
+    if (int rc = carve_sweep_ws(d_ws, ws_bytes, part, w)) return rc;
+    a.m = mm;
+    a.settings = d_settings;
+    a.ld_s = ld_s;
+    a.ns = ns;
+    a.particles = d_particles;
+    a.ld_p = ld_p;
+    a.weights = d_weights;
+    a.draw_idx = d_draw_idx;
+    a.nd = nd;
+    a.n_particles = np;
+    a.uniform_w = 1.0 / (double)nd;
+    a.moments = d_moments;
+    a.chunk = plan.chunk;
+    a.part1 = w.part1;
+    a.part2 = w.part2;
+    return 0;
+}
+
+}  // namespace obe
+
+using namespace obe;
+
+extern "C" {
+
+int64_t obe_workspace_bytes(int64_t n_particles, int64_t n_settings, int32_t n_channels, int32_t n_dims) {
+    if (n_particles < 1) n_particles = 1;
+    if (n_settings < 1) n_settings = 1;
+    if (n_channels < 1) n_channels = 1;
+    if (n_dims < 1) n_dims = 1;
+    int64_t d = sweep_ws_doubles(n_settings, n_particles, n_channels);
+    const int64_t nv = std::max<int64_t>(2 + 2 * n_dims, (int64_t)n_dims * (n_dims + 1) / 2);
+    d = std::max<int64_t>(d, 1024 * nv + nv);                       // moments
+    d = std::max<int64_t>(d, (n_particles + 2047) / 2048 + 8);      // cdf block sums
+    d = std::max<int64_t>(d, 2 * (int64_t)kMaxBlocks + 8);          // update partials
+    return (d + 64) * (int64_t)sizeof(double);
+}
+
+int obe_sweep_utility(const obe_model* m, const double* d_settings, int64_t ld_s, int64_t n_settings,
+                      const double* d_particles, int64_t ld_p, int64_t n_particles, const double* d_weights,
+                      const int64_t* d_draw_idx, int64_t n_draws, const double* d_moments,
+                      const double* d_noise_var, int64_t noise_ld, const double* d_cost, double cost_scalar,
+                      double* d_yvar, double* d_utility, double* h_best, int64_t* h_best_idx, void* d_ws,
+                      int64_t ws_bytes, void* stream) {
+    if (!d_noise_var || !d_yvar || !d_utility) return bad_arg("obe_sweep_utility: bad output/noise pointer");
+    obe_model mm;
+    SweepPlan plan;
+    SweepArgs a{};
+    SweepWs w;
+    if (int rc = prepare_sweep(m, mm, d_settings, ld_s, n_settings, d_particles, ld_p, n_particles, d_weights,
+                               d_draw_idx, n_draws, d_moments, d_ws, ws_bytes, plan, a, w))
+        return rc;
+    hipStream_t st = as_stream(stream);
+    int rc = dispatch_model(mm, [&](auto M) -> int { return launch_sweep<decltype(M)>(plan, a, st); });
+    if (rc) return rc;
+    UtilArgs ua{d_noise_var, noise_ld, d_cost, cost_scalar};
+    const int nb = stream_blocks(n_settings, kBlock);
+    sweep_finalize<<<nb, kBlock, 0, st>>>(w.part1, w.part2, plan.nchunks, mm.n_channels, n_settings, d_moments,
+                                          d_draw_idx == nullptr, ua, d_yvar, d_utility, w.bv, w.bi);
+    OBE_CHECK_LAUNCH("sweep_finalize");
+    argmax_fold<<<1, kBlock, 0, st>>>(w.bv, w.bi, nb, w.out_v, w.out_i);
+    OBE_CHECK_LAUNCH("argmax_fold");
+    return read_best(w, h_best, h_best_idx, st);
+}
+
+int obe_sweep_kernel_time(const obe_model* m, const double* d_settings, int64_t ld_s, int64_t n_settings,
+                          const double* d_particles, int64_t ld_p, int64_t n_particles, const double* d_weights,
+                          const double* d_moments, void* d_ws, int64_t ws_bytes, int32_t iters, float* h_ms_avg,
+                          void* stream) {
+    if (!h_ms_avg || iters < 1) return bad_arg("obe_sweep_kernel_time: bad arguments");
+    obe_model mm;
+    SweepPlan plan;
+    SweepArgs a{};
+    SweepWs w;
+    if (int rc = prepare_sweep(m, mm, d_settings, ld_s, n_settings, d_particles, ld_p, n_particles, d_weights,
+                               nullptr, 0, d_moments, d_ws, ws_bytes, plan, a, w))
+        return rc;
+    hipStream_t st = as_stream(stream);
+    hipEvent_t e0, e1;
+    OBE_HIP_TRY(hipEventCreate(&e0));
+    OBE_HIP_TRY(hipEventCreate(&e1));
+    int rc = dispatch_model(mm, [&](auto M) -> int { return launch_sweep<decltype(M)>(plan, a, st); });   // warm
+    if (!rc) {
+        (void)hipEventRecord(e0, st);
+        for (int i = 0; i < iters && !rc; ++i)
+            rc = dispatch_model(mm, [&](auto M) -> int { return launch_sweep<decltype(M)>(plan, a, st); });
+        (void)hipEventRecord(e1, st);
+        hipError_t e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e != hipSuccess) rc = fail(e, "sweep timing");
+        *h_ms_avg = ms / (float)iters;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
+int obe_yspace_variance(const double* d_yspace, int64_t n_draws, int32_t n_channels, int64_t n_settings,
+                        double* d_yvar, void* stream) {
+    if (!d_yspace || !d_yvar || n_draws <= 0 || n_channels < 1 || n_settings <= 0)
+        return bad_arg("obe_yspace_variance: bad pointer/size");
+    const int64_t row = (int64_t)n_channels * n_settings;
+    yspace_var_kernel<<<stream_blocks(row, kBlock), kBlock, 0, as_stream(stream)>>>(d_yspace, n_draws, row, d_yvar);
+    OBE_CHECK_LAUNCH("yspace_var_kernel");
+    return 0;
+}
+
+int obe_utility_argmax(const double* d_yvar, int32_t n_channels, int64_t n_settings, const double* d_noise_var,
+                       int64_t noise_ld, const double* d_cost, double cost_scalar, double* d_utility,
+                       double* h_best, int64_t* h_best_idx, void* d_ws, int64_t ws_bytes, void* stream) {
+    if (!d_yvar || !d_noise_var || !d_utility || n_settings <= 0 || n_channels < 1 || n_channels > OBE_MAX_CHANNELS)
+        return bad_arg("obe_utility_argmax: bad pointer/size");
+    SweepWs w;
+    if (int rc = carve_sweep_ws(d_ws, ws_bytes, 0, w)) return rc;
+    hipStream_t st = as_stream(stream);
+    UtilArgs ua{d_noise_var, noise_ld, d_cost, cost_scalar};
+    const int nb = stream_blocks(n_settings, kBlock);
+    utility_kernel<<<nb, kBlock, 0, st>>>(d_yvar, n_channels, n_settings, ua, d_utility, w.bv, w.bi);
+    OBE_CHECK_LAUNCH("utility_kernel");
+    argmax_fold<<<1, kBlock, 0, st>>>(w.bv, w.bi, nb, w.out_v, w.out_i);
+    OBE_CHECK_LAUNCH("argmax_fold");
+    return read_best(w, h_best, h_best_idx, st);
+}
+
+int obe_argmax(const double* d_v, int64_t n, double* h_best, int64_t* h_best_idx, void* d_ws, int64_t ws_bytes,
+               void* stream) {
+    if (!d_v || n <= 0) return bad_arg("obe_argmax: bad pointer/size");
+    SweepWs w;
+    if (int rc = carve_sweep_ws(d_ws, ws_bytes, 0, w)) return rc;
+    hipStream_t st = as_stream(stream);
+    const int nb = stream_blocks(n, kBlock);
+    argmax_kernel<<<nb, kBlock, 0, st>>>(d_v, n, w.bv, w.bi);
+    OBE_CHECK_LAUNCH("argmax_kernel");
+    argmax_fold<<<1, kBlock, 0, st>>>(w.bv, w.bi, nb, w.out_v, w.out_i);
+    OBE_CHECK_LAUNCH("argmax_fold");
+    return read_best(w, h_best, h_best_idx, st);
+}
+
+}  // extern "C"

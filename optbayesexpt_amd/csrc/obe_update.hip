@@ -1,0 +1,479 @@
+// K2 — Bayes update of the particle weights, plus the model-evaluation wrappers and
+// the OptBayesExptNoiseParameter constraint mask.  All HBM-bound streams:
+//   pass A  read (D+1) rows, write t = nan_to_num(w * L), block partial sums of t
+//   pass B  read t, write w' = nan_to_num(t / sum t), block partial sums of w'^2
+//   pass C  one block folds the partials into two scalars
+// Algorithmic traffic per particle: 8(D_read + 1) + 8 (A) + 16 (B) bytes.
+// Reductions are fixed-order (no float atomics) so results are run-to-run identical.
+#include "obe_common.h"
+#include "obe_models.h"
+
+namespace obe {
+
+struct LikArgs {
+    int n_ch;          // channels entering the likelihood product
+    int use_rows;      // sigma from particle rows (NoiseParameter) instead of sigma[]
+    int use_choke;
+    int noise_rows[OBE_MAX_CHANNELS];
+    double y_meas[OBE_MAX_CHANNELS];
+    double sigma[OBE_MAX_CHANNELS];
+    double choke;
+};
+
+// obe_base.py:269-271 and :451-461 (obe_noiseparam.py:109-120 for use_rows)
+__device__ __forceinline__ double likelihood_of(const double* y, const LikArgs& a,
+                                                const double* particles, int64_t ld, int64_t p) {
+    double lk = 1.0;
+    for (int ch = 0; ch < a.n_ch; ++ch) {
+        const double s = a.use_rows ? particles[(int64_t)a.noise_rows[ch] * ld + p] : a.sigma[ch];
+        const double z = (y[ch] - a.y_meas[ch]) / s;
+        const double e = exp(-(z * z) / 2.0);
+        lk = lk * (e / s);
+    }
+    if (a.use_choke) lk = pow(lk, a.choke);
+    return lk;
+}
+
+struct SettingArg {
+    double x[OBE_MAX_SETDIMS];
+};
+
+// pass A, model fused
+template <class M>
+__global__ __launch_bounds__(kBlock) void update_model_kernel(
+    obe_model m, SettingArg st, LikArgs la, const double* __restrict__ particles, int64_t ld,
+    int64_t n, double* __restrict__ weights, double* __restrict__ partials) {
+    __shared__ double red[kBlock / kWave];
+    double acc = 0.0;
+    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (int64_t)gridDim.x * kBlock) {
+        double y[M::NC];
+        M::eval(st.x, ParamRef{particles + p, ld}, m, y);
+        const double t = nan_to_num(weights[p] * likelihood_of(y, la, particles, ld, p));
+        weights[p] = t;
+        acc += t;
+    }
+    const double s = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// pass A, model output supplied (C, N) with ld_y between channels
+__global__ __launch_bounds__(kBlock) void update_y_kernel(
+    LikArgs la, int n_channels, const double* __restrict__ yv, int64_t ld_y,
+    const double* __restrict__ particles, int64_t ld, int64_t n, double* __restrict__ weights,
+    double* __restrict__ partials) {
+    __shared__ double red[kBlock / kWave];
+    double acc = 0.0;
+    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (int64_t)gridDim.x * kBlock) {
+        double y[OBE_MAX_CHANNELS];
+        for (int c = 0; c < n_channels; ++c) y[c] = yv[(int64_t)c * ld_y + p];
+        const double t = nan_to_num(weights[p] * likelihood_of(y, la, particles, ld, p));
+        weights[p] = t;
+        acc += t;
+    }
+    const double s = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// pass A, likelihood supplied
+__global__ __launch_bounds__(kBlock) void update_lik_kernel(const double* __restrict__ lik, int64_t n,
+                                                            double* __restrict__ weights,
+                                                            double* __restrict__ partials) {
+    __shared__ double red[kBlock / kWave];
+    double acc = 0.0;
+    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (int64_t)gridDim.x * kBlock) {
+        const double t = nan_to_num(weights[p] * lik[p]);
+        weights[p] = t;
+        acc += t;
+    }
+    const double s = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// pass B: normalise by the (deterministically re-folded) total; partial sums of w'^2
+__global__ __launch_bounds__(kBlock) void normalize_kernel(const double* __restrict__ partials_in,
+                                                           int n_partials, int64_t n,
+                                                           double* __restrict__ weights,
+                                                           double* __restrict__ partials_out) {
+    __shared__ double red[kBlock / kWave];
+    const double total = block_sum_array(partials_in, n_partials, red);
+    double acc = 0.0;
+    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (int64_t)gridDim.x * kBlock) {
+        const double w = nan_to_num(weights[p] / total);
+        weights[p] = w;
+        acc += nan_to_num(w * w);
+    }
+    const double s = block_sum(acc, red);
+    if (threadIdx.x == 0) partials_out[blockIdx.x] = s;
+}
+
+// pass C: scalars[0] = sum t, scalars[1] = sum w'^2
+__global__ __launch_bounds__(kBlock) void fold2_kernel(const double* __restrict__ pa, const double* __restrict__ pb,
+                                                       int n_partials, double* __restrict__ scalars) {
+    __shared__ double red[kBlock / kWave];
+    const double a = block_sum_array(pa, n_partials, red);
+    __syncthreads();
+    const double b = block_sum_array(pb, n_partials, red);
+    if (threadIdx.x == 0) {
+        scalars[0] = a;
+        scalars[1] = b;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void weight_sums_kernel(const double* __restrict__ weights, int64_t n,
+                                                             double* __restrict__ pa, double* __restrict__ pb) {
+    __shared__ double red[kBlock / kWave];
+    double a = 0.0, b = 0.0;
+    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (int64_t)gridDim.x * kBlock) {
+        const double w = weights[p];
+        a += nan_to_num(w * w);
+        b += w;
+    }
+    const double sa = block_sum(a, red);
+    __syncthreads();
+    const double sb = block_sum(b, red);
+    if (threadIdx.x == 0) {
+        pa[blockIdx.x] = sa;
+        pb[blockIdx.x] = sb;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void likelihood_y_kernel(LikArgs la, int n_channels,
+                                                              const double* __restrict__ yv, int64_t ld_y,
+                                                              const double* __restrict__ particles, int64_t ld,
+                                                              int64_t n, double* __restrict__ out) {
+    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (int64_t)gridDim.x * kBlock) {
+        double y[OBE_MAX_CHANNELS];
+        for (int c = 0; c < n_channels; ++c) y[c] = yv[(int64_t)c * ld_y + p];
+        out[p] = likelihood_of(y, la, particles, ld, p);
+    }
+}
+
+template <class M>
+__global__ __launch_bounds__(kBlock) void eval_particles_kernel(obe_model m, SettingArg st,
+                                                                const double* __restrict__ particles, int64_t ld,
+                                                                int64_t n, double* __restrict__ out, int64_t ld_y) {
+    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (int64_t)gridDim.x * kBlock) {
+        double y[M::NC];
+        M::eval(st.x, ParamRef{particles + p, ld}, m, y);
+#pragma unroll
+        for (int c = 0; c < M::NC; ++c) out[(int64_t)c * ld_y + p] = y[c];
+    }
+}
+
+struct ParamArg {
+    double th[OBE_MAX_DIMS];
+};
+
+template <class M>
+__global__ __launch_bounds__(kBlock) void eval_settings_kernel(obe_model m, ParamArg pa,
+                                                               const double* __restrict__ settings, int64_t ld_s,
+                                                               int64_t n, double* __restrict__ out, int64_t ld_y) {
+    for (int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x; s < n; s += (int64_t)gridDim.x * kBlock) {
+        double x[M::NS], y[M::NC];
+#pragma unroll
+        for (int k = 0; k < M::NS; ++k) x[k] = settings[(int64_t)k * ld_s + s];
+        M::eval(x, ParamRef{pa.th, 1}, m, y);
+#pragma unroll
+        for (int c = 0; c < M::NC; ++c) out[(int64_t)c * ld_y + s] = y[c];
+    }
+}
+
+// ---- OptBayesExptNoiseParameter.enforce_parameter_constraints (obe_noiseparam.py:57-79)
+struct RowsArg {
+    int n;
+    int rows[OBE_MAX_DIMS];
+};
+
+__global__ __launch_bounds__(kBlock) void mask_kernel(RowsArg ra, const double* __restrict__ particles, int64_t ld,
+                                                      int64_t n, double* __restrict__ weights,
+                                                      double* __restrict__ psum, double* __restrict__ pcount) {
+    __shared__ double red[kBlock / kWave];
+    double acc = 0.0, cnt = 0.0;
+    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (int64_t)gridDim.x * kBlock) {
+        bool bad = false;
+        for (int k = 0; k < ra.n; ++k) bad = bad || (particles[(int64_t)ra.rows[k] * ld + p] <= 0.0);
+        double w = weights[p];
+        if (bad) {
+            w = 0.0;
+            weights[p] = 0.0;
+            cnt += 1.0;
+        }
+        acc += w;
+    }
+    const double s = block_sum(acc, red);
+    __syncthreads();
+    const double c = block_sum(cnt, red);
+    if (threadIdx.x == 0) {
+        psum[blockIdx.x] = s;
+        pcount[blockIdx.x] = c;
+    }
+}
+
+// renormalise only if anything was zeroed (scalars[1] = count)
+__global__ __launch_bounds__(kBlock) void mask_renorm_kernel(const double* __restrict__ scalars, int64_t n,
+                                                             double* __restrict__ weights) {
+    if (scalars[1] == 0.0) return;
+    const double total = scalars[0];
+    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (int64_t)gridDim.x * kBlock)
+        weights[p] = weights[p] / total;
+}
+
+// good_setting(): p = nan_to_num(u ** pickiness)  (obe_base.py:781-783)
+__global__ __launch_bounds__(kBlock) void power_kernel(const double* __restrict__ u, int64_t n, double k,
+                                                       double* __restrict__ p, double* __restrict__ partials) {
+    __shared__ double red[kBlock / kWave];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const double v = nan_to_num(pow(u[i], k));
+        p[i] = v;
+        acc += v;
+    }
+    const double s = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// p /= sum(p)   (obe_base.py:784)
+__global__ __launch_bounds__(kBlock) void divide_by_total_kernel(const double* __restrict__ partials, int n_partials,
+                                                                 int64_t n, double* __restrict__ p) {
+    __shared__ double red[kBlock / kWave];
+    const double total = block_sum_array(partials, n_partials, red);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        p[i] = p[i] / total;
+}
+
+// np.average(sigma**2, weights=w) per channel from the K3 block: m2[row] / sum w
+__global__ void noise_var_kernel(const double* __restrict__ moments, int d, RowsArg ra, double* __restrict__ out) {
+    const int c = threadIdx.x;
+    if (c < ra.n) out[c] = moments[2 + 2 * d + ra.rows[c]] / moments[0];
+}
+
+static int fill_lik_args(LikArgs& la, const double* h_y_meas, const double* h_sigma,
+                         const int32_t* h_noise_rows, int32_t n_lik_channels, double choke, int n_rows) {
+    if (n_lik_channels < 0 || n_lik_channels > OBE_MAX_CHANNELS) return bad_arg("n_lik_channels out of range");
+    if (!h_y_meas) return bad_arg("h_y_meas is NULL");
+    if (!h_sigma && !h_noise_rows) return bad_arg("need h_sigma or h_noise_rows");
+    la.n_ch = n_lik_channels;
+    la.use_rows = h_noise_rows != nullptr;
+    la.use_choke = !(choke != choke);
+    la.choke = la.use_choke ? choke : 1.0;
+    for (int c = 0; c < OBE_MAX_CHANNELS; ++c) {
+        la.y_meas[c] = c < n_lik_channels ? h_y_meas[c] : 0.0;
+        la.sigma[c] = (c < n_lik_channels && h_sigma) ? h_sigma[c] : 1.0;
+        la.noise_rows[c] = (c < n_lik_channels && h_noise_rows) ? h_noise_rows[c] : 0;
+        if (la.use_rows && c < n_lik_channels && (la.noise_rows[c] < 0 || la.noise_rows[c] >= n_rows))
+            return bad_arg("noise row index out of range");
+    }
+    return 0;
+}
+
+struct UpdateWs {
+    double* pa;
+    double* pb;
+    double* scalars;
+};
+static int carve_update_ws(void* d_ws, int64_t ws_bytes, UpdateWs& w) {
+    const int64_t need = (2 * (int64_t)kMaxBlocks + 8) * sizeof(double);
+    if (!d_ws || ws_bytes < need) return bad_arg("workspace too small");
+    w.pa = static_cast<double*>(d_ws);
+    w.pb = w.pa + kMaxBlocks;
+    w.scalars = w.pb + kMaxBlocks;
+    return 0;
+}
+
+static int finish_update(const UpdateWs& w, int nb, int64_t n, double* d_weights, double* h_out, hipStream_t st) {
+    normalize_kernel<<<nb, kBlock, 0, st>>>(w.pa, nb, n, d_weights, w.pb);
+    OBE_CHECK_LAUNCH("normalize_kernel");
+    fold2_kernel<<<1, kBlock, 0, st>>>(w.pa, w.pb, nb, w.scalars);
+    OBE_CHECK_LAUNCH("fold2_kernel");
+    if (h_out) {
+        OBE_HIP_TRY(hipMemcpyAsync(h_out, w.scalars, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+        OBE_HIP_TRY(hipStreamSynchronize(st));
+    }
+    return 0;
+}
+
+}  // namespace obe
+
+using namespace obe;
+
+extern "C" {
+
+int obe_bayes_update_model(const obe_model* m, const double* d_particles, int64_t ld_p, int64_t n_particles,
+                           double* d_weights, const double* h_setting, const double* h_y_meas,
+                           const double* h_sigma, const int32_t* h_noise_rows, int32_t n_lik_channels,
+                           double choke, void* d_ws, int64_t ws_bytes, double* h_out, void* stream) {
+    if (!m || !d_particles || !d_weights || n_particles <= 0) return bad_arg("obe_bayes_update_model: bad pointer/size");
+    obe_model mm = *m;
+    if (int rc = obe_model_validate(&mm)) return rc;
+    if (n_lik_channels > mm.n_channels) return bad_arg("n_lik_channels exceeds model channels");
+    LikArgs la;
+    if (int rc = fill_lik_args(la, h_y_meas, h_sigma, h_noise_rows, n_lik_channels, choke, mm.n_params)) return rc;
+    UpdateWs w;
+    if (int rc = carve_update_ws(d_ws, ws_bytes, w)) return rc;
+    SettingArg sa{};
+    for (int k = 0; k < mm.n_setdims; ++k) sa.x[k] = h_setting ? h_setting[k] : 0.0;
+    hipStream_t st = as_stream(stream);
+    const int nb = stream_blocks(n_particles, kBlock);
+    int rc = dispatch_model(mm, [&](auto M) -> int {
+        using Model = decltype(M);
+        update_model_kernel<Model><<<nb, kBlock, 0, st>>>(mm, sa, la, d_particles, ld_p, n_particles, d_weights, w.pa);
+        OBE_CHECK_LAUNCH("update_model_kernel");
+        return 0;
+    });
+    if (rc) return rc;
+    return finish_update(w, nb, n_particles, d_weights, h_out, st);
+}
+
+int obe_bayes_update_y(const double* d_y, int64_t ld_y, int32_t n_channels, const double* d_particles,
+                       int64_t ld_p, int64_t n_particles, double* d_weights, const double* h_y_meas,
+                       const double* h_sigma, const int32_t* h_noise_rows, int32_t n_lik_channels, double choke,
+                       void* d_ws, int64_t ws_bytes, double* h_out, void* stream) {
+    if (!d_y || !d_weights || n_particles <= 0) return bad_arg("obe_bayes_update_y: bad pointer/size");
+    if (n_channels < 1 || n_channels > OBE_MAX_CHANNELS || n_lik_channels > n_channels) return bad_arg("bad channel count");
+    if (h_noise_rows && !d_particles) return bad_arg("noise rows need d_particles");
+    LikArgs la;
+    if (int rc = fill_lik_args(la, h_y_meas, h_sigma, h_noise_rows, n_lik_channels, choke, OBE_MAX_DIMS)) return rc;
+    UpdateWs w;
+    if (int rc = carve_update_ws(d_ws, ws_bytes, w)) return rc;
+    hipStream_t st = as_stream(stream);
+    const int nb = stream_blocks(n_particles, kBlock);
+    update_y_kernel<<<nb, kBlock, 0, st>>>(la, n_channels, d_y, ld_y, d_particles, ld_p, n_particles, d_weights, w.pa);
+    OBE_CHECK_LAUNCH("update_y_kernel");
+    return finish_update(w, nb, n_particles, d_weights, h_out, st);
+}
+
+int obe_bayes_update_lik(const double* d_lik, int64_t n_particles, double* d_weights, void* d_ws,
+                         int64_t ws_bytes, double* h_out, void* stream) {
+    if (!d_lik || !d_weights || n_particles <= 0) return bad_arg("obe_bayes_update_lik: bad pointer/size");
+    UpdateWs w;
+    if (int rc = carve_update_ws(d_ws, ws_bytes, w)) return rc;
+    hipStream_t st = as_stream(stream);
+    const int nb = stream_blocks(n_particles, kBlock);
+    update_lik_kernel<<<nb, kBlock, 0, st>>>(d_lik, n_particles, d_weights, w.pa);
+    OBE_CHECK_LAUNCH("update_lik_kernel");
+    return finish_update(w, nb, n_particles, d_weights, h_out, st);
+}
+
+int obe_likelihood_y(const double* d_y, int64_t ld_y, int32_t n_channels, const double* d_particles,
+                     int64_t ld_p, int64_t n_particles, const double* h_y_meas, const double* h_sigma,
+                     const int32_t* h_noise_rows, int32_t n_lik_channels, double choke, double* d_lik_out,
+                     void* stream) {
+    if (!d_y || !d_lik_out || n_particles <= 0) return bad_arg("obe_likelihood_y: bad pointer/size");
+    if (n_channels < 1 || n_channels > OBE_MAX_CHANNELS || n_lik_channels > n_channels) return bad_arg("bad channel count");
+    if (h_noise_rows && !d_particles) return bad_arg("noise rows need d_particles");
+    LikArgs la;
+    if (int rc = fill_lik_args(la, h_y_meas, h_sigma, h_noise_rows, n_lik_channels, choke, OBE_MAX_DIMS)) return rc;
+    hipStream_t st = as_stream(stream);
+    likelihood_y_kernel<<<stream_blocks(n_particles, kBlock), kBlock, 0, st>>>(la, n_channels, d_y, ld_y, d_particles,
+                                                                                ld_p, n_particles, d_lik_out);
+    OBE_CHECK_LAUNCH("likelihood_y_kernel");
+    return 0;
+}
+
+int obe_weight_sums(const double* d_weights, int64_t n_particles, void* d_ws, int64_t ws_bytes, double* h_out,
+                    void* stream) {
+    if (!d_weights || n_particles <= 0 || !h_out) return bad_arg("obe_weight_sums: bad pointer/size");
+    UpdateWs w;
+    if (int rc = carve_update_ws(d_ws, ws_bytes, w)) return rc;
+    hipStream_t st = as_stream(stream);
+    const int nb = stream_blocks(n_particles, kBlock);
+    weight_sums_kernel<<<nb, kBlock, 0, st>>>(d_weights, n_particles, w.pa, w.pb);
+    OBE_CHECK_LAUNCH("weight_sums_kernel");
+    fold2_kernel<<<1, kBlock, 0, st>>>(w.pa, w.pb, nb, w.scalars);
+    OBE_CHECK_LAUNCH("fold2_kernel");
+    OBE_HIP_TRY(hipMemcpyAsync(h_out, w.scalars, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    OBE_HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+int obe_eval_over_particles(const obe_model* m, const double* d_particles, int64_t ld_p, int64_t n_particles,
+                            const double* h_setting, double* d_y_out, int64_t ld_y, void* stream) {
+    if (!m || !d_particles || !d_y_out || n_particles <= 0) return bad_arg("obe_eval_over_particles: bad pointer/size");
+    obe_model mm = *m;
+    if (int rc = obe_model_validate(&mm)) return rc;
+    SettingArg sa{};
+    for (int k = 0; k < mm.n_setdims; ++k) sa.x[k] = h_setting ? h_setting[k] : 0.0;
+    hipStream_t st = as_stream(stream);
+    return dispatch_model(mm, [&](auto M) -> int {
+        using Model = decltype(M);
+        eval_particles_kernel<Model><<<stream_blocks(n_particles, kBlock), kBlock, 0, st>>>(
+            mm, sa, d_particles, ld_p, n_particles, d_y_out, ld_y);
+        OBE_CHECK_LAUNCH("eval_particles_kernel");
+        return 0;
+    });
+}
+
+int obe_eval_over_settings(const obe_model* m, const double* d_settings, int64_t ld_s, int64_t n_settings,
+                           const double* h_params, double* d_y_out, int64_t ld_y, void* stream) {
+    if (!m || !d_settings || !d_y_out || !h_params || n_settings <= 0) return bad_arg("obe_eval_over_settings: bad pointer/size");
+    obe_model mm = *m;
+    if (int rc = obe_model_validate(&mm)) return rc;
+    ParamArg pa{};
+    for (int i = 0; i < mm.n_params && i < OBE_MAX_DIMS; ++i) pa.th[i] = h_params[i];
+    hipStream_t st = as_stream(stream);
+    return dispatch_model(mm, [&](auto M) -> int {
+        using Model = decltype(M);
+        eval_settings_kernel<Model><<<stream_blocks(n_settings, kBlock), kBlock, 0, st>>>(
+            mm, pa, d_settings, ld_s, n_settings, d_y_out, ld_y);
+        OBE_CHECK_LAUNCH("eval_settings_kernel");
+        return 0;
+    });
+}
+
+int obe_mask_nonpositive(const double* d_particles, int64_t ld_p, int64_t n_particles, const int32_t* h_rows,
+                         int32_t n_rows, double* d_weights, int64_t* h_changed, void* d_ws, int64_t ws_bytes,
+                         void* stream) {
+    if (!d_particles || !d_weights || !h_rows || n_rows < 1 || n_rows > OBE_MAX_DIMS || n_particles <= 0)
+        return bad_arg("obe_mask_nonpositive: bad pointer/size");
+    UpdateWs w;
+    if (int rc = carve_update_ws(d_ws, ws_bytes, w)) return rc;
+    RowsArg ra{};
+    ra.n = n_rows;
+    for (int k = 0; k < n_rows; ++k) ra.rows[k] = h_rows[k];
+    hipStream_t st = as_stream(stream);
+    const int nb = stream_blocks(n_particles, kBlock);
+    mask_kernel<<<nb, kBlock, 0, st>>>(ra, d_particles, ld_p, n_particles, d_weights, w.pa, w.pb);
+    OBE_CHECK_LAUNCH("mask_kernel");
+    fold2_kernel<<<1, kBlock, 0, st>>>(w.pa, w.pb, nb, w.scalars);
+    OBE_CHECK_LAUNCH("fold2_kernel");
+    mask_renorm_kernel<<<nb, kBlock, 0, st>>>(w.scalars, n_particles, d_weights);
+    OBE_CHECK_LAUNCH("mask_renorm_kernel");
+    if (h_changed) {
+        double sc[2];
+        OBE_HIP_TRY(hipMemcpyAsync(sc, w.scalars, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+        OBE_HIP_TRY(hipStreamSynchronize(st));
+        *h_changed = (int64_t)sc[1];
+    }
+    return 0;
+}
+
+int obe_power_normalize(const double* d_u, int64_t n, double exponent, double* d_p_out, void* d_ws,
+                        int64_t ws_bytes, void* stream) {
+    if (!d_u || !d_p_out || n <= 0) return bad_arg("obe_power_normalize: bad pointer/size");
+    UpdateWs w;
+    if (int rc = carve_update_ws(d_ws, ws_bytes, w)) return rc;
+    hipStream_t st = as_stream(stream);
+    const int nb = stream_blocks(n, kBlock);
+    power_kernel<<<nb, kBlock, 0, st>>>(d_u, n, exponent, d_p_out, w.pa);
+    OBE_CHECK_LAUNCH("power_kernel");
+    divide_by_total_kernel<<<nb, kBlock, 0, st>>>(w.pa, nb, n, d_p_out);
+    OBE_CHECK_LAUNCH("divide_by_total_kernel");
+    return 0;
+}
+
+int obe_noise_var_from_moments(const double* d_moments, int32_t n_dims, const int32_t* h_rows, int32_t n_rows,
+                               double* d_out, void* stream) {
+    if (!d_moments || !h_rows || !d_out || n_rows < 1 || n_rows > OBE_MAX_CHANNELS)
+        return bad_arg("obe_noise_var_from_moments: bad pointer/size");
+    RowsArg ra{};
+    ra.n = n_rows;
+    for (int k = 0; k < n_rows; ++k) {
+        if (h_rows[k] < 0 || h_rows[k] >= n_dims) return bad_arg("noise row index out of range");
+        ra.rows[k] = h_rows[k];
+    }
+    noise_var_kernel<<<1, kWave, 0, as_stream(stream)>>>(d_moments, n_dims, ra, d_out);
+    OBE_CHECK_LAUNCH("noise_var_kernel");
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,99 @@
+"""Settings-axis sharding across the GPUs of one node (one process per GPU).
+
+Every setting's utility is independent given the particle cloud, so
+rank r sweeps the contiguous slice ``[r*N_s/G, (r+1)*N_s/G)`` of the flattened settings
+and the cloud (34 MB at 1M particles) is replicated: each rank applies the same Bayes
+update and the same seeded resample, so replicas stay bit-identical and no particle
+data ever crosses xGMI.  The only data-path collective is the arg-max combine of
+``opt_setting``: one all-gather of 16 bytes per rank ``(best value, global index)``
+over RCCL (``torch.distributed`` backend "nccl"), followed by a local first-max —
+the message is latency-bound (tens of microseconds), irrelevant next to a
+multi-millisecond sweep.  With backend "gloo" the same code runs on CPU tensors, which
+is how the N>1 logic is tested without GPUs.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_settings, rank, world_size):
+    """Contiguous, balanced partition: the first ``n % world`` ranks get one extra."""
+    base, extra = divmod(int(n_settings), int(world_size))
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def first_max(values, indices):
+    """np.argmax tie rule on (value, global index) pairs: NaN wins, then the largest
+    value, ties broken by the lowest global index.  Returns the winning position."""
+    best = 0
+    for k in range(1, len(values)):
+        a_nan, b_nan = np.isnan(values[k]), np.isnan(values[best])
+        if a_nan != b_nan:
+            take = a_nan
+        elif a_nan and b_nan:
+            take = indices[k] < indices[best]
+        elif values[k] != values[best]:
+            take = values[k] > values[best]
+        else:
+            take = indices[k] < indices[best]
+        if take:
+            best = k
+    return best
+
+
+class SettingsShard:
+    """This process's slice of the settings axis and its collectives."""
+
+    def __init__(self, rank=None, world_size=None, group=None):
+        self.group = group
+        if rank is None or world_size is None:
+            if not dist.is_initialized():
+                raise RuntimeError("SettingsShard needs torch.distributed to be initialised "
+                                   "(or explicit rank/world_size)")
+            rank, world_size = dist.get_rank(group), dist.get_world_size(group)
+        self.rank, self.world_size = int(rank), int(world_size)
+
+    def bounds(self, n_settings):
+        return shard_bounds(n_settings, self.rank, self.world_size)
+
+    def _comm_device(self, device):
+        backend = dist.get_backend(self.group)
+        return torch.device(device) if backend == "nccl" else torch.device("cpu")
+
+    def combine_best(self, value, global_index, device="cpu"):
+        """Global first-maximum from each rank's local (value, global index)."""
+        if self.world_size == 1:
+            return value, global_index
+        dev = self._comm_device(device)
+        # 16 B per rank: the index travels as the bit pattern of an int64 inside a f64 slot
+        mine = torch.tensor([value, 0.0], dtype=torch.float64)
+        mine[1:].view(torch.int64)[0] = int(global_index)
+        mine = mine.to(dev)
+        gathered = torch.empty(2 * self.world_size, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(gathered, mine, group=self.group)
+        g = gathered.cpu().reshape(self.world_size, 2)
+        vals = g[:, 0].numpy()
+        idxs = g[:, 1].contiguous().view(torch.int64).numpy()
+        k = first_max(vals, idxs)
+        return float(vals[k]), int(idxs[k])
+
+    def gather_rows(self, local, n_settings):
+        """All ranks' (rows, n_local) slices assembled into a host (rows, n_settings) array."""
+        rows = local.shape[0]
+        if self.world_size == 1:
+            return local.cpu().numpy()
+        dev = self._comm_device(local.device)
+        widest = shard_bounds(n_settings, 0, self.world_size)
+        pad = widest[1] - widest[0]
+        buf = torch.zeros((rows, pad), dtype=torch.float64, device=dev)
+        b, e = self.bounds(n_settings)
+        buf[:, :e - b] = local[:, :e - b].to(dev)
+        gathered = torch.empty((self.world_size, rows, pad), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(gathered, buf, group=self.group)
+        gathered = gathered.cpu().numpy()
+        out = np.empty((rows, n_settings))
+        for r in range(self.world_size):
+            rb, re = shard_bounds(n_settings, r, self.world_size)
+            out[:, rb:re] = gathered[r, :, :re - rb]
+        return out

@@ -1,0 +1,137 @@
+"""Device-model registry (host side).
+
+The reference takes an arbitrary Python callable ``model_function(settings,
+parameters, constants)`` (obe_base.py:50-72) and leans on NumPy broadcasting; a HIP
+kernel cannot call that.  A :class:`DeviceModel` is a *recognisable* model: it carries
+the id of a hand-written gfx950 device function (include/obe_hip.h, ``enum
+obe_model_id``) and is itself a callable with the reference's signature, so user code
+that needs plain numbers from it — ``MeasurementSimulator(my_obe.model_function, ...)``
+in every demo — keeps working unchanged.  That NumPy form is never used by the
+classes in this package: all library arithmetic runs in the HIP kernels.
+
+Plain Python callables are still accepted by ``OptBayesExpt`` ("host-callable" mode):
+then only the *user's own function* runs on the host, and its outputs are uploaded for
+the likelihood / weight update / variance / argmax kernels.
+"""
+import numpy as np
+
+from ._lib import OBE_MAX_CONSTS, OBE_MAX_DIMS, ObeModelStruct
+
+MODEL_LORENTZ = 1
+MODEL_LINE_AB = 2
+MODEL_LINE_MB = 3
+MODEL_FIRST_PARAM = 4
+MODEL_RABI = 5
+MODEL_COIL = 6
+
+
+class DeviceModel:
+    """A measurement model that exists as a device function in libobe_hip.
+
+    Attributes:
+        model_id, aux: identify the device function.
+        n_read: parameter rows the model reads (the particle array may have more,
+            e.g. a trailing noise parameter).
+        n_setdims, n_channels, n_consts: shape of the model.
+    """
+
+    def __init__(self, name, model_id, aux, n_read, n_setdims, n_channels, n_consts, numpy_form):
+        self.name = name
+        self.model_id = model_id
+        self.aux = aux
+        self.n_read = n_read
+        self.n_setdims = n_setdims
+        self.n_channels = n_channels
+        self.n_consts = n_consts
+        self._numpy_form = numpy_form
+        self.__name__ = name
+
+    def __call__(self, sets, pars, cons):
+        """Reference calling convention, for user-side simulation and plotting."""
+        return self._numpy_form(sets, pars, cons)
+
+    def __repr__(self):
+        return f"DeviceModel({self.name!r})"
+
+    def struct(self, n_params, cons):
+        """The ``obe_model`` passed across the C ABI."""
+        cons = [float(c) for c in cons]
+        if len(cons) < self.n_consts:
+            raise ValueError(f"{self.name} needs {self.n_consts} constant(s), got {len(cons)}")
+        if len(cons) > OBE_MAX_CONSTS:
+            raise ValueError(f"at most {OBE_MAX_CONSTS} constants are supported")
+        if not (self.n_read <= n_params <= OBE_MAX_DIMS):
+            raise ValueError(f"{self.name} reads {self.n_read} parameters; the particle array has "
+                             f"{n_params} (device limit {OBE_MAX_DIMS})")
+        m = ObeModelStruct()
+        m.id, m.aux = self.model_id, self.aux
+        m.n_params, m.n_setdims, m.n_channels = n_params, self.n_setdims, self.n_channels
+        m.n_consts = len(cons)
+        for i, c in enumerate(cons):
+            m.consts[i] = c
+        return m
+
+
+def lorentzian(n_peaks=1):
+    """``y = b + sum_k a / (((x - x0_k)/d)**2 + 1)``; parameters ``(x0_1..x0_K, a, b[, ...])``,
+    constants ``(d,)``.  K=1 is demos/find_peak/sequentialLorentzian.py:53-75."""
+    if not 1 <= n_peaks <= 8:
+        raise ValueError("n_peaks must be 1..8")
+
+    def form(sets, pars, cons):
+        x, = sets
+        a, b = pars[n_peaks], pars[n_peaks + 1]
+        d, = cons
+        y = b
+        for k in range(n_peaks):
+            y = y + a / (((x - pars[k]) / d) ** 2 + 1)
+        return y
+    return DeviceModel(f"lorentzian[{n_peaks}]", MODEL_LORENTZ, n_peaks, n_peaks + 2, 1, 1, 1, form)
+
+
+def line_ab():
+    """``y = p0 + p1*x`` (tests/test_optbayesexpt.py:11-14)."""
+    def form(sets, pars, cons):
+        x, = sets
+        return pars[0] + pars[1] * x
+    return DeviceModel("line_ab", MODEL_LINE_AB, 0, 2, 1, 1, 0, form)
+
+
+def line_mb():
+    """``y = p0*x + p1`` (demos/line_plus_noise/line_plus_noise.py:36-53)."""
+    def form(sets, pars, cons):
+        x, = sets
+        return pars[0] * x + pars[1]
+    return DeviceModel("line_mb", MODEL_LINE_MB, 0, 2, 1, 1, 0, form)
+
+
+def first_parameter():
+    """``y = p0`` (tests/test_zinference.py:21-26)."""
+    def form(sets, pars, cons):
+        return pars[0]
+    return DeviceModel("first_parameter", MODEL_FIRST_PARAM, 0, 1, 1, 1, 0, form)
+
+
+def rabi():
+    """Rabi counts, settings ``(pulsetime, detuning)``, parameters ``(B1, f_center)``,
+    constants ``(baseline, contrast, T1)`` (demos/pipulse/pipulse.py:18-49)."""
+    def form(sets, pars, cons):
+        pulsetime, delta_f = sets
+        b1, f_center = pars[0], pars[1]
+        baseline, contrast, t1 = cons
+        zz = ((delta_f - f_center) / b1) ** 2
+        f_rabi = np.hypot(delta_f - f_center, b1)
+        return baseline * (1 - np.exp(-pulsetime / t1) * contrast / 2 *
+                           (1 - np.cos(np.pi * 2 * f_rabi * pulsetime)) / (zz + 1))
+    return DeviceModel("rabi", MODEL_RABI, 0, 2, 2, 1, 3, form)
+
+
+def coil():
+    """Impedance of a lossy coil with stray capacitance, setting ``(omega,)``, parameters
+    ``(L, R, C[, ...])``, two channels (Re Z, Im Z) (demos/lockin/lockin_of_coil.py:63-102)."""
+    def form(sets, pars, cons):
+        w, = sets
+        L, R, C = pars[0], pars[1], pars[2]
+        z = 1 / (1 / (R + 1j * w * L) + 1j * w * C)
+        return np.array((np.real(z), np.imag(z)))
+    return DeviceModel("coil", MODEL_COIL, 0, 3, 1, 2, 0, form)

@@ -1,0 +1,493 @@
+"""OptBayesExpt — sequential Bayesian experiment design on one (or a shard of) MI355X.
+
+Constructor, attributes, methods and override points follow the reference class
+(optbayesexpt/obe_base.py:21-824).  The hot path named by BASELINE.json — the utility
+sweep behind ``opt_setting()`` and the posterior update in ``pdf_update()`` — runs in
+the HIP kernels of libobe_hip.so:
+
+=====================================  ==========================================
+reference                              here
+=====================================  ==========================================
+``yvar_from_parameter_draws`` (:463)   ``obe_sweep_utility`` (K1), draws or full
+``utility_variance`` (:628)            fused into the K1 finalize pass
+``opt_setting`` argmax (:748)          device first-max (K5) [+ RCCL all-gather]
+``eval_over_all_parameters`` +         ``obe_bayes_update_model`` (K2, fused)
+``likelihood`` + ``bayesian_update``
+=====================================  ==========================================
+
+Two kinds of measurement model are accepted:
+
+* a :class:`~optbayesexpt_amd.models.DeviceModel` — everything above runs on the GPU;
+* any Python callable with the reference signature ("host-callable" mode) — the
+  user's function is evaluated on the host exactly where the reference evaluates it,
+  and its outputs are uploaded for the likelihood / update / variance / argmax kernels.
+
+Override points of the reference (``enforce_parameter_constraints``, ``cost_estimate``,
+``yvar_noise_model``, ``likelihood``, ``utility_*``) remain ordinary methods that
+subclasses may replace with NumPy code; the fused kernels are used only while the
+corresponding methods are not overridden.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from ._mirror import Mirror, TrackedArray
+from .models import DeviceModel
+from .particlepdf import ParticlePDF, _P, _ptr
+
+DEFAULT_N_DRAWS = 30            # obe_base.py:19
+rng = np.random.default_rng()   # module-level generator of the reference (random_setting)
+
+UTILITY_METHODS = ["variance_approx", "pseudo_utility", "full_kld_utility", "max_min",
+                   "variance_full"]
+SELECTION_METHODS = ["optimal", "good", "random"]
+
+
+def _overridden(obj, name, *owners):
+    """True if ``obj``'s class replaces method ``name`` defined by one of ``owners``."""
+    impl = getattr(type(obj), name)
+    return all(impl is not getattr(o, name) for o in owners)
+
+
+class OptBayesExpt(ParticlePDF):
+    """Sequential Bayesian experiment design (see module docstring).
+
+    Extensions beyond the reference signature (obe_base.py:154-159):
+
+    ``utility_method='variance_full'``
+        the full settings x particles sweep: every particle is a draw and the
+        predicted variance is weighted by the particle weights (the N_DRAWS -> all
+        limit of ``yvar_from_parameter_draws``).
+    ``settings_shard``
+        a :class:`~optbayesexpt_amd.dist.SettingsShard`; this process then sweeps only
+        its contiguous slice of the settings and ``opt_setting`` combines the per-rank
+        maxima with one all-gather.
+    """
+
+    def __init__(self, measurement_model, setting_values, parameter_samples,
+                 constants, n_draws=DEFAULT_N_DRAWS, choke=None,
+                 use_jit=True, utility_method="variance_approx",
+                 selection_method="optimal", pickiness=15,
+                 default_noise_std=1.0, settings_shard=None, **kwargs):
+        ParticlePDF.__init__(self, parameter_samples, use_jit=use_jit, **kwargs)
+
+        self.model_function = measurement_model
+        self._device_model = measurement_model if isinstance(measurement_model, DeviceModel) else None
+        self.setting_values = setting_values
+        #: (S, N_s) all setting combinations, meshgrid indexing='ij' (obe_base.py:174-176)
+        self.allsettings = np.array([s.flatten() for s in
+                                     np.meshgrid(*setting_values, indexing="ij")])
+        self.setting_indices = np.arange(len(self.allsettings[0]), dtype=int)
+        self._n_settings = self.allsettings.shape[1]
+        self._parameters = self._particles      # alias, refreshed by pdf_update (obe_base.py:185,395)
+        self.cons = constants
+        self.choke = choke
+        self.N_DRAWS = n_draws
+        self.pickiness = pickiness
+        self.measurement_results = []
+        self.last_setting_index = 0
+
+        if self._device_model is not None:
+            dm = self._device_model
+            if self.allsettings.shape[0] != dm.n_setdims:
+                raise ValueError(f"{dm.name} takes {dm.n_setdims} setting(s), got {self.allsettings.shape[0]}")
+            self._model_struct = dm.struct(self.n_dims, constants)
+            self._lib.call("obe_model_validate", self._model_struct)
+            self.n_channels = dm.n_channels
+        else:
+            self._model_struct = None
+            self.n_channels = self._model_output_len()
+        if self.n_channels > _lib.OBE_MAX_CHANNELS:
+            raise ValueError(f"at most {_lib.OBE_MAX_CHANNELS} channels are supported on the device")
+
+        if self.n_channels == 1:
+            def wrapped_function(s, p, c):
+                return (measurement_model(s, p, c),)
+            self._model_function = wrapped_function
+        else:
+            self._model_function = self.model_function
+
+        # settings on the device; a shard sweeps only [s_begin, s_end)
+        self._shard = settings_shard
+        if settings_shard is not None:
+            self._s_begin, self._s_end = settings_shard.bounds(self._n_settings)
+        else:
+            self._s_begin, self._s_end = 0, self._n_settings
+        self._settings_dev = torch.from_numpy(np.ascontiguousarray(self.allsettings, dtype=np.float64)) \
+            .to(self._device)
+        n_local = self._s_end - self._s_begin
+        self._yvar_dev = torch.zeros((self.n_channels, max(n_local, 1)), dtype=torch.float64, device=self._device)
+        self._utility_dev = torch.zeros(max(n_local, 1), dtype=torch.float64, device=self._device)
+        self._noise_dev = torch.zeros(self.n_channels, dtype=torch.float64, device=self._device)
+        self._noise_cache = None
+        self._alloc_scratch()
+
+        self.utility_y_space = np.array([])
+        self.set_n_draws(n_draws)
+        self.default_noise_std = np.ones((self.n_channels, 1)) * default_noise_std
+
+        if utility_method == "variance_approx":
+            _utility = self.utility_variance
+        elif utility_method == "variance_full":
+            if self._device_model is None:
+                raise ValueError("utility_method='variance_full' needs a DeviceModel")
+            _utility = self.utility_variance
+        elif utility_method in ("pseudo_utility", "max_min", "full_kld_utility"):
+            raise NotImplementedError(
+                f"utility_method {utility_method!r} is outside the accelerated hot path "
+                "(SURVEY.md §8f); use 'variance_approx' or 'variance_full'")
+        else:
+            raise SyntaxError(f"Unknown utility method, {utility_method}. "
+                              f"Valid utility methods are: {UTILITY_METHODS}")
+        self.utility_method = utility_method
+        self.utility = _utility
+
+        if selection_method == "optimal":
+            _get_setting = self.opt_setting
+        elif selection_method == "good":
+            _get_setting = self.good_setting
+        elif selection_method == "random":
+            _get_setting = self.random_setting
+        else:
+            raise SyntaxError(f"Unknown selection_method, {selection_method}. "
+                              f"Valid selection methods are: {SELECTION_METHODS}")
+        self.get_setting = _get_setting
+
+    # ------------------------------------------------------------------ state
+    def _scratch_dims(self):
+        return getattr(self, "_n_settings", 1), getattr(self, "n_channels", 1)
+
+    @property
+    def parameters(self):
+        """The parameter samples the model is evaluated on: an alias of ``particles``
+        that is refreshed by ``pdf_update`` (obe_base.py:185, 395)."""
+        return self._parameters.host()
+
+    @parameters.setter
+    def parameters(self, value):
+        if isinstance(value, TrackedArray) and value._obe_owner is self._particles \
+                and value.shape == self._particles.shape:
+            self._parameters = self._particles           # ``self.parameters = self.particles``
+        else:
+            self._parameters = Mirror(self._device, host=np.asarray(value))
+
+    def set_n_draws(self, n_draws=None):
+        """obe_base.py:274-296."""
+        if n_draws == "default":
+            self.N_DRAWS = DEFAULT_N_DRAWS
+        elif n_draws:
+            self.N_DRAWS = n_draws
+        if self._device_model is None:
+            self.utility_y_space = np.zeros((self.N_DRAWS, self.n_channels, self._n_settings))
+        return self.N_DRAWS
+
+    # -------------------------------------------------------- model evaluation
+    def eval_over_all_parameters(self, onesettingset):
+        """Model for one setting and all parameter samples -> C arrays of N_p
+        (obe_base.py:298-320)."""
+        if self._device_model is None:
+            return self._model_function(onesettingset, self.parameters, self.cons)
+        y = self._eval_over_all_parameters_device(onesettingset)
+        return y.cpu().numpy()
+
+    def _eval_over_all_parameters_device(self, onesettingset):
+        par = self._parameters.tensor()
+        y = torch.empty((self.n_channels, par.shape[1]), dtype=torch.float64, device=self._device)
+        st = self._setting_array(onesettingset)
+        self._lib.call("obe_eval_over_particles", self._model_struct, _ptr(par), par.shape[1], par.shape[1],
+                       _lib.host_ptr(st), _ptr(y), par.shape[1], self._stream())
+        return y
+
+    def eval_over_all_settings(self, oneparamset):
+        """Model for all settings and one parameter set -> C arrays of N_s
+        (obe_base.py:322-338)."""
+        if self._device_model is None:
+            return self._model_function(self.allsettings, oneparamset, self.cons)
+        th = _lib.f64(np.asarray(oneparamset, dtype=np.float64).reshape(-1)[:self.n_dims], None)
+        if th.size < self._device_model.n_read:
+            raise ValueError("parameter set is shorter than the model's parameter list")
+        thp = np.zeros(_lib.OBE_MAX_DIMS)
+        thp[:th.size] = th
+        y = torch.empty((self.n_channels, self._n_settings), dtype=torch.float64, device=self._device)
+        self._lib.call("obe_eval_over_settings", self._model_struct, _ptr(self._settings_dev),
+                       self._n_settings, self._n_settings, _lib.host_ptr(thp), _ptr(y), self._n_settings,
+                       self._stream())
+        return y.cpu().numpy()
+
+    def _setting_array(self, onesettingset):
+        st = np.zeros(_lib.OBE_MAX_SETDIMS)
+        vals = np.asarray(onesettingset, dtype=np.float64).reshape(-1)
+        st[:min(vals.size, _lib.OBE_MAX_SETDIMS)] = vals[:_lib.OBE_MAX_SETDIMS]
+        return st
+
+    # -------------------------------------------------------------- pdf_update
+    def _record_channels(self, y_meas, sigma):
+        """zip(y_model, atleast_1d(y_meas), atleast_1d(sigma)) truncation
+        (obe_base.py:453-455)."""
+        y = np.atleast_1d(np.asarray(y_meas, dtype=np.float64)).reshape(-1)
+        n = min(self.n_channels, y.size)
+        s = None
+        if sigma is not None:
+            s = np.atleast_1d(np.asarray(sigma, dtype=np.float64)).reshape(-1)
+            n = min(n, s.size)
+            pad = np.ones(_lib.OBE_MAX_CHANNELS)
+            pad[:n] = s[:n]
+            s = pad
+        yy = np.zeros(_lib.OBE_MAX_CHANNELS)
+        yy[:n] = y[:n]
+        return n, yy, s
+
+    def _likelihood_inputs(self, measurement_record):
+        """(n_lik_channels, y_meas[4], sigma[4] or None, noise_rows[4] or None)."""
+        _, y_meas, sigma = measurement_record
+        n, yy, s = self._record_channels(y_meas, sigma)
+        return n, yy, s, None
+
+    def _choke_value(self):
+        return float("nan") if self.choke is None else float(self.choke)
+
+    def pdf_update(self, measurement_record, y_model_data=None):
+        """Bayesian update of the parameter distribution from one measurement
+        (obe_base.py:340-399).  Returns ``(particles, particle_weights)``."""
+        onesetting = measurement_record[0]
+        fused = (self._device_model is not None and y_model_data is None
+                 and not _overridden(self, "eval_over_all_parameters", OptBayesExpt)
+                 and not self._likelihood_overridden())
+        if fused:
+            n, yy, s, rows = self._likelihood_inputs(measurement_record)
+            par = self._parameters.tensor()
+            w = self._weights.tensor()
+            if par.shape[1] != w.shape[0]:
+                raise ValueError("parameters and particle_weights have different lengths")
+            self._lib.call("obe_bayes_update_model", self._model_struct, _ptr(par), par.shape[1],
+                           self.n_particles, _ptr(w), _lib.host_ptr(self._setting_array(onesetting)),
+                           _lib.host_ptr(yy), None if s is None else _lib.host_ptr(s),
+                           None if rows is None else _lib.host_ptr(rows), n, self._choke_value(),
+                           _ptr(self._ws), self._ws_bytes, _lib.host_ptr(self._host_out), self._stream())
+            self._after_weight_update(self._host_out[1])
+        else:
+            if y_model_data is None:
+                y_model_data = self.eval_over_all_parameters(onesetting)
+            if self._likelihood_overridden():
+                likyhd = self.likelihood(y_model_data, measurement_record)   # user NumPy code
+                self.bayesian_update(likyhd)
+            else:
+                y_dev = self._y_to_device(y_model_data)
+                n, yy, s, rows = self._likelihood_inputs(measurement_record)
+                par = self._parameters.tensor()
+                w = self._weights.tensor()
+                self._lib.call("obe_bayes_update_y", _ptr(y_dev), y_dev.shape[1], self.n_channels,
+                               _ptr(par), par.shape[1], self.n_particles, _ptr(w), _lib.host_ptr(yy),
+                               None if s is None else _lib.host_ptr(s),
+                               None if rows is None else _lib.host_ptr(rows), n, self._choke_value(),
+                               _ptr(self._ws), self._ws_bytes, _lib.host_ptr(self._host_out), self._stream())
+                self._after_weight_update(self._host_out[1])
+        self._parameters = self._particles
+        if self.just_resampled:
+            self.enforce_parameter_constraints()
+        return self.particles, self.particle_weights
+
+    def _likelihood_overridden(self):
+        return _overridden(self, "likelihood", OptBayesExpt)
+
+    def _y_to_device(self, y_model_data):
+        if isinstance(y_model_data, torch.Tensor):
+            return y_model_data.to(self._device, torch.float64).reshape(self.n_channels, -1).contiguous()
+        rows = [np.broadcast_to(np.asarray(r, dtype=np.float64), (self.n_particles,)) for r in y_model_data]
+        return torch.from_numpy(np.array(rows[:self.n_channels], dtype=np.float64)).to(self._device)
+
+    def enforce_parameter_constraints(self):
+        """Stub for subclasses (obe_base.py:401-416); called after each resample."""
+        pass
+
+    def likelihood(self, y_model, measurement_record):
+        """Gaussian likelihood of the measurement for every parameter sample
+        (obe_base.py:418-461), computed on the device from ``y_model`` (C x N_p)."""
+        y_dev = self._y_to_device(y_model)
+        n, yy, s, rows = self._likelihood_inputs(measurement_record)
+        par = self._parameters.tensor()
+        out = torch.empty(y_dev.shape[1], dtype=torch.float64, device=self._device)
+        self._lib.call("obe_likelihood_y", _ptr(y_dev), y_dev.shape[1], self.n_channels, _ptr(par),
+                       par.shape[1], y_dev.shape[1], _lib.host_ptr(yy),
+                       None if s is None else _lib.host_ptr(s),
+                       None if rows is None else _lib.host_ptr(rows), n, self._choke_value(), _ptr(out),
+                       self._stream())
+        return out.cpu().numpy()
+
+    # ----------------------------------------------------------------- utility
+    def yvar_noise_model(self):
+        """Measurement-noise variance used by the utility (obe_base.py:542-564)."""
+        return self.default_noise_std ** 2
+
+    def y_var_noise_model(self):
+        return self.yvar_noise_model()
+
+    def cost_estimate(self):
+        """Cost of a measurement per setting (obe_base.py:566-577)."""
+        return 1.0
+
+    def _noise_var_device(self):
+        """(tensor, ld): noise variance on the device — one value per channel (ld = 0)
+        or, for an overriding yvar_noise_model() that returns per-setting values, a
+        (C, n_local) array (ld = n_local)."""
+        nv = np.asarray(self.yvar_noise_model(), dtype=np.float64)
+        c, ns = self.n_channels, self._n_settings
+        per_channel = nv.size == 1 or nv.shape in ((c,), (c, 1))
+        if per_channel:
+            flat = np.array(np.broadcast_to(nv.reshape(-1), (c,)), dtype=np.float64)
+            key = flat.tobytes()
+            if self._noise_cache != key:
+                self._noise_dev.copy_(torch.from_numpy(flat))
+                self._noise_cache = key
+            return self._noise_dev, 0
+        full = np.broadcast_to(nv, (c, ns))[:, self._s_begin:self._s_end]
+        t = torch.from_numpy(np.array(full)).to(self._device)
+        return t, t.shape[1]
+
+    def _cost_device(self):
+        cost = self.cost_estimate()
+        if np.ndim(cost) == 0:
+            return None, float(cost)
+        c = np.array(np.broadcast_to(np.asarray(cost, dtype=np.float64), (self._n_settings,)))
+        return torch.from_numpy(c[self._s_begin:self._s_end].copy()).to(self._device), 1.0
+
+    def _utility_fusable(self):
+        return (self._device_model is not None
+                and self.utility.__func__ is OptBayesExpt.utility_variance
+                and not _overridden(self, "yvar_from_parameter_draws", OptBayesExpt)
+                and not _overridden(self, "eval_over_all_settings", OptBayesExpt))
+
+    def _sweep_device(self, want_best):
+        """K1 + K5 on this rank's settings slice.  Leaves yvar/utility on the device;
+        returns (best value, best *global* index) if ``want_best``."""
+        full = self.utility_method == "variance_full"
+        idx = None
+        n_draws = 0
+        if not full:
+            idx = self._draw_indices(self.N_DRAWS)       # consumes N_DRAWS uniforms (randdraw)
+            n_draws = self.N_DRAWS
+        mom = self._moments_on_device()
+        p, w = self._pw_tensors()
+        noise, noise_ld = self._noise_var_device()
+        cost_t, cost_s = self._cost_device()
+        n_local = self._s_end - self._s_begin
+        best = np.zeros(1)
+        best_idx = np.zeros(1, dtype=np.int64)
+        s_ptr = _P(self._settings_dev.data_ptr() + 8 * self._s_begin)
+        self._lib.call("obe_sweep_utility", self._model_struct, s_ptr, self._n_settings, n_local,
+                       _ptr(p), p.shape[1], self.n_particles, _ptr(w),
+                       None if idx is None else _ptr(idx), n_draws, _ptr(mom),
+                       _ptr(noise), noise_ld, None if cost_t is None else _ptr(cost_t), cost_s,
+                       _ptr(self._yvar_dev), _ptr(self._utility_dev),
+                       _lib.host_ptr(best) if want_best else None,
+                       _lib.host_ptr(best_idx) if want_best else None,
+                       _ptr(self._ws), self._ws_bytes, self._stream())
+        if want_best:
+            return float(best[0]), int(best_idx[0]) + self._s_begin
+        return None
+
+    def yvar_from_parameter_draws(self):
+        """Variance of the model output over parameter draws, per setting: (C, N_s)
+        (obe_base.py:463-489; all particles, weighted, for 'variance_full')."""
+        if self._device_model is not None and not _overridden(self, "eval_over_all_settings", OptBayesExpt):
+            self._sweep_device(False)
+            return self._gather_settings(self._yvar_dev)
+        # host-callable model: the user's function fills the y-space, the device reduces it
+        paramsets = self.randdraw(self.N_DRAWS).T
+        for i, oneparamset in enumerate(paramsets):
+            self.utility_y_space[i] = self.eval_over_all_settings(oneparamset)
+        ysp = torch.from_numpy(np.ascontiguousarray(self.utility_y_space)).to(self._device)
+        yvar = torch.empty((self.n_channels, self._n_settings), dtype=torch.float64, device=self._device)
+        self._lib.call("obe_yspace_variance", _ptr(ysp), self.N_DRAWS, self.n_channels, self._n_settings,
+                       _ptr(yvar), self._stream())
+        return yvar.cpu().numpy()
+
+    def utility_variance(self):
+        """Variance-approximation utility per setting, (N_s,) (obe_base.py:628-655)."""
+        if self._utility_fusable() and not _overridden(self, "utility_variance", OptBayesExpt):
+            self._sweep_device(False)
+            return self._gather_settings(self._utility_dev.reshape(1, -1))[0]
+        var_p = self.yvar_from_parameter_draws()
+        return self._utility_from_host_yvar(var_p)
+
+    def _utility_from_host_yvar(self, var_p):
+        """sum_c var_p / var_n / cost on the device from a host (C, N_s) variance."""
+        yv = torch.from_numpy(np.ascontiguousarray(var_p, dtype=np.float64)).to(self._device)
+        noise, noise_ld = self._noise_var_device()
+        if noise_ld:
+            raise NotImplementedError("per-setting noise model with a host-computed variance")
+        cost = self.cost_estimate()
+        cost_t = None if np.ndim(cost) == 0 else \
+            torch.from_numpy(np.array(np.broadcast_to(np.asarray(cost, np.float64),
+                                                      (self._n_settings,)))).to(self._device)
+        util = torch.empty(self._n_settings, dtype=torch.float64, device=self._device)
+        self._lib.call("obe_utility_argmax", _ptr(yv), self.n_channels, self._n_settings, _ptr(noise), 0,
+                       None if cost_t is None else _ptr(cost_t), float(cost) if cost_t is None else 1.0,
+                       _ptr(util), None, None, _ptr(self._ws), self._ws_bytes, self._stream())
+        return util.cpu().numpy()
+
+    def _gather_settings(self, local):
+        """Host (rows, N_s) array from this rank's (rows, n_local) device slice."""
+        if self._shard is None:
+            return local.cpu().numpy()
+        return self._shard.gather_rows(local, self._n_settings)
+
+    # --------------------------------------------------------------- selection
+    def opt_setting(self):
+        """The setting with maximum utility (obe_base.py:733-756)."""
+        if self._utility_fusable():
+            val, bestindex = self._sweep_device(True)
+            if self._shard is not None:
+                val, bestindex = self._shard.combine_best(val, bestindex, self._device)
+        else:
+            utility = np.asarray(self.utility(), dtype=np.float64)       # user-overridden utility
+            u = torch.from_numpy(np.ascontiguousarray(utility)).to(self._device)
+            best = np.zeros(1)
+            best_idx = np.zeros(1, dtype=np.int64)
+            self._lib.call("obe_argmax", _ptr(u), u.numel(), _lib.host_ptr(best), _lib.host_ptr(best_idx),
+                           _ptr(self._ws), self._ws_bytes, self._stream())
+            bestindex = int(best_idx[0])
+        bestvalues = self.allsettings[:, bestindex]
+        self.last_setting_index = bestindex
+        return tuple(bestvalues)
+
+    def good_setting(self, pickiness=None):
+        """A setting drawn with probability ~ utility**pickiness (obe_base.py:758-789)."""
+        if pickiness is None:
+            pickiness = self.pickiness
+        if self._shard is not None:
+            raise NotImplementedError("good_setting with a sharded settings axis (SURVEY.md §8e, next)")
+        if self._utility_fusable():
+            self._sweep_device(False)
+            u = self._utility_dev
+        else:
+            u = torch.from_numpy(np.ascontiguousarray(self.utility(), dtype=np.float64)).to(self._device)
+        n = u.numel()
+        prob = torch.empty(n, dtype=torch.float64, device=self._device)
+        cdf = torch.empty(n, dtype=torch.float64, device=self._device)
+        self._lib.call("obe_power_normalize", _ptr(u), n, float(pickiness), _ptr(prob), _ptr(self._ws),
+                       self._ws_bytes, self._stream())
+        self._lib.call("obe_weight_cdf", _ptr(prob), n, 0, _ptr(cdf), None, _ptr(self._ws), self._ws_bytes,
+                       self._stream())
+        uni = torch.from_numpy(np.atleast_1d(self.rng.random())).to(self._device)
+        idx = torch.empty(1, dtype=torch.int64, device=self._device)
+        self._lib.call("obe_cdf_search", _ptr(cdf), n, _ptr(uni), 1, _ptr(idx), self._stream())
+        goodindex = int(idx.cpu()[0])
+        self.last_setting_index = goodindex
+        return tuple(self.allsettings[:, goodindex])
+
+    def random_setting(self):
+        """A uniformly random setting (obe_base.py:791-805)."""
+        settingindex = rng.choice(self.setting_indices)
+        self.last_setting_index = settingindex
+        return self.allsettings[:, settingindex]
+
+    def _model_output_len(self):
+        """Number of output channels of a host-callable model, by a trial evaluation
+        (obe_base.py:807-824)."""
+        trial_rng = np.random.default_rng()
+        settingindex = trial_rng.choice(self.setting_indices)
+        one_setting = self.allsettings[:, settingindex]
+        one_param_set = self.randdraw(n_draws=1)
+        singleshot = self.model_function(one_setting, one_param_set, self.cons)
+        return len(np.atleast_1d(singleshot))

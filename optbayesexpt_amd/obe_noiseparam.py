@@ -1,0 +1,86 @@
+"""OptBayesExptNoiseParameter — measurement noise as an unknown (particle) parameter.
+
+Mirrors optbayesexpt/obe_noiseparam.py:5-136: the likelihood takes sigma from a
+parameter row (per particle), the utility's noise variance is the weighted mean of
+sigma^2, and after every resample particles with sigma <= 0 get zero weight.  All
+three run in libobe_hip kernels (K2 with ``h_noise_rows``, the K3 moment block, K6).
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .obe_base import OptBayesExpt, _overridden
+from .particlepdf import _ptr
+
+
+class OptBayesExptNoiseParameter(OptBayesExpt):
+    """``noise_parameter_index``: int or tuple, one parameter row per output channel
+    (obe_noiseparam.py:45-55)."""
+
+    def __init__(self, measurement_model, setting_values, parameter_samples,
+                 constants, noise_parameter_index=None, **kwargs):
+        OptBayesExpt.__init__(self, measurement_model, setting_values,
+                              parameter_samples, constants, **kwargs)
+        self.noise_parameter_index = np.atleast_1d(noise_parameter_index)
+        if len(self.noise_parameter_index) != self.n_channels:
+            raise RuntimeError(f"noise_parameter_index is not compatible with"
+                               f" {self.n_channels} measurement channels")
+        self._noise_rows = np.zeros(_lib.OBE_MAX_DIMS, dtype=np.int32)
+        rows = np.asarray(self.noise_parameter_index, dtype=np.int64)
+        rows = np.where(rows < 0, rows + self.n_dims, rows)          # NumPy negative indexing
+        if np.any(rows < 0) or np.any(rows >= self.n_dims):
+            raise IndexError("noise_parameter_index out of range")
+        self._noise_rows[:self.n_channels] = rows
+
+    # -- likelihood: sigma is a parameter row (obe_noiseparam.py:81-120) --------------
+    def _likelihood_inputs(self, measurement_record):
+        y_meas = measurement_record[1]
+        n, yy, _ = self._record_channels(y_meas, None)
+        return n, yy, None, self._noise_rows
+
+    def _likelihood_overridden(self):
+        return _overridden(self, "likelihood", OptBayesExpt, OptBayesExptNoiseParameter)
+
+    def likelihood(self, y_model, measurement_record):
+        """Per-particle-sigma Gaussian likelihood; same device kernel as the base class,
+        with sigma read from the noise parameter rows."""
+        return OptBayesExpt.likelihood(self, y_model, measurement_record)
+
+    # -- constraint: sigma > 0 (obe_noiseparam.py:57-79) ------------------------------
+    def enforce_parameter_constraints(self):
+        """Zero the weight of every particle whose noise parameter is <= 0 and
+        renormalise; called by ``pdf_update`` right after a resample."""
+        par = self._parameters.tensor()
+        w = self._weights.tensor()
+        changed = np.zeros(1, dtype=np.int64)
+        self._lib.call("obe_mask_nonpositive", _ptr(par), par.shape[1], self.n_particles,
+                       _lib.host_ptr(self._noise_rows), self.n_channels, _ptr(w), _lib.host_ptr(changed),
+                       _ptr(self._ws), self._ws_bytes, self._stream())
+        if changed[0]:
+            self._weights.mark_device_written()
+        self.last_constraint_count = int(changed[0])
+
+    # -- noise model: weighted mean of sigma^2 (obe_noiseparam.py:122-136) ------------
+    def yvar_noise_model(self):
+        """(C, 1) weighted mean of sigma^2, reduced on the device (K3 block)."""
+        t, _ = OptBayesExptNoiseParameter._noise_var_device(self)
+        return t.cpu().numpy().reshape((self.n_channels, 1))
+
+    def _noise_var_device(self):
+        if _overridden(self, "yvar_noise_model", OptBayesExptNoiseParameter):
+            return OptBayesExpt._noise_var_device(self)
+        if self._parameters is self._particles:
+            mom = self._moments_on_device()
+        else:
+            # stale alias after set_pdf(): the reference averages the rows of
+            # ``parameters`` (old samples) with the current weights
+            par, w = self._parameters.tensor(), self._weights.tensor()
+            if par.shape[1] != w.shape[0]:
+                raise ValueError("parameters and particle_weights have different lengths")
+            mom = torch.zeros_like(self._moments_dev)
+            self._lib.call("obe_moments", _ptr(par), par.shape[1], self.n_dims, par.shape[1], _ptr(w), 0,
+                           _ptr(mom), None, _ptr(self._ws), self._ws_bytes, self._stream())
+        self._lib.call("obe_noise_var_from_moments", _ptr(mom), self.n_dims, _lib.host_ptr(self._noise_rows),
+                       self.n_channels, _ptr(self._noise_dev), self._stream())
+        self._noise_cache = None
+        return self._noise_dev, 0

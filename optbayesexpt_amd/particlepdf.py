@@ -1,0 +1,316 @@
+"""ParticlePDF — the weighted-particle posterior, resident on one MI355X.
+
+Same constructor, attributes and methods as the reference class
+(optbayesexpt/particlepdf.py:12-345); every numerical step is a HIP kernel in
+libobe_hip.so reached through ctypes.  The host keeps only what must stay on the host
+for stream parity with the reference: the NumPy ``Generator`` (``self.rng``) that
+produces the uniforms and normals of a resample, and the D x D SVD of the nudge
+covariance (LAPACK, exactly as ``Generator.multivariate_normal`` does it).
+"""
+import ctypes
+import warnings
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._mirror import Mirror
+
+_P = ctypes.c_void_p
+SQRT_EPS = float(np.sqrt(np.finfo(np.float64).eps))   # numpy's tolerance on sum(p) in choice()
+
+
+def _ptr(t):
+    return _P(t.data_ptr())
+
+
+class ParticlePDF:
+    """A probability distribution represented by weighted samples ("particles").
+
+    Arguments and keyword arguments are those of the reference (particlepdf.py:79-80);
+    ``use_jit`` is accepted and ignored (the HIP kernels replace the numba hooks).
+    ``device`` (extension) selects the GPU; default: the current torch device.
+
+    Extension, ``tuning_parameters['strict_cdf']`` (default ``False``): build the
+    resampling CDF in np.cumsum's serial rounding order (bit-identical CDF, ~ms at 1e6
+    particles) instead of the parallel blocked scan.
+    """
+
+    def __init__(self, prior, a_param=0.98, resample_threshold=0.5,
+                 auto_resample=True, scale=True, use_jit=True, device=None):
+        self._lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("optbayesexpt_amd needs a HIP device (MI355X / gfx950); "
+                               "there is no CPU fallback")
+        self._device = torch.device(device) if device is not None else \
+            torch.device("cuda", torch.cuda.current_device())
+
+        #: dict: a_param / resample_threshold / auto_resample / scale, read at call time
+        self.tuning_parameters = {"a_param": a_param,
+                                  "resample_threshold": resample_threshold,
+                                  "auto_resample": auto_resample,
+                                  "scale": scale}
+        self._set_cloud(prior, None)
+        #: bool: True if the last bayesian_update() resampled
+        self.just_resampled = False
+        #: numpy Generator feeding randdraw() and resample(); reseed by assignment
+        self.rng = np.random.default_rng()
+        self._host_out = np.zeros(16)
+
+    # ------------------------------------------------------------------ state
+    def _set_cloud(self, samples, weights):
+        host = np.asarray(samples)
+        if host.ndim != 2:
+            raise ValueError("prior/samples must be n_dims x n_particles")
+        self._particles = Mirror(self._device, host=host)
+        self.n_particles = host.shape[-1]
+        self.n_dims = host.shape[0]
+        if self.n_dims > _lib.OBE_MAX_DIMS:
+            raise ValueError(f"at most {_lib.OBE_MAX_DIMS} parameters are supported on the device")
+        self._weights = Mirror(self._device, host=np.ones(self.n_particles) / self.n_particles)
+        self._alloc_scratch()
+        if weights is not None:
+            # weights / np.sum(weights) (particlepdf.py:171) as a device pass: uniform
+            # weights times the given array, normalised by its sum
+            self._host_out = np.zeros(16)
+            self._weights = Mirror(self._device, host=np.ones(self.n_particles))
+            lik = torch.from_numpy(np.array(weights, dtype=np.float64)).to(self._device)
+            w = self._weights.tensor()
+            self._lib.call("obe_bayes_update_lik", _ptr(lik), self.n_particles, _ptr(w), _ptr(self._ws),
+                           self._ws_bytes, _lib.host_ptr(self._host_out), self._stream())
+            self._weights.mark_device_written()
+
+    def _scratch_dims(self):
+        """(n_settings, n_channels) the workspace must cover; OptBayesExpt overrides."""
+        return 1, 1
+
+    def _alloc_scratch(self):
+        n, d = self.n_particles, self.n_dims
+        n_settings, n_channels = self._scratch_dims()
+        nbytes = self._lib.workspace_bytes(n, n_settings, n_channels, d)
+        self._ws = torch.empty(nbytes // 8 + 1, dtype=torch.float64, device=self._device)
+        self._ws_bytes = self._ws.numel() * 8
+        self._moments_dev = torch.zeros(self._lib.moments_len(d), dtype=torch.float64, device=self._device)
+        self._moments_host = np.zeros(self._lib.moments_len(d))
+        self._mom_host_key = None      # (particles version, weights version, has_cov) of the host copy
+        self._mom_dev_key = None       # same, for the device copy
+        self._cdf_dev = torch.empty(n, dtype=torch.float64, device=self._device)
+        self._cdf_key = None           # (weights version, strict)
+        self._sumsq_key = None         # weights version for which _sumsq is valid
+        self._sumsq = None
+        self.last_draw_indices_device = None
+
+    @property
+    def particles(self):
+        """``n_dims x n_particles`` ndarray (host mirror of the device array)."""
+        return self._particles.host()
+
+    @particles.setter
+    def particles(self, value):
+        value = np.asarray(value)
+        self._particles.set_host(value)
+        self.n_particles = value.shape[-1]
+        self.n_dims = value.shape[0]
+
+    @property
+    def particle_weights(self):
+        """ndarray of probability weights; in-place writes are tracked and uploaded."""
+        return self._weights.host()
+
+    @particle_weights.setter
+    def particle_weights(self, value):
+        self._weights.set_host(np.asarray(value))
+
+    @property
+    def _particle_indices(self):
+        return np.arange(self.n_particles, dtype="int")
+
+    def _stream(self):
+        return _P(torch.cuda.current_stream(self._device).cuda_stream)
+
+    def _pw_tensors(self):
+        p, w = self._particles.tensor(), self._weights.tensor()
+        if p.shape[1] != w.shape[0]:
+            raise ValueError("particles and particle_weights have different lengths")
+        return p, w
+
+    # ---------------------------------------------------------------- set_pdf
+    def set_pdf(self, samples, weights=None):
+        """Re-initialise the distribution (particlepdf.py:147-171)."""
+        samples = np.asarray(samples)
+        if weights is not None:
+            if len(weights) != samples.shape[-1]:
+                raise ValueError("Length of weights does not match the number of particles.")
+            weights = np.asarray(weights, dtype=np.float64)
+        self._set_cloud(samples, weights)
+
+    # ---------------------------------------------------------------- moments
+    def _moments(self, want_cov):
+        """Host copy of the K3 output block (computes it if stale); synchronises."""
+        key = (self._particles.version, self._weights.version)
+        hk = self._mom_host_key
+        if hk is not None and hk[:2] == key and (hk[2] or not want_cov):
+            return self._moments_host
+        p, w = self._pw_tensors()
+        self._lib.call("obe_moments", _ptr(p), p.shape[1], self.n_dims, self.n_particles, _ptr(w),
+                       1 if want_cov else 0, _ptr(self._moments_dev), _lib.host_ptr(self._moments_host),
+                       _ptr(self._ws), self._ws_bytes, self._stream())
+        self._mom_host_key = self._mom_dev_key = key + (bool(want_cov),)
+        return self._moments_host
+
+    def _moments_on_device(self):
+        """Device copy of the first moments, current for the present cloud (no sync)."""
+        key = (self._particles.version, self._weights.version)
+        dk = self._mom_dev_key
+        if dk is None or dk[:2] != key:
+            p, w = self._pw_tensors()
+            self._lib.call("obe_moments", _ptr(p), p.shape[1], self.n_dims, self.n_particles, _ptr(w),
+                           0, _ptr(self._moments_dev), None, _ptr(self._ws), self._ws_bytes, self._stream())
+            self._mom_dev_key = key + (False,)
+        return self._moments_dev
+
+    def mean(self):
+        """Weighted mean, shape ``(n_dims,)`` (particlepdf.py:173-183)."""
+        d = self.n_dims
+        return self._moments(False)[2:2 + d].copy()
+
+    def covariance(self):
+        """Weighted covariance ``(n_dims, n_dims)`` (particlepdf.py:185-198)."""
+        d = self.n_dims
+        m = self._moments(True)
+        return m[2 + 4 * d:2 + 4 * d + d * d].reshape((d, d)).copy()
+
+    def std(self):
+        """Per-parameter standard deviation (particlepdf.py:200-214)."""
+        d = self.n_dims
+        return self._moments(False)[2 + 3 * d:2 + 4 * d].copy()
+
+    # ------------------------------------------------------------ Bayes update
+    def bayesian_update(self, likelihood):
+        """weights <- normalised(weights * likelihood), then the resample test
+        (particlepdf.py:216-234).  ``likelihood`` is an ndarray or a device tensor."""
+        if isinstance(likelihood, torch.Tensor):
+            lik = likelihood.to(device=self._device, dtype=torch.float64).contiguous()
+        else:
+            lik = torch.from_numpy(np.array(
+                np.broadcast_to(np.asarray(likelihood, dtype=np.float64), (self.n_particles,)))).to(self._device)
+        w = self._weights.tensor()
+        self._lib.call("obe_bayes_update_lik", _ptr(lik), self.n_particles, _ptr(w), _ptr(self._ws),
+                       self._ws_bytes, _lib.host_ptr(self._host_out), self._stream())
+        self._after_weight_update(self._host_out[1])
+
+    def _after_weight_update(self, sum_w2):
+        self._weights.mark_device_written()
+        self._sumsq, self._sumsq_key = float(sum_w2), self._weights.version
+        if self.tuning_parameters["auto_resample"]:
+            self.resample_test()
+
+    def _sum_w2(self):
+        if self._sumsq_key != self._weights.version:
+            w = self._weights.tensor()
+            self._lib.call("obe_weight_sums", _ptr(w), self.n_particles, _ptr(self._ws), self._ws_bytes,
+                           _lib.host_ptr(self._host_out), self._stream())
+            self._sumsq, self._sumsq_key = float(self._host_out[0]), self._weights.version
+        return self._sumsq
+
+    def resample_test(self):
+        """Resample if the effective particle number is low (particlepdf.py:236-258)."""
+        with np.errstate(divide="ignore"):
+            n_eff = np.float64(1.0) / np.float64(self._sum_w2())
+        self.last_n_eff = float(n_eff)
+        if n_eff < 0.1 * self.n_particles:
+            warnings.warn("\nParticle filter rejected > 90 % of particles. "
+                          f"N_eff = {n_eff:.2f}. "
+                          "Particle impoverishment may lead to errors.",
+                          RuntimeWarning)
+            self.resample()
+            self.just_resampled = True
+        elif n_eff / self.n_particles < self.tuning_parameters["resample_threshold"]:
+            self.resample()
+            self.just_resampled = True
+        else:
+            self.just_resampled = False
+
+    # --------------------------------------------------------------- resample
+    def _cdf(self):
+        strict = bool(self.tuning_parameters.get("strict_cdf", False))
+        key = (self._weights.version, strict)
+        if self._cdf_key != key:
+            w = self._weights.tensor()
+            if self._cdf_dev.numel() != self.n_particles:
+                self._cdf_dev = torch.empty(self.n_particles, dtype=torch.float64, device=self._device)
+            self._lib.call("obe_weight_cdf", _ptr(w), self.n_particles, 1 if strict else 0,
+                           _ptr(self._cdf_dev), _lib.host_ptr(self._host_out), _ptr(self._ws),
+                           self._ws_bytes, self._stream())
+            total = self._host_out[0]
+            # numpy's validation of p in Generator.choice (ValueError in the reference)
+            if total != total:
+                raise ValueError("probabilities contain NaN")
+            if abs(total - 1.0) > SQRT_EPS:
+                raise ValueError("probabilities do not sum to 1")
+            self._cdf_key = key
+        return self._cdf_dev
+
+    def _draw_indices(self, n_draws):
+        """Device int64 indices of ``n_draws`` weighted draws: uniforms from self.rng
+        (host, same stream as Generator.choice), CDF search on the device."""
+        if self._weights.shape[0] != self.n_particles:
+            raise ValueError("a and p must have same size")
+        cdf = self._cdf()
+        u = self.rng.random(n_draws)
+        u_dev = torch.from_numpy(np.atleast_1d(u)).to(self._device)
+        idx = torch.empty(n_draws, dtype=torch.int64, device=self._device)
+        self._lib.call("obe_cdf_search", _ptr(cdf), self.n_particles, _ptr(u_dev), n_draws, _ptr(idx),
+                       self._stream())
+        self.last_draw_indices_device = idx
+        return idx
+
+    def randdraw(self, n_draws=1):
+        """``n_dims x n_draws`` weighted random draws (particlepdf.py:312-345)."""
+        idx = self._draw_indices(n_draws)
+        p = self._particles.tensor()
+        out = torch.empty((self.n_dims, n_draws), dtype=torch.float64, device=self._device)
+        self._lib.call("obe_gather_columns", _ptr(p), p.shape[1], self.n_dims, self.n_particles, _ptr(idx),
+                       n_draws, _ptr(out), n_draws, self._stream())
+        return out.cpu().numpy()
+
+    @property
+    def last_draw_indices(self):
+        """Host copy of the particle indices of the most recent draw (diagnostic)."""
+        t = self.last_draw_indices_device
+        return None if t is None else t.cpu().numpy()
+
+    def resample(self):
+        """Multinomial resample + Gaussian nudge (+ contraction if ``scale``)
+        (particlepdf.py:260-310).  RNG order as in the reference: N uniforms, then
+        N x D standard normals."""
+        n, d = self.n_particles, self.n_dims
+        idx = self._draw_indices(n)
+        m = self._moments(True)                       # pre-resample weights (:290-291)
+        mean = m[2:2 + d].copy()
+        cov = m[2 + 4 * d:2 + 4 * d + d * d].reshape((d, d))
+        a = self.tuning_parameters["a_param"]
+        newcov = (1 - a ** 2) * cov
+        # Generator.multivariate_normal(method='svd'): x = z @ (u * sqrt(s)).T
+        u, s, vh = np.linalg.svd(newcov)
+        if not np.allclose(np.dot(vh.T * s, vh), newcov, rtol=1e-8, atol=1e-8):
+            warnings.warn("covariance is not symmetric positive-semidefinite.", RuntimeWarning)
+        factor = np.ascontiguousarray(u * np.sqrt(s))
+        z = self.rng.standard_normal((n, d))
+        z_dev = torch.from_numpy(z).to(self._device)
+        old = self._particles.tensor()
+        new = torch.empty((d, n), dtype=torch.float64, device=self._device)
+        w = self._weights.tensor()
+        self._lib.call("obe_resample_particles", _ptr(old), old.shape[1], d, n, _ptr(idx), _ptr(z_dev),
+                       _lib.host_ptr(factor), _lib.host_ptr(mean), float(a),
+                       1 if self.tuning_parameters["scale"] else 0, _ptr(new), n, _ptr(w), self._stream())
+        self._particles = Mirror(self._device, tensor=new)
+        self._weights.mark_device_written()
+        self.last_resample_indices_device = idx
+
+    @staticmethod
+    def _normalized_product(weight_array, likelihood_array):
+        """Kept for API compatibility (particlepdf.py:347-360); the product path is
+        ``bayesian_update``."""
+        raise NotImplementedError("use ParticlePDF.bayesian_update(); the normalised product "
+                                  "runs on the device")

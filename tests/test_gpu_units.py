@@ -1,0 +1,402 @@
+"""HIP path unit parity (GPU): every C-ABI family against the golden unit vectors, the
+oracle on seeded random inputs, and the literal expectations of the reference's own
+unit tests (same toy inputs).  Integer results exact, float64 results to 1e-10."""
+import warnings
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose, assert_array_equal
+
+import _replay
+import oracle
+from oracle import models as omodels
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def obe(hip):
+    import optbayesexpt_amd
+    return optbayesexpt_amd
+
+
+@pytest.fixture(scope="module")
+def unit():
+    return _replay.load("unit_cases.npz")
+
+
+# ----------------------------------------------------------------- K3 moments
+@pytest.mark.parametrize("d", [1, 3, 10])
+def test_moments_match_reference(obe, unit, d):
+    x, w = unit[f"mom{d}_x"], unit[f"mom{d}_w"]
+    pdf = obe.ParticlePDF(x)
+    pdf.particle_weights = w
+    assert_allclose(pdf.mean(), unit[f"mom{d}_mean"], rtol=1e-12)
+    cov = pdf.covariance()
+    assert cov.shape == (d, d)
+    assert_allclose(cov, unit[f"mom{d}_cov"], rtol=1e-12, atol=1e-12 * np.abs(unit[f"mom{d}_cov"]).max())
+    # std() is a one-pass formula: accuracy eps*<x^2>/var
+    sd = unit[f"mom{d}_std"]
+    tol = 1e-12 * sd + 64 * 2.3e-16 * unit[f"mom{d}_mean"] ** 2 / sd
+    assert np.all(np.abs(pdf.std() - sd) <= tol)
+
+
+def test_moments_large_ragged(obe):
+    g = np.random.default_rng(5)
+    for n in (1, 63, 64, 65, 255, 257, 100003):
+        x = g.normal(3, 2, (4, n))
+        w = g.exponential(1, n)
+        w /= w.sum()
+        pdf = obe.ParticlePDF(x)
+        pdf.particle_weights = w
+        assert_allclose(pdf.mean(), oracle.weighted_mean(x, w), rtol=1e-12)
+        if n > 1:
+            ref = oracle.weighted_covariance(x, w)
+            assert_allclose(pdf.covariance(), ref, rtol=1e-11, atol=1e-12 * np.abs(ref).max())
+
+
+# ------------------------------------------------------- K4 draws and resample
+@pytest.mark.parametrize("tag,scale", [("s0", False), ("s1", True)])
+@pytest.mark.parametrize("strict", [False, True])
+def test_randdraw_and_resample_match_reference(obe, unit, tag, scale, strict):
+    pdf = obe.ParticlePDF(unit[f"rs_{tag}_x"].copy(), scale=scale)
+    pdf.tuning_parameters["strict_cdf"] = strict
+    pdf.particle_weights = unit[f"rs_{tag}_w"].copy()
+    pdf.rng = np.random.default_rng(4242)
+    draws = pdf.randdraw(30)
+    assert_array_equal(pdf.last_draw_indices, unit[f"rs_{tag}_draw_idx"])       # bit-exact indices
+    assert_array_equal(draws, unit[f"rs_{tag}_draws"])
+    pdf.resample()
+    assert_array_equal(pdf.last_draw_indices, unit[f"rs_{tag}_resample_idx"])   # bit-exact indices
+    ref = unit[f"rs_{tag}_particles"]
+    got = pdf.particles
+    assert got.shape == ref.shape
+    for i in range(ref.shape[0]):
+        assert_allclose(got[i], ref[i], rtol=RTOL)
+    assert_array_equal(pdf.particle_weights, unit[f"rs_{tag}_weights"])
+
+
+def test_strict_cdf_is_bitwise_numpy_cumsum(obe, hip):
+    """tuning_parameters['strict_cdf']: the device CDF equals np.cumsum(w)/cumsum[-1] bit
+    for bit; the parallel scan agrees to ~1e-13 and gives the same indices."""
+    import torch
+    from optbayesexpt_amd import _lib
+    from optbayesexpt_amd.particlepdf import _ptr
+    g = np.random.default_rng(11)
+    for n in (1, 5, 64, 1000, 2048, 2049, 300001):
+        w = g.exponential(1.0, n) ** 2
+        w /= w.sum()
+        ref = oracle.weight_cdf(w)
+        wd = torch.from_numpy(w).cuda()
+        ws = torch.empty(hip.workspace_bytes(n, 1, 1, 1) // 8 + 1, dtype=torch.float64, device="cuda")
+        out = {}
+        for strict in (1, 0):
+            cdf = torch.empty(n, dtype=torch.float64, device="cuda")
+            tot = np.zeros(1)
+            hip.call("obe_weight_cdf", _ptr(wd), n, strict, _ptr(cdf), _lib.host_ptr(tot), _ptr(ws),
+                     ws.numel() * 8, None)
+            out[strict] = cdf.cpu().numpy()
+        assert_array_equal(out[1], ref)
+        assert_allclose(out[0], ref, rtol=1e-12)
+        assert out[0][-1] == 1.0
+        u = g.random(4096)
+        ud = torch.from_numpy(u).cuda()
+        for strict in (1, 0):
+            idx = torch.empty(u.size, dtype=torch.int64, device="cuda")
+            cdf = torch.from_numpy(out[strict]).cuda()
+            hip.call("obe_cdf_search", _ptr(cdf), n, _ptr(ud), u.size, _ptr(idx), None)
+            assert_array_equal(idx.cpu().numpy(), ref.searchsorted(u, side="right"))
+
+
+# ------------------------------------------------------------- K2 Bayes update
+def test_bayes_update_nan_inf_and_zero_likelihood(obe, unit):
+    n = unit["bu_w"].size
+    pdf = obe.ParticlePDF(np.zeros((1, n)), auto_resample=False)
+    pdf.particle_weights = unit["bu_w"].copy()
+    pdf.bayesian_update(unit["bu_lik"])
+    assert_allclose(pdf.particle_weights, unit["bu_out"], rtol=1e-12)
+    assert_array_equal(pdf.particle_weights == 0, unit["bu_out"] == 0)           # NaN -> 0
+    pdf.particle_weights = unit["bu_w"].copy()
+    pdf.bayesian_update(np.zeros(n))                                               # 0/0 -> zeros
+    assert not np.any(pdf.particle_weights)
+    pdf.resample_test()
+    assert np.isinf(pdf.last_n_eff) and pdf.just_resampled is False
+    lik = np.ones(n)
+    lik[7] = np.inf                                                                # inf -> DBL_MAX
+    pdf.particle_weights = unit["bu_w"].copy()
+    pdf.bayesian_update(lik)
+    with np.errstate(all="ignore"):
+        assert_allclose(pdf.particle_weights, oracle.normalized_product(unit["bu_w"], lik), rtol=1e-12)
+
+
+def test_infer_matches_reference_and_analytic(obe, unit):
+    """reference tests/test_zinference.py:89-108."""
+    xs = unit["infer_x"]
+    n = xs.size
+
+    class MyObe(obe.OptBayesExpt):
+        def enforce_parameter_constraints(self):
+            bad = np.argwhere(self.parameters[1] < 0)
+            for index in bad:
+                self.particle_weights[index] = 0
+            self.particle_weights = self.particle_weights / np.sum(self.particle_weights)
+
+    o = MyObe(obe.models.first_parameter(), (0,), (xs, np.ones(n)), (0,))
+    o.tuning_parameters["resample_threshold"] = 0
+    o.pdf_update(((), 1.0, 1.0))
+    known = np.exp(-(1.0 - xs) ** 2 / 2) / np.sqrt(2 * np.pi)
+    known /= np.sum(known)
+    assert_allclose(o.particle_weights, known, atol=1e-15, rtol=1e-15)    # the reference's own bar
+    assert_allclose(o.particle_weights, unit["infer_w"], rtol=1e-12, atol=1e-300)
+    # sigma passed as an (N_p,) array: only element 0 is consumed (zip truncation)
+    o2 = MyObe(obe.models.first_parameter(), (0,), (xs, np.ones(n)), (0,))
+    o2.tuning_parameters["resample_threshold"] = 0
+    o2.pdf_update(((), 1.0, o2.parameters[1]))
+    assert_allclose(o2.particle_weights, unit["infer_w"], rtol=1e-12, atol=1e-300)
+
+
+def test_likelihood_two_channel_choke(obe, unit):
+    n = unit["lk_ym"].shape[1]
+    o = obe.OptBayesExpt(obe.models.coil(), (np.logspace(4, 6, 5),), np.ones((4, n)), (), choke=0.6)
+    got = o.likelihood(unit["lk_ym"], ((1.0,), (0.3, -0.2), (1.5, 0.7)))
+    assert_allclose(got, unit["lk_out"], rtol=1e-12)
+
+
+# ------------------------------------- the reference's own unit tests, restated
+def _toy_pdf(obe):
+    return obe.ParticlePDF((np.array([0, 1, 2, 3]), np.array([1, 3, 2, 4])))
+
+
+def test_reference_particlepdf_literals(obe):
+    """reference tests/test_particlepdf.py:17-152, same inputs and expected values."""
+    pdf = _toy_pdf(obe)
+    assert (pdf.n_dims, pdf.n_particles) == (2, 4)
+    assert_array_equal(np.asarray([[0, 1, 2, 3], [1, 3, 2, 4]]), pdf.particles)
+    assert_array_equal([.25, .25, .25, .25], pdf.particle_weights)
+    assert pdf.just_resampled is False
+    assert pdf.mean().shape == (2,)
+    assert_allclose(pdf.mean(), (1.5, 2.5), rtol=1e-15)
+    assert_allclose(pdf.covariance(), [[5 / 3, 4 / 3], [4 / 3, 5 / 3]])
+    assert_allclose(pdf.std(), np.sqrt(np.array([1, 1]) * 5.0 / 4.0), rtol=1e-15)
+    samples = np.arange(15).reshape((3, 5))
+    pdf.set_pdf(samples)
+    assert (pdf.n_dims, pdf.n_particles) == (3, 5)
+    assert_array_equal(samples, pdf.particles)
+    assert_array_equal(np.ones(5) / 5.0, pdf.particle_weights)
+    pdf.set_pdf(samples, weights=np.array([1, 2, 3, 4, 5]))
+    assert_allclose(pdf.particle_weights, np.array([1, 2, 3, 4, 5]) / 15, rtol=1e-15)
+    with pytest.raises(ValueError):
+        pdf.set_pdf(samples, weights=np.ones(4))
+    pdf = _toy_pdf(obe)
+    pdf.tuning_parameters["auto_resample"] = False
+    lik = np.array([.5, 1.5, 1.5, .5])
+    pdf.bayesian_update(lik)
+    assert_allclose(pdf.particle_weights, lik / np.sum(lik), rtol=1e-15)
+    pdf = _toy_pdf(obe)
+    pdf.particle_weights = np.array([0, .5, .5, 0])
+    pdf.resample()
+    assert pdf.particles.shape == (2, 4)
+    assert_array_equal([.25, .25, .25, .25], pdf.particle_weights)
+    pdf = _toy_pdf(obe)
+    pdf.particle_weights = np.array([.1, .4, .4, .1])      # N_eff 2.94
+    pdf.resample_test()
+    assert pdf.just_resampled is False
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        pdf.particle_weights = np.array([0, .75, .25, 0])  # N_eff 1.6
+        pdf.resample_test()
+    assert pdf.just_resampled is True
+
+
+def test_reference_optbayesexpt_literals(obe):
+    """reference tests/test_optbayesexpt.py:21-69."""
+    pars = (np.array([0, 1, 2, 3]), np.array([1, 3, 2, 4]))
+    o = obe.OptBayesExpt(obe.models.line_ab(), (np.array([0, 1, 2]),), pars, ())
+    assert_array_equal((np.array([0, 1, 2]),), o.allsettings)
+    assert_array_equal(pars, o.parameters)
+    assert_array_equal([[1, 4, 4, 7]], o.eval_over_all_parameters((1,)))
+    assert_array_equal([[1, 4, 7]], o.eval_over_all_settings([1, 3]))
+    ymodel = np.array(((1, 4, 4, 7),))
+    assert_allclose(o.likelihood(ymodel, ((1,), (5.0,), 1.0)), np.exp(-(ymodel - 5.0) ** 2 / 2)[0], rtol=1e-15)
+    lkl = np.exp(-(np.array((1, 4, 4, 7)) - 5.0) ** 2 / 2)
+    parts, wts = o.pdf_update(((1,), 5.0, 1.0))
+    assert_allclose(o.particle_weights, lkl / np.sum(lkl), rtol=1e-15)
+    assert_array_equal(parts, o.particles)
+    with pytest.raises(SyntaxError):
+        obe.OptBayesExpt(obe.models.line_ab(), (np.array([0, 1, 2]),), pars, (), utility_method="nope")
+    with pytest.raises(SyntaxError):
+        obe.OptBayesExpt(obe.models.line_ab(), (np.array([0, 1, 2]),), pars, (), selection_method="nope")
+    with pytest.raises(RuntimeError):
+        obe.OptBayesExptNoiseParameter(obe.models.line_ab(), (np.array([0, 1, 2]),), pars, (),
+                                       noise_parameter_index=(0, 1))
+
+
+# --------------------------------------------------- K1 full sweep (D1-ii) parity
+def _full_cases(obe, f):
+    m = obe.models
+    return [("lor", m.lorentzian(), omodels.lorentzian, (f["fs_lor_x"],), (0.1,), None, 500.0),
+            ("ml7", m.lorentzian(7), omodels.multi_lorentzian(7), (f["fs_lor_x"],), (0.1,), 9, None),
+            ("coil", m.coil(), omodels.coil, (f["fs_coil_w"],), (), (3, 3), None),
+            ("rabi", m.rabi(), omodels.rabi, (f["fs_rabi_s0"], f["fs_rabi_s1"]),
+             (100000.0, 0.01, 2.0), None, 300.0)]
+
+
+def _make(obe, dm, sv, prior, cons, noise_idx, noise_std, **kw):
+    if noise_idx is None:
+        return obe.OptBayesExpt(dm, sv, prior.copy(), cons, utility_method="variance_full",
+                                default_noise_std=noise_std, **kw)
+    return obe.OptBayesExptNoiseParameter(dm, sv, prior.copy(), cons, utility_method="variance_full",
+                                          noise_parameter_index=noise_idx, **kw)
+
+
+def test_full_sweep_uniform_matches_reference(obe):
+    """Reference driven with every particle as a draw (golden) vs the HIP full sweep."""
+    f = _replay.load("full_sweep_uniform.npz")
+    for tag, dm, _, sv, cons, nidx, nstd in _full_cases(obe, f):
+        o = _make(obe, dm, sv, f[f"fs_{tag}_prior"], cons, nidx, nstd)
+        yvar = o.yvar_from_parameter_draws()
+        ref = f[f"fs_{tag}_yvar"]
+        assert yvar.shape == ref.shape
+        assert_allclose(yvar, ref, rtol=RTOL, atol=1e-13 * ref.max(), err_msg=tag)
+        util = o.utility()
+        assert_allclose(util, f[f"fs_{tag}_utility"], rtol=RTOL, atol=1e-13 * f[f"fs_{tag}_utility"].max())
+        o.opt_setting()
+        assert o.last_setting_index == int(np.argmax(f[f"fs_{tag}_utility"]))
+
+
+def test_full_sweep_nonuniform_weights_matches_oracle(obe):
+    """After real updates the weights are non-uniform: HIP weighted variance vs the
+    oracle's two-pass weighted variance (not expressible with the reference itself)."""
+    f = _replay.load("full_sweep_uniform.npz")
+    g = np.random.default_rng(99)
+    for tag, dm, fn, sv, cons, nidx, nstd in _full_cases(obe, f):
+        prior = f[f"fs_{tag}_prior"]
+        o = _make(obe, dm, sv, prior, cons, nidx, nstd, auto_resample=False)
+        w = g.exponential(1.0, prior.shape[1]) ** 2
+        w /= w.sum()
+        o.particle_weights = w
+        yvar = o.yvar_from_parameter_draws()
+        ref = oracle.yvar_full_sweep(fn, oracle.flatten_settings(sv), prior, w, cons, chunk=512)
+        assert_allclose(yvar, ref, rtol=RTOL, atol=1e-13 * ref.max(), err_msg=tag)
+
+
+def test_sweep_shapes_ragged(obe):
+    """Setting counts around every tile boundary, particle counts around chunk/tile
+    boundaries, draws mode and full mode; against the oracle."""
+    g = np.random.default_rng(3)
+    for ns, n in [(1, 1), (1, 300), (63, 64), (257, 1000), (1025, 2049), (4099, 513)]:
+        prior = np.array([g.uniform(2, 4, n), g.uniform(-2000, -400, n), g.normal(50000, 1000, n)])
+        sv = (np.linspace(1.5, 4.5, ns),)
+        w = g.exponential(1.0, n)
+        w /= w.sum()
+        o = obe.OptBayesExpt(obe.models.lorentzian(), sv, prior.copy(), (0.1,),
+                             utility_method="variance_full", auto_resample=False, default_noise_std=7.0)
+        o.particle_weights = w
+        ref = oracle.yvar_full_sweep(omodels.lorentzian, oracle.flatten_settings(sv), prior, w, (0.1,))
+        assert_allclose(o.yvar_from_parameter_draws(), ref, rtol=RTOL, atol=1e-13 * ref.max() + 1e-18)
+        util = oracle.utility_from_yvar(ref, 49.0, 1.0)
+        o.opt_setting()
+        assert o.last_setting_index == int(np.argmax(util))
+        # reference-semantics mode on the same cloud
+        o2 = obe.OptBayesExpt(obe.models.lorentzian(), sv, prior.copy(), (0.1,), n_draws=30,
+                              auto_resample=False)
+        o2.particle_weights = w
+        o2.rng = np.random.default_rng(8)
+        got = o2.yvar_from_parameter_draws()
+        idx = o2.last_draw_indices
+        ref2 = oracle.yvar_from_draws(omodels.lorentzian, oracle.flatten_settings(sv), prior[:, idx], (0.1,))
+        assert_array_equal(idx, oracle.choice_indices(w, np.random.default_rng(8).random(30)))
+        assert_allclose(got, ref2, rtol=RTOL, atol=1e-13 * ref2.max() + 1e-18)   # 1e-18: (eps*y)^2 of identical draws
+
+
+def test_argmax_semantics(obe, hip):
+    """np.argmax: first maximum wins, NaN beats everything."""
+    import torch
+    from optbayesexpt_amd import _lib
+    from optbayesexpt_amd.particlepdf import _ptr
+    g = np.random.default_rng(1)
+    ws = torch.empty(hip.workspace_bytes(1, 1 << 20, 1, 1) // 8 + 1, dtype=torch.float64, device="cuda")
+    cases = []
+    for n in (1, 2, 255, 256, 257, 70001):
+        v = g.normal(size=n)
+        cases.append(v)
+        t = v.copy()
+        t[[0, n // 2, n - 1]] = v.max() + 1          # ties
+        cases.append(t)
+        q = v.copy()
+        q[n // 3] = np.nan
+        q[n - 1] = np.nan
+        cases.append(q)
+        cases.append(np.full(n, -np.inf))
+    for v in cases:
+        best, idx = np.zeros(1), np.zeros(1, dtype=np.int64)
+        hip.call("obe_argmax", _ptr(torch.from_numpy(v).cuda()), v.size, _lib.host_ptr(best),
+                 _lib.host_ptr(idx), _ptr(ws), ws.numel() * 8, None)
+        assert int(idx[0]) == int(np.argmax(v))
+
+
+# ----------------------------------------------------------- hooks and mirrors
+def test_hooks_cost_array_and_inplace_weight_writes(obe):
+    """demos/lockin/lockin_of_coil.py:115-152 pattern: a subclass that overrides
+    cost_estimate() with a per-setting array and zeroes weights in place."""
+    g = np.random.default_rng(21)
+    n, ns = 3000, 97
+    prior = np.array([g.uniform(2, 4, n), g.uniform(-2000, -400, n), g.normal(50000, 1000, n)])
+    sv = (np.linspace(1.5, 4.5, ns),)
+
+    class Sub(obe.OptBayesExpt):
+        def cost_estimate(self):
+            cost = np.ones_like(self.allsettings[0]) * 3.0
+            cost[self.last_setting_index] = 1.0
+            return cost
+
+        def enforce_parameter_constraints(self):
+            bad = np.argwhere(self.parameters[0] < 2.5).flatten()
+            for i in bad:
+                self.particle_weights[i] = 0
+            self.particle_weights = self.particle_weights / np.sum(self.particle_weights)
+
+    class OSub(oracle.OracleOptBayesExpt):
+        cost_estimate = Sub.cost_estimate
+        enforce_parameter_constraints = Sub.enforce_parameter_constraints
+
+    a = Sub(obe.models.lorentzian(), sv, prior.copy(), (0.1,), scale=False, default_noise_std=100.0)
+    b = OSub(omodels.lorentzian, sv, prior.copy(), (0.1,), scale=False, default_noise_std=100.0)
+    a.rng, b.rng = np.random.default_rng(5), np.random.default_rng(5)
+    sim = np.random.default_rng(6)
+    resamples = 0
+    for cyc in range(25):
+        xa, xb = a.opt_setting(), b.opt_setting()
+        assert a.last_setting_index == b.last_setting_index
+        y = float(omodels.lorentzian(xb, (3.0, -1000.0, 50000.0), (0.1,)) + 100 * sim.standard_normal())
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            a.pdf_update((xa, y, 100.0))
+            b.pdf_update((xb, y, 100.0))
+        assert a.just_resampled == b.just_resampled
+        resamples += a.just_resampled
+        assert_allclose(a.particle_weights, b.particle_weights, rtol=RTOL, atol=1e-13 * b.particle_weights.max())
+    assert resamples >= 2
+    assert np.sum(a.particle_weights == 0) == np.sum(b.particle_weights == 0)
+
+
+def test_set_pdf_keeps_stale_parameters_alias(obe):
+    """set_pdf() re-initialises particles but not ``parameters`` (obe_base.py:185,395):
+    the next pdf_update evaluates the model on the old samples, as in the reference."""
+    g = np.random.default_rng(2)
+    n = 500
+    p1 = np.array([g.uniform(-1, 1, n), g.uniform(-1, 1, n)])
+    p2 = np.array([g.uniform(-1, 1, n), g.uniform(-1, 1, n)])
+    sv = (np.linspace(0, 1, 11),)
+    a = obe.OptBayesExpt(obe.models.line_ab(), sv, p1.copy(), (), auto_resample=False)
+    b = oracle.OracleOptBayesExpt(omodels.line_ab, sv, p1.copy(), (), auto_resample=False)
+    for o in (a, b):
+        o.set_pdf(p2.copy())
+        o.pdf_update(((0.5,), 0.2, 0.3))
+    assert_array_equal(a.particles, p2)
+    assert_allclose(a.particle_weights, b.particle_weights, rtol=RTOL)
+    for o in (a, b):
+        o.pdf_update(((0.25,), 0.1, 0.3))
+    assert_allclose(a.particle_weights, b.particle_weights, rtol=RTOL)
