@@ -1,0 +1,248 @@
+#!/usr/bin/env python
+"""bench.py — model-evals/s per opt_setting()+pdf_update() cycle, fp64 (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c5]
+
+One "step" is one measurement cycle of the hot path on synthetic data:
+``x = obe.opt_setting()`` (full settings x particles utility sweep, argmax) followed by
+``obe.pdf_update((x, y, sigma))`` (Bayes update, N_eff test, resample when it triggers).
+Default workload = BASELINE.json configs[2] ("c3": Lorentzian 3-param, 65 536 settings x
+1 048 576 particles, the config the metric's target is quoted on; it fits one GPU).
+With N > 1 (launched by torch.distributed.run, one process per GPU) the settings axis
+is sharded — configs[3] — and the per-rank maxima are combined with one RCCL
+all-gather; total work is fixed, so ``scaling`` is "strong".
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      — the dominant kernel (K1 sweep): achieved FP64 TFLOP/s from HIP events
+                  around the kernel on its launch stream, against the FP64 vector peak;
+                  the algorithmic HBM figure the north_star asks for rides along.
+  roofline_update — the HBM-bound Bayes update (K2), bytes / time.
+  cpu_baseline  — the NumPy oracle on one host core, on a bounded sub-grid (N = 1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X datasheet FP64 vector = 256 CU x 128 flop/clk x 2.4 GHz
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+FLOP_PER_EVAL = {"lorentzian": 10, "lorentzian7": 46}
+
+CONFIGS = {
+    # name: (n_settings, n_particles, model, description)
+    "c2": (4096, 262144, "lorentzian", "Lorentzian 3-param, 4 096 settings x 262 144 particles"),
+    "c3": (65536, 1048576, "lorentzian", "Lorentzian 3-param, 65 536 settings x 1 048 576 particles"),
+    "c5": (16384, 524288, "lorentzian7", "7-Lorentzian sum, 10 params, 16 384 settings x 524 288 particles, "
+                                         "OptBayesExptNoiseParameter"),
+}
+
+
+def make_workload(cfg, seed=20240424):
+    """Synthetic inputs of SURVEY.md §8(d)."""
+    ns, n_p, model, _ = CONFIGS[cfg]
+    g = np.random.default_rng(seed)
+    settings = (np.linspace(1.5, 4.5, ns),)
+    if model == "lorentzian":
+        prior = np.array([g.uniform(2, 4, n_p), g.uniform(-2000, -400, n_p), g.normal(50000, 1000, n_p)])
+        true = (3.0, -1000.0, 50000.0)
+        sigma = 500.0
+    else:
+        prior = np.vstack([g.uniform(2, 4, (7, n_p)), g.uniform(400, 2000, (1, n_p)),
+                           g.normal(500, 1000, (1, n_p)), g.exponential(500, (1, n_p))])
+        true = (2.2, 2.5, 2.8, 3.1, 3.4, 3.7, 3.9, 1000.0, 500.0, 500.0)
+        sigma = 500.0
+    return settings, prior, (0.1,), true, sigma
+
+
+def build_obe(cfg, shard, settings, prior, cons):
+    import optbayesexpt_amd as obe
+    model = CONFIGS[cfg][2]
+    if model == "lorentzian":
+        return obe.OptBayesExpt(obe.models.lorentzian(1), settings, prior, cons, scale=False,
+                                utility_method="variance_full", default_noise_std=500.0,
+                                settings_shard=shard)
+    return obe.OptBayesExptNoiseParameter(obe.models.lorentzian(7), settings, prior, cons, scale=False,
+                                          utility_method="variance_full", noise_parameter_index=9,
+                                          settings_shard=shard)
+
+
+def cpu_baseline(cfg, settings, prior, cons, true, sigma, n_sub=128):
+    """The oracle (NumPy, one core) on a bounded sample of the same workload: the full
+    particle cloud against ``n_sub`` evenly spaced settings for the sweep, plus the full
+    update.  Throughput = algorithmic evals / time, to be read as evals/s of the
+    reference-style NumPy path on this host."""
+    import oracle
+    from oracle import models as om
+    fn = om.lorentzian if CONFIGS[cfg][2] == "lorentzian" else om.multi_lorentzian(7)
+    ns, n_p = CONFIGS[cfg][0], CONFIGS[cfg][1]
+    sub = (np.ascontiguousarray(settings[0][:: max(1, ns // n_sub)][:n_sub]),)
+    w = np.full(n_p, 1.0 / n_p)
+    t0 = time.perf_counter()
+    yvar = oracle.yvar_full_sweep(fn, oracle.flatten_settings(sub), prior, w, cons, chunk=4096)
+    util = oracle.utility_from_yvar(yvar, sigma ** 2, 1.0)
+    best = int(np.argmax(util))
+    x = (sub[0][best],)
+    y_model = fn(x, prior, cons)
+    lik = oracle.gauss_likelihood(y_model, float(fn(x, true, cons)), sigma)
+    w2 = oracle.normalized_product(w, lik)
+    oracle.effective_particles(w2)
+    dt = time.perf_counter() - t0
+    evals = len(sub[0]) * n_p + n_p
+    return {"value": evals / dt, "unit": "model-evals/s", "cores": 1, "kind": "port",
+            "sample": f"{len(sub[0])} of {ns} settings x all {n_p} particles (two-pass weighted variance, "
+                      f"chunked) + full {n_p}-particle update, {dt:.1f} s; NumPy ufuncs are single-threaded",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    shard = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        from optbayesexpt_amd import SettingsShard
+        shard = SettingsShard()
+
+    from optbayesexpt_amd import _lib
+    from optbayesexpt_amd.particlepdf import _ptr
+
+    cfg = args.config
+    ns, n_p, model, desc = CONFIGS[cfg]
+    settings, prior, cons, true, sigma = make_workload(cfg)
+    obe = build_obe(cfg, shard, settings, prior.copy(), cons)
+    obe.rng = np.random.default_rng(1234)               # identical on every rank: replicas stay in step
+    sim = np.random.default_rng(4321)
+    truth_fn = obe.model_function          # the DeviceModel's NumPy form, as the demos' simulators use it
+    noise_rec = model == "lorentzian"
+
+    def one_step():
+        x = obe.opt_setting()
+        y = float(truth_fn(x, true, cons)) + sigma * sim.standard_normal()
+        obe.pdf_update((x, y, sigma) if noise_rec else (x, y))
+        return int(obe.just_resampled)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    # state for the benchmark: a few real updates (non-uniform weights), SURVEY §8(d)
+    for _ in range(max(args.warmup, 0)):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    resamples = 0
+    for _ in range(args.steps):
+        resamples += one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    evals_per_step = ns * n_p + n_p
+    value = args.steps * evals_per_step / elapsed
+
+    # ---- roofline of the dominant kernel (K1), HIP events on the launch stream ----
+    lib = _lib.load()
+    n_local = obe._s_end - obe._s_begin
+    mom = obe._moments_on_device()
+    p, w = obe._pw_tensors()
+    ms = ctypes.c_float(0.0)
+    stream = obe._stream()
+    s_ptr = ctypes.c_void_p(obe._settings_dev.data_ptr() + 8 * obe._s_begin)
+    lib.call("obe_sweep_kernel_time", obe._model_struct, s_ptr, ns, n_local, _ptr(p), p.shape[1], n_p,
+             _ptr(w), _ptr(mom), _ptr(obe._ws), obe._ws_bytes, 5, ctypes.byref(ms), stream)
+    k1_s = ms.value * 1e-3
+    flop = FLOP_PER_EVAL[model] * n_local * n_p
+    d = prior.shape[0]
+    k1_bytes = 8 * (d + 1) * n_p + 8 * 2 * n_local          # compulsory: cloud + settings + utility
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(cfg, {}).get("sweep_kernel_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"kernel": "sweep_kernel (K1)", "bound": "fp64_valu",
+                "achieved": flop / k1_s / 1e12, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": flop / k1_s / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                "flop_per_eval": FLOP_PER_EVAL[model], "evals_per_launch": n_local * n_p,
+                "launch_ms": ms.value, "traffic": traffic,
+                "hbm_algorithmic": {"bytes": k1_bytes, "achieved": k1_bytes / k1_s / 1e9, "peak": HBM_PEAK_GBS,
+                                    "unit": "GB/s", "frac": k1_bytes / k1_s / 1e9 / HBM_PEAK_GBS,
+                                    "note": "compute-bound kernel: ~1e4 flop per compulsory byte"}}
+
+    # ---- the HBM-bound update (K2: 3 launches), events around the whole call ----
+    timer = ctypes.c_void_p()
+    lib.call("obe_timer_create", ctypes.byref(timer))
+    wcopy = w.clone()
+    host_out = np.zeros(4)
+    st_arr, yy, ss = np.zeros(4), np.zeros(4), np.ones(4) * sigma
+    st_arr[0], yy[0] = 3.0, 49500.0
+    rows = None
+    if not noise_rec:
+        rows = np.zeros(16, dtype=np.int32)
+        rows[0] = 9
+    reps = 20
+    upd_ms = ctypes.c_float(0.0)
+    for timed in (False, True):
+        if timed:
+            lib.call("obe_timer_start", timer, stream)
+        for _ in range(reps):
+            lib.call("obe_bayes_update_model", obe._model_struct, _ptr(p), p.shape[1], n_p, _ptr(wcopy),
+                     _lib.host_ptr(st_arr), _lib.host_ptr(yy), _lib.host_ptr(ss) if rows is None else None,
+                     None if rows is None else _lib.host_ptr(rows), 1, float("nan"), _ptr(obe._ws),
+                     obe._ws_bytes, None, stream)
+        if timed:
+            lib.call("obe_timer_stop", timer, stream, ctypes.byref(upd_ms))
+    lib.call("obe_timer_destroy", timer)
+    n_read = obe._device_model.n_read + (0 if noise_rec else 1)
+    k2_bytes = 8 * (n_read + 1) * n_p + 8 * n_p + 16 * n_p
+    k2_s = upd_ms.value * 1e-3 / reps
+    roofline_update = {"kernel": "update_model_kernel + normalize_kernel + fold2_kernel (K2)", "bound": "hbm",
+                       "achieved": k2_bytes / k2_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": k2_bytes / k2_s / 1e9 / HBM_PEAK_GBS, "bytes": k2_bytes,
+                       "call_us": k2_s * 1e6, "traffic": None}
+
+    out = {"metric": "model-evals/sec (settings x particles) per opt_setting+update cycle, fp64",
+           "value": value, "unit": "model-evals/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"{cfg}: {desc}", "n_settings": ns, "n_particles": n_p,
+                      "utility": "variance_full (every particle a draw, weighted variance)",
+                      "settings_per_rank": n_local, "sharding": f"settings axis / {world}",
+                      "resamples_in_timed_steps": resamples},
+           "roofline": roofline, "roofline_update": roofline_update}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, settings, prior, cons, true, sigma)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

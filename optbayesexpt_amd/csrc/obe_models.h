@@ -6,11 +6,14 @@
 //                 function, one correctly-rounded op at a time (no FMA contraction);
 //                 used by the HBM-bound kernels (Bayes update, eval_over_*), where
 //                 it costs nothing and gives reference-identical bits.
-//   eval_fast() — the flop-bound sweep form: per-setting and per-particle terms are
-//                 hoisted (prep_setting / pack), divisions become v_rcp_f64 + Newton,
-//                 and products/sums are fused.  Outputs are *shifted* by a
-//                 per-particle-independent constant (the mean background), which
-//                 leaves the variance unchanged and removes the cancellation.
+//   sweep_eval() — the flop-bound sweep form, for the SPT settings one lane owns at
+//                 once: per-setting and per-particle terms are hoisted (prep_setting /
+//                 pack), the SPT divisions share ONE v_rcp_f64 + Newton (Montgomery's
+//                 batch inversion), and products/sums are fused.  It returns
+//                 sqrt(w) * (y - offset): the weight is folded into the packed particle
+//                 (one multiply per particle instead of one per evaluation) and the
+//                 offset is a particle-independent constant (the mean background),
+//                 which leaves the variance unchanged and removes the cancellation.
 #pragma once
 
 #include <type_traits>
@@ -19,15 +22,51 @@
 
 namespace obe {
 
-// 1/q to ~1 ulp: v_rcp_f64 seeds ~2^-23 relative (ISA: "2**29 ULP"), two Newton steps
-// square that twice.
+// 1/q to ~1 ulp.  v_rcp_f64 seeds 2^-24.4 relative (measured on gfx950, tools/
+// microbench_fp64.hip); one cubically convergent step  r (1 + e + e^2),  e = 1 - q r,
+// takes that to 2^-73 before rounding: 3 FMAs instead of the 4 of two Newton steps.
 __device__ __forceinline__ double fast_rcp(double q) {
-    double r = __builtin_amdgcn_rcp(q);
-    double e = fma(-q, r, 1.0);
-    r = fma(r, e, r);
-    e = fma(-q, r, 1.0);
-    r = fma(r, e, r);
-    return r;
+    const double r = __builtin_amdgcn_rcp(q);
+    const double e = fma(-q, r, 1.0);
+    const double t = fma(e, e, e);
+    return fma(r, t, r);
+}
+
+// Batch inversion: r[j] = 1/q[j] for N values from one reciprocal of their product
+// (3(N-1) multiplies + 1 rcp instead of N rcp + 4N Newton FMAs).  q >= 1 on every
+// caller, so the product cannot underflow; it overflows only beyond q ~ 1e77.
+template <int N>
+__device__ __forceinline__ void batch_rcp(const double (&q)[N], double (&r)[N]) {
+    if constexpr (N == 1) {
+        r[0] = fast_rcp(q[0]);
+    } else if constexpr (N == 2) {
+        const double inv = fast_rcp(q[0] * q[1]);
+        r[0] = inv * q[1];
+        r[1] = inv * q[0];
+    } else if constexpr (N == 4) {
+        const double p01 = q[0] * q[1], p23 = q[2] * q[3];
+        const double inv = fast_rcp(p01 * p23);
+        const double i01 = inv * p23, i23 = inv * p01;
+        r[0] = i01 * q[1];
+        r[1] = i01 * q[0];
+        r[2] = i23 * q[3];
+        r[3] = i23 * q[2];
+    } else {
+        static_assert(N == 8, "batch_rcp: N must be 1, 2, 4 or 8");
+        const double p01 = q[0] * q[1], p23 = q[2] * q[3], p45 = q[4] * q[5], p67 = q[6] * q[7];
+        const double p03 = p01 * p23, p47 = p45 * p67;
+        const double inv = fast_rcp(p03 * p47);
+        const double i03 = inv * p47, i47 = inv * p03;
+        const double i01 = i03 * p23, i23 = i03 * p01, i45 = i47 * p67, i67 = i47 * p45;
+        r[0] = i01 * q[1];
+        r[1] = i01 * q[0];
+        r[2] = i23 * q[3];
+        r[3] = i23 * q[2];
+        r[4] = i45 * q[5];
+        r[5] = i45 * q[4];
+        r[6] = i67 * q[7];
+        r[7] = i67 * q[6];
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -38,7 +77,7 @@ template <int K>
 struct Lorentz {
     static constexpr int NS = 1, NC = 1, NREAD = K + 2;
     static constexpr int NXS = 1;        // prepared setting: x/d
-    static constexpr int NPK = K + 2;    // packed particle: x0_k/d ..., a, b - bbar
+    static constexpr int NPK = K + 2;    // packed particle: x0_k/d ..., sw*a, sw*(b - bbar)
 
     __device__ static void eval(const double* x, const ParamRef& th, const obe_model& m, double* y) {
         const double d = m.consts[0];
@@ -55,22 +94,31 @@ struct Lorentz {
     __device__ static void prep_setting(const double* x, const obe_model& m, double* xs) {
         xs[0] = x[0] / m.consts[0];
     }
-    __device__ static void pack(const ParamRef& th, const double* thbar, const obe_model& m, double* pk) {
+    __device__ static void pack(const ParamRef& th, const double* thbar, const obe_model& m, double sw,
+                                double* pk) {
         const double d = m.consts[0];
 #pragma unroll
         for (int k = 0; k < K; ++k) pk[k] = th(k) / d;
-        pk[K] = th(K);
-        pk[K + 1] = th(K + 1) - thbar[K + 1];
+        pk[K] = sw * th(K);
+        pk[K + 1] = sw * (th(K + 1) - thbar[K + 1]);
     }
-    __device__ __forceinline__ static void eval_fast(const double* xs, const double* pk, double* y) {
-        double acc = pk[K + 1];
+    template <int SPT>
+    __device__ __forceinline__ static void sweep_eval(const double (&xs)[SPT][NXS], const double* pk, double,
+                                                      const obe_model&, double (&v)[SPT][NC]) {
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) v[j][0] = pk[K + 1];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const double t = xs[0] - pk[k];
-            const double q = fma(t, t, 1.0);
-            acc = fma(pk[K], fast_rcp(q), acc);
+            double q[SPT], r[SPT];
+#pragma unroll
+            for (int j = 0; j < SPT; ++j) {
+                const double t = xs[j][0] - pk[k];
+                q[j] = fma(t, t, 1.0);
+            }
+            batch_rcp<SPT>(q, r);
+#pragma unroll
+            for (int j = 0; j < SPT; ++j) v[j][0] = fma(pk[K], r[j], v[j][0]);
         }
-        y[0] = acc;
     }
 };
 
@@ -82,12 +130,15 @@ struct LineAB {
         y[0] = th(0) + bx;
     }
     __device__ static void prep_setting(const double* x, const obe_model&, double* xs) { xs[0] = x[0]; }
-    __device__ static void pack(const ParamRef& th, const double* thbar, const obe_model&, double* pk) {
-        pk[0] = th(0) - thbar[0];
-        pk[1] = th(1);
+    __device__ static void pack(const ParamRef& th, const double* thbar, const obe_model&, double sw, double* pk) {
+        pk[0] = sw * (th(0) - thbar[0]);
+        pk[1] = sw * th(1);
     }
-    __device__ __forceinline__ static void eval_fast(const double* xs, const double* pk, double* y) {
-        y[0] = fma(pk[1], xs[0], pk[0]);
+    template <int SPT>
+    __device__ __forceinline__ static void sweep_eval(const double (&xs)[SPT][NXS], const double* pk, double,
+                                                      const obe_model&, double (&v)[SPT][NC]) {
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) v[j][0] = fma(pk[1], xs[j][0], pk[0]);
     }
 };
 
@@ -99,12 +150,15 @@ struct LineMB {
         y[0] = mx + th(1);
     }
     __device__ static void prep_setting(const double* x, const obe_model&, double* xs) { xs[0] = x[0]; }
-    __device__ static void pack(const ParamRef& th, const double* thbar, const obe_model&, double* pk) {
-        pk[0] = th(0);
-        pk[1] = th(1) - thbar[1];
+    __device__ static void pack(const ParamRef& th, const double* thbar, const obe_model&, double sw, double* pk) {
+        pk[0] = sw * th(0);
+        pk[1] = sw * (th(1) - thbar[1]);
     }
-    __device__ __forceinline__ static void eval_fast(const double* xs, const double* pk, double* y) {
-        y[0] = fma(pk[0], xs[0], pk[1]);
+    template <int SPT>
+    __device__ __forceinline__ static void sweep_eval(const double (&xs)[SPT][NXS], const double* pk, double,
+                                                      const obe_model&, double (&v)[SPT][NC]) {
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) v[j][0] = fma(pk[0], xs[j][0], pk[1]);
     }
 };
 
@@ -113,10 +167,15 @@ struct FirstParam {
     static constexpr int NS = 1, NC = 1, NREAD = 1, NXS = 1, NPK = 1;
     __device__ static void eval(const double*, const ParamRef& th, const obe_model&, double* y) { y[0] = th(0); }
     __device__ static void prep_setting(const double* x, const obe_model&, double* xs) { xs[0] = x[0]; }
-    __device__ static void pack(const ParamRef& th, const double* thbar, const obe_model&, double* pk) {
-        pk[0] = th(0) - thbar[0];
+    __device__ static void pack(const ParamRef& th, const double* thbar, const obe_model&, double sw, double* pk) {
+        pk[0] = sw * (th(0) - thbar[0]);
     }
-    __device__ __forceinline__ static void eval_fast(const double*, const double* pk, double* y) { y[0] = pk[0]; }
+    template <int SPT>
+    __device__ __forceinline__ static void sweep_eval(const double (&)[SPT][NXS], const double* pk, double,
+                                                      const obe_model&, double (&v)[SPT][NC]) {
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) v[j][0] = pk[0];
+    }
 };
 
 // Rabi oscillation counts, demos/pipulse/pipulse.py:18-49
@@ -143,16 +202,18 @@ struct Rabi {
         xs[0] = x[0];
         xs[1] = x[1];
     }
-    __device__ static void pack(const ParamRef& th, const double*, const obe_model&, double* pk) {
+    __device__ static void pack(const ParamRef& th, const double*, const obe_model&, double, double* pk) {
         pk[0] = th(0);
         pk[1] = th(1);
     }
-    // needs the constants: handled through eval_fast_m below
-    static constexpr bool kFastNeedsModel = true;
-    __device__ __forceinline__ static void eval_fast_m(const double* xs, const double* pk,
-                                                       const obe_model& m, double* y) {
+    template <int SPT>
+    __device__ __forceinline__ static void sweep_eval(const double (&xs)[SPT][NXS], const double* pk, double sw,
+                                                      const obe_model& m, double (&v)[SPT][NC]) {
         // y - baseline: same variance, without the 1 - frac cancellation
-        y[0] = -(m.consts[0] * frac(xs[0], xs[1], pk[0], pk[1], m.consts[1], m.consts[2]));
+        const double scale = -(sw * m.consts[0]);
+#pragma unroll
+        for (int j = 0; j < SPT; ++j)
+            v[j][0] = scale * frac(xs[j][0], xs[j][1], pk[0], pk[1], m.consts[1], m.consts[2]);
     }
 };
 
@@ -186,26 +247,23 @@ struct Coil {
         formula(x[0], th(0), th(1), th(2), y);
     }
     __device__ static void prep_setting(const double* x, const obe_model&, double* xs) { xs[0] = x[0]; }
-    __device__ static void pack(const ParamRef& th, const double*, const obe_model&, double* pk) {
+    __device__ static void pack(const ParamRef& th, const double*, const obe_model&, double, double* pk) {
         pk[0] = th(0);
         pk[1] = th(1);
         pk[2] = th(2);
     }
-    __device__ __forceinline__ static void eval_fast(const double* xs, const double* pk, double* y) {
-        formula(xs[0], pk[0], pk[1], pk[2], y);
+    template <int SPT>
+    __device__ __forceinline__ static void sweep_eval(const double (&xs)[SPT][NXS], const double* pk, double sw,
+                                                      const obe_model&, double (&v)[SPT][NC]) {
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) {
+            double y[2];
+            formula(xs[j][0], pk[0], pk[1], pk[2], y);
+            v[j][0] = sw * y[0];
+            v[j][1] = sw * y[1];
+        }
     }
 };
-
-template <class M, class = void>
-struct fast_needs_model { static constexpr bool value = false; };
-template <class M>
-struct fast_needs_model<M, std::enable_if_t<M::kFastNeedsModel>> { static constexpr bool value = true; };
-
-template <class M>
-__device__ __forceinline__ void model_eval_fast(const double* xs, const double* pk, const obe_model& m, double* y) {
-    if constexpr (fast_needs_model<M>::value) M::eval_fast_m(xs, pk, m, y);
-    else M::eval_fast(xs, pk, y);
-}
 
 // Host-side dispatch: f(ModelType{}) for the model named by m.id / m.aux.
 template <class F>

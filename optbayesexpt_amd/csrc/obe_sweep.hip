@@ -21,6 +21,7 @@
 // Variance numerics: moments are accumulated about a per-setting shift
 // c_s = model(x_s; mean parameters), so  var = (S2 - S1^2/W)/W  does not cancel
 // catastrophically (np.var is two-pass; the shift plays the role of its first pass).
+#include <cstdlib>
 #include <cstring>
 
 #include "obe_common.h"
@@ -29,7 +30,7 @@
 namespace obe {
 
 constexpr int kSweepLdsDoubles = 4096;   // 32 KiB tile per workgroup -> 4-5 workgroups per CU
-constexpr int kMaxChunks = 256;
+constexpr int kMaxChunks = 1024;
 
 struct SweepPlan {
     int spt;           // settings per thread
@@ -38,12 +39,19 @@ struct SweepPlan {
     int64_t chunk;     // draws per chunk
 };
 
+// Tuned on MI355X at 65 536 x 1 048 576 (tools/tune_sweep.sh): 8 settings per lane (one
+// batched reciprocal per 8 evaluations) and ~3000 workgroups (12 per CU, 3 resident at
+// 161 VGPRs) gave the shortest kernel; fewer, larger workgroups lose 3-5 % to the tail.
 static SweepPlan plan_sweep(int64_t ns, int64_t nd) {
+    static const int force_spt = getenv("OBE_SWEEP_SPT") ? atoi(getenv("OBE_SWEEP_SPT")) : 0;         // tuning aids
+    static const int force_blocks = getenv("OBE_SWEEP_BLOCKS") ? atoi(getenv("OBE_SWEEP_BLOCKS")) : 0;
     SweepPlan p;
-    p.spt = ns >= 4096 ? 4 : (ns >= 1024 ? 2 : 1);
+    p.spt = ns >= 4096 ? 8 : (ns >= 1024 ? 4 : (ns >= 512 ? 2 : 1));
+    if (force_spt == 1 || force_spt == 2 || force_spt == 4 || force_spt == 8) p.spt = force_spt;
     p.tiles_x = static_cast<int>((ns + (int64_t)kBlock * p.spt - 1) / ((int64_t)kBlock * p.spt));
-    int64_t want = (1024 + p.tiles_x - 1) / p.tiles_x;       // ~4 workgroups per CU in total
-    int64_t cap = std::min<int64_t>(kMaxChunks, (nd + 255) / 256);
+    const int target_blocks = force_blocks > 0 ? force_blocks : 3072;
+    int64_t want = (target_blocks + p.tiles_x - 1) / p.tiles_x;
+    int64_t cap = std::min<int64_t>(kMaxChunks, (nd + 511) / 512);     // >= 512 draws per chunk
     if (cap < 1) cap = 1;
     p.nchunks = static_cast<int>(std::max<int64_t>(1, std::min(want, cap)));
     p.chunk = (nd + p.nchunks - 1) / p.nchunks;
@@ -79,15 +87,15 @@ struct SweepArgs {
 template <class M, int SPT>
 __global__ __launch_bounds__(kBlock) void sweep_kernel(SweepArgs a) {
     constexpr int NC = M::NC, NXS = M::NXS, NPK = M::NPK;
-    constexpr int NPKW = (NPK + 1 + 1) & ~1;   // packed particle + weight, padded to 16 B
+    constexpr int NPKW = (NPK + 1 + 1) & ~1;   // packed particle + sqrt(weight), padded to 16 B
     extern __shared__ __attribute__((aligned(16))) double tile[];
 
     double xs[SPT][NXS], cs[SPT][NC], s1[SPT][NC], s2[SPT][NC];
     const double* __restrict__ thbar = a.moments + 2;   // weighted-mean parameters (K3 output)
 
-    {   // prepared settings and the per-setting shift
+    {   // prepared settings and the per-setting shift c_s = y'(x_s; mean parameters)
         double pkbar[NPK];
-        M::pack(ParamRef{thbar, 1}, thbar, a.m, pkbar);
+        M::pack(ParamRef{thbar, 1}, thbar, a.m, 1.0, pkbar);
 #pragma unroll
         for (int j = 0; j < SPT; ++j) {
             int64_t s = ((int64_t)blockIdx.x * SPT + j) * kBlock + threadIdx.x;
@@ -96,10 +104,10 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(SweepArgs a) {
 #pragma unroll
             for (int k = 0; k < M::NS; ++k) x[k] = a.settings[(int64_t)k * a.ld_s + s];
             M::prep_setting(x, a.m, xs[j]);
-            model_eval_fast<M>(xs[j], pkbar, a.m, cs[j]);
 #pragma unroll
             for (int c = 0; c < NC; ++c) s1[j][c] = s2[j][c] = 0.0;
         }
+        M::template sweep_eval<SPT>(xs, pkbar, 1.0, a.m, cs);
     }
 
     const int64_t p_begin = (int64_t)blockIdx.y * a.chunk;
@@ -118,11 +126,12 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(SweepArgs a) {
             } else {
                 w = a.weights[p];
             }
+            const double sw = sqrt(w);
             double pk[NPK];
-            M::pack(ParamRef{a.particles + src, a.ld_p}, thbar, a.m, pk);
+            M::pack(ParamRef{a.particles + src, a.ld_p}, thbar, a.m, sw, pk);
 #pragma unroll
             for (int k = 0; k < NPK; ++k) tile[i * NPKW + k] = pk[k];
-            tile[i * NPKW + NPK] = w;
+            tile[i * NPKW + NPK] = sw;
         }
         __syncthreads();
 #pragma unroll 2
@@ -130,17 +139,16 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(SweepArgs a) {
             double pk[NPK];
 #pragma unroll
             for (int k = 0; k < NPK; ++k) pk[k] = tile[i * NPKW + k];   // same address in every lane: LDS broadcast
-            const double w = tile[i * NPKW + NPK];
+            const double sw = tile[i * NPKW + NPK];
+            double v[SPT][NC];
+            M::template sweep_eval<SPT>(xs, pk, sw, a.m, v);             // sqrt(w) * y'
 #pragma unroll
             for (int j = 0; j < SPT; ++j) {
-                double y[NC];
-                model_eval_fast<M>(xs[j], pk, a.m, y);
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
-                    const double u = y[c] - cs[j][c];
-                    const double wu = w * u;
-                    s1[j][c] += wu;
-                    s2[j][c] = fma(wu, u, s2[j][c]);
+                    const double u = fma(-cs[j][c], sw, v[j][c]);        // sqrt(w) * (y' - c_s)
+                    s1[j][c] = fma(sw, u, s1[j][c]);                     // sum w (y' - c_s)
+                    s2[j][c] = fma(u, u, s2[j][c]);                      // sum w (y' - c_s)^2
                 }
             }
         }
@@ -325,6 +333,7 @@ static int launch_sweep(const SweepPlan& p, SweepArgs& a, hipStream_t st) {
     const size_t lds = (size_t)tile * NPKW * sizeof(double);
     dim3 grid(p.tiles_x, p.nchunks);
     switch (p.spt) {
+        case 8: sweep_kernel<M, 8><<<grid, kBlock, lds, st>>>(a); break;
         case 4: sweep_kernel<M, 4><<<grid, kBlock, lds, st>>>(a); break;
         case 2: sweep_kernel<M, 2><<<grid, kBlock, lds, st>>>(a); break;
         default: sweep_kernel<M, 1><<<grid, kBlock, lds, st>>>(a); break;

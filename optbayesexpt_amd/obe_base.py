@@ -49,6 +49,25 @@ def _overridden(obj, name, *owners):
     return all(impl is not getattr(o, name) for o in owners)
 
 
+class _LazyState:
+    """What ``pdf_update`` returns: behaves like the reference's ``(particles,
+    particle_weights)`` tuple (unpacking, indexing, len), but the two host arrays are
+    only copied off the device if the caller actually looks at them."""
+
+    def __init__(self, owner):
+        self._owner = owner
+
+    def __len__(self):
+        return 2
+
+    def __getitem__(self, i):
+        return (self._owner.particles, self._owner.particle_weights)[i]
+
+    def __iter__(self):
+        yield self._owner.particles
+        yield self._owner.particle_weights
+
+
 class OptBayesExpt(ParticlePDF):
     """Sequential Bayesian experiment design (see module docstring).
 
@@ -285,7 +304,7 @@ class OptBayesExpt(ParticlePDF):
         self._parameters = self._particles
         if self.just_resampled:
             self.enforce_parameter_constraints()
-        return self.particles, self.particle_weights
+        return _LazyState(self)
 
     def _likelihood_overridden(self):
         return _overridden(self, "likelihood", OptBayesExpt)

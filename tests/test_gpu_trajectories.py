@@ -32,7 +32,7 @@ def test_trajectory_matches_reference(hip, name):
     fx = _replay.load_traj(name)
     o = _replay.construct(fx, obe.OptBayesExpt, obe.OptBayesExptNoiseParameter,
                           device_models()[fx["meta"]["model"]])
-    stats = _replay.replay(fx, o, RTOL,
+    stats = _replay.replay(fx, o, _replay.HIP_RTOL[name],
                            get_draw_idx=lambda x: x.last_draw_indices,
                            get_utility=lambda x: x._utility_dev.cpu().numpy())
     assert stats["cycles"] == fx["meta"]["n_cycles"]
