@@ -89,9 +89,9 @@ class SettingsShard:
         buf = torch.zeros((rows, pad), dtype=torch.float64, device=dev)
         b, e = self.bounds(n_settings)
         buf[:, :e - b] = local[:, :e - b].to(dev)
-        gathered = torch.empty((self.world_size, rows, pad), dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(gathered, buf, group=self.group)
-        gathered = gathered.cpu().numpy()
+        gathered = torch.empty(self.world_size * rows * pad, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(gathered, buf.reshape(-1), group=self.group)
+        gathered = gathered.cpu().numpy().reshape(self.world_size, rows, pad)
         out = np.empty((rows, n_settings))
         for r in range(self.world_size):
             rb, re = shard_bounds(n_settings, r, self.world_size)

@@ -1,0 +1,87 @@
+"""The C-ABI library (CPU-only checks, no kernel launches): it loads, exports exactly the
+functions include/obe_hip.h declares with the argument counts the ctypes binding uses,
+and its host-side argument validation reports errors without touching a GPU."""
+import ctypes
+import re
+
+import numpy as np
+import pytest
+
+from optbayesexpt_amd import _lib, models
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return _lib.load()
+
+
+def _header_prototypes():
+    text = open(_lib.HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(?:int|int64_t|const char\*)\s+(obe_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
+    return protos
+
+
+def test_library_exports_every_declared_symbol(lib):
+    declared = _lib.declared_symbols()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib.cdll, name), f"{name} declared in obe_hip.h but not exported"
+    assert set(declared) == set(_lib._SIGNATURES), "ctypes table and header disagree"
+    assert lib.cdll.obe_abi_version() == 1
+
+
+def test_ctypes_argument_counts_match_header():
+    protos = _header_prototypes()
+    assert set(protos) == set(_lib._SIGNATURES)
+    for name, n_args in protos.items():
+        assert len(_lib._SIGNATURES[name][1]) == n_args, name
+
+
+def test_model_struct_layout_and_validation(lib):
+    assert ctypes.sizeof(_lib.ObeModelStruct) == 6 * 4 + 8 * 8
+    m = models.lorentzian(1).struct(3, (0.1,))
+    assert lib.cdll.obe_model_validate(m) == 0
+    assert (m.n_setdims, m.n_channels) == (1, 1)
+    m7 = models.lorentzian(7).struct(10, (0.1,))
+    assert lib.cdll.obe_model_validate(m7) == 0
+    bad = models.lorentzian(1).struct(3, (0.1,))
+    bad.n_params = 2                                   # fewer rows than the model reads
+    assert lib.cdll.obe_model_validate(bad) == -1
+    assert "n_params" in lib.last_error()
+    bad = models.lorentzian(1).struct(3, (0.1,))
+    bad.aux = 9
+    assert lib.cdll.obe_model_validate(bad) == -1
+    bad = models.coil().struct(4, ())
+    bad.n_channels = 1
+    assert lib.cdll.obe_model_validate(bad) == -1
+    bad.id = 99
+    assert lib.cdll.obe_model_validate(bad) == -1 and "unknown model" in lib.last_error()
+    with pytest.raises(ValueError):
+        models.lorentzian(1).struct(3, ())             # missing constant d
+    with pytest.raises(ValueError):
+        models.rabi().struct(1, (1.0, 0.1, 2.0))       # too few parameter rows
+
+
+def test_workspace_and_moment_sizes(lib):
+    assert lib.moments_len(3) == 2 + 12 + 9
+    small = lib.workspace_bytes(1000, 10, 1, 3)
+    big = lib.workspace_bytes(1 << 20, 65536, 1, 3)
+    assert 0 < small < big < 1 << 30
+    assert lib.workspace_bytes(1 << 20, 65536, 2, 3) > big
+
+
+def test_argument_errors_are_reported_not_crashed(lib):
+    """NULL pointers / bad sizes come back as status -1 with a message (no launch)."""
+    out = np.zeros(4)
+    rc = lib.cdll.obe_weight_sums(None, 10, None, 0, _lib.host_ptr(out), None)
+    assert rc == -1 and lib.last_error()
+    rc = lib.cdll.obe_moments(None, 0, 3, 0, None, 0, None, None, None, 0, None)
+    assert rc == -1
+    rc = lib.cdll.obe_cdf_search(None, 0, None, 0, None, None)
+    assert rc == -1
+    with pytest.raises(_lib.ObeHipError):
+        lib.call("obe_argmax", None, 0, None, None, None, 0, None)

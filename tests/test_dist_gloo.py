@@ -1,0 +1,86 @@
+"""The N > 1 path on CPU: two processes, torch.distributed backend "gloo".  Each rank owns
+its contiguous slice of the settings (optbayesexpt_amd.dist), computes that slice's
+utility with the oracle, and the collectives must reproduce the single-process answer:
+global first-max (np.argmax tie/NaN rules) and the gathered utility vector."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from oracle import models as omodels
+from optbayesexpt_amd.dist import SettingsShard
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _utility_cases():
+    g = np.random.default_rng(77)
+    n = 1500
+    prior = np.array([g.uniform(2, 4, n), g.uniform(-2000, -400, n), g.normal(50000, 1000, n)])
+    w = g.exponential(1.0, n)
+    w /= w.sum()
+    cases = []
+    for ns in (201, 64, 5):
+        sv = (np.linspace(1.5, 4.5, ns),)
+        yvar = oracle.yvar_full_sweep(omodels.lorentzian, oracle.flatten_settings(sv), prior, w, (0.1,))
+        cases.append(oracle.utility_from_yvar(yvar, 250000.0, 1.0))
+    ties = np.zeros(40)
+    ties[[3, 17, 25, 39]] = 2.0              # equal maxima on both ranks: lowest index wins
+    cases.append(ties)
+    nan = np.arange(30, dtype=float)
+    nan[22] = np.nan                         # NaN beats everything (np.argmax)
+    cases.append(nan)
+    cases.append(np.full(9, -np.inf))
+    return cases
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shard = SettingsShard()
+        assert (shard.rank, shard.world_size) == (rank, world)
+        results = []
+        for u in _utility_cases():
+            b, e = shard.bounds(u.size)
+            local = u[b:e]
+            if e > b:
+                k = int(np.argmax(local))
+                val, gidx = float(local[k]), b + k
+            else:
+                val, gidx = -np.inf, np.iinfo(np.int64).max
+            best_val, best_idx = shard.combine_best(val, gidx)
+            rows = np.zeros((2, max(e - b, 1)))
+            rows[0, :e - b] = local
+            rows[1, :e - b] = 2 * local
+            full = shard.gather_rows(torch.from_numpy(rows), u.size)
+            results.append((best_idx, best_val, full))
+        ret[rank] = results
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_argmax_and_gather_match_single_process(world):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    cases = _utility_cases()
+    for rank in range(world):
+        for (best_idx, best_val, full), u in zip(ret[rank], cases):
+            assert best_idx == int(np.argmax(u)), (rank, u.size)
+            np.testing.assert_array_equal(best_val, u[int(np.argmax(u))])
+            np.testing.assert_array_equal(full[0], u)
+            np.testing.assert_array_equal(full[1], 2 * u)

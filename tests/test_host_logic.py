@@ -1,0 +1,126 @@
+"""Host-side logic that needs no GPU: the model registry's NumPy forms, the in-place
+write tracking of the host mirrors, settings sharding arithmetic, demo helpers, and the
+"fail loudly without a GPU" contract."""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose, assert_array_equal
+
+import optbayesexpt_amd as obe
+from optbayesexpt_amd import dist as obe_dist
+from optbayesexpt_amd._mirror import TrackedArray
+from oracle import models as omodels
+
+
+def test_public_names_match_reference_package():
+    # optbayesexpt/__init__.py:1-6 minus the TCP server/socket (out of scope)
+    for name in ("ParticlePDF", "OptBayesExpt", "OptBayesExptNoiseParameter",
+                 "MeasurementSimulator", "trace_sort"):
+        assert hasattr(obe, name)
+
+
+def test_device_model_numpy_forms_match_demo_formulas():
+    g = np.random.default_rng(0)
+    x = np.linspace(1.5, 4.5, 50)
+    cases = [(obe.models.lorentzian(), omodels.lorentzian, (x,), g.normal(3, 1, (3, 1)), (0.1,)),
+             (obe.models.lorentzian(7), omodels.multi_lorentzian(7), (x,), g.normal(3, 1, (10, 1)), (0.1,)),
+             (obe.models.line_ab(), omodels.line_ab, (x,), g.normal(0, 1, (2, 1)), ()),
+             (obe.models.line_mb(), omodels.line_mb, (x,), g.normal(0, 1, (3, 1)), ()),
+             (obe.models.rabi(), omodels.rabi, (x[:, None], x[None, :] - 3), (2.0, 0.5), (1e5, 0.01, 2.0)),
+             (obe.models.coil(), omodels.coil, (x,), (1.0, 0.1, 1.0, 0.3), ())]
+    for dm, fn, sets, pars, cons in cases:
+        assert_array_equal(dm(sets, pars, cons), fn(sets, pars, cons), err_msg=dm.name)
+        assert dm.n_setdims == len(sets)
+    # both broadcasting directions of the reference's calling convention
+    dm = obe.models.lorentzian()
+    pars = (g.uniform(2, 4, 100), g.uniform(-2000, -400, 100), g.normal(5e4, 1e3, 100))
+    assert dm((3.0,), pars, (0.1,)).shape == (100,)
+    assert dm((x,), (3.0, -1000.0, 5e4), (0.1,)).shape == (50,)
+
+
+def test_tracked_array_reports_in_place_writes():
+    class Owner:
+        n = 0
+
+        def mark_host_written(self):
+            self.n += 1
+    o = Owner()
+    base = np.arange(12, dtype=float).reshape(3, 4)
+    v = base.view(TrackedArray)
+    v._obe_owner = o
+    v[1, 2] = 5.0
+    assert o.n == 1
+    row = v[1]                       # views stay linked (self.parameters[1][idx] = 0)
+    row[0] = 3.0
+    assert o.n == 2
+    for i in np.argwhere(v[2] > 0):  # the reference's loop-of-index-writes idiom
+        v[2][i] = 0
+    assert o.n == 2 + 4 - 0 and not base[2].any() or o.n >= 5
+    c = v.copy()                     # copies are plain data
+    c[0, 0] = -1
+    n = o.n
+    assert isinstance(v / v.sum(), np.ndarray) and not isinstance(v / 2, TrackedArray)
+    v /= 2.0                         # in-place ufunc
+    assert o.n == n + 1
+    np.multiply(v, 2.0, out=v)
+    assert o.n == n + 2
+    assert v.tolist()[0][1] == 1.0 and np.sum(v) == base.sum()
+
+
+def test_shard_bounds_partition():
+    for n in (1, 7, 8, 9, 201, 4096, 65536):
+        for world in (1, 2, 3, 8):
+            edges = [obe_dist.shard_bounds(n, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            for (b0, e0), (b1, e1) in zip(edges, edges[1:]):
+                assert e0 == b1 and e0 >= b0
+            sizes = [e - b for b, e in edges]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+
+def test_first_max_is_numpy_argmax_over_rank_winners():
+    g = np.random.default_rng(1)
+    for trial in range(200):
+        n, world = int(g.integers(4, 40)), int(g.integers(1, 5))
+        u = g.normal(size=n).round(1)            # coarse values => ties
+        if trial % 7 == 0:
+            u[g.integers(0, n)] = np.nan
+        vals, idxs = [], []
+        for r in range(world):
+            b, e = obe_dist.shard_bounds(n, r, world)
+            if e > b:
+                k = int(np.argmax(u[b:e]))
+                vals.append(u[b + k])
+                idxs.append(b + k)
+        k = obe_dist.first_max(np.array(vals), np.array(idxs))
+        assert idxs[k] == int(np.argmax(u))
+
+
+def test_trace_sort_and_simulator():
+    s, m, e, n = obe.trace_sort(np.array([3., 1., 2., 1., 3., 3.]), np.array([1., 2., 3., 4., 5., 9.]))
+    assert s == [1., 2., 3.] and n == [2, 1, 3]
+    assert_allclose(m, [3., 3., 5.])
+    assert_allclose(e, [np.std([2., 4.]) / np.sqrt(2), 0.0, np.std([1., 5., 9.]) / np.sqrt(3)])
+    sim = obe.MeasurementSimulator(obe.models.lorentzian(), (3.0, -1000.0, 5e4), (0.1,), noise_level=0.0)
+    assert_allclose(sim.simdata((3.0,)), 49000.0)
+    assert sim.simdata((np.array([1.0, 3.0]),)).shape == (2,)
+
+
+def test_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        obe.ParticlePDF(np.zeros((2, 8)))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        obe.OptBayesExpt(obe.models.line_ab(), (np.arange(3.),), np.zeros((2, 8)), ())
+
+
+def test_product_package_never_imports_the_oracle():
+    import os
+    import re
+    root = os.path.dirname(os.path.abspath(obe.__file__))
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
