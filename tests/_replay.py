@@ -23,13 +23,24 @@ TRAJECTORIES = ["lorentz3_opt", "lorentz3_scale_choke", "lorentz3_good",
 
 # Relative tolerance of the HIP path per trajectory.  1e-10 is the bar of BASELINE.json.
 # The 10-parameter trajectory is the exception: there the *reference itself* is only
-# reproducible to ~2e-9 — summing its covariance in a different (equally valid) order on
-# the CPU already moves the utilities by 2e-10 after the first resample and 2e-9 later
+# reproducible to ~1e-7 over 24 cycles — summing its covariance in a different (equally
+# valid) order on the CPU already moves the utilities by 2e-10 after the first resample,
+# 3e-9 by cycle 10 and 1e-7 by cycle 20
 # (tests/test_oracle_golden.py::test_reference_conditioning_10_parameters), because the
 # SVD-based nudge amplifies last-bit differences of a 10x10 covariance whose eigenvalues
-# span six decades.  No implementation with a different summation order can do better.
+# span six decades, and every resample compounds it.  No implementation with a
+# different summation order can do better; integer outputs are still compared exactly.
 HIP_RTOL = {name: 1e-10 for name in TRAJECTORIES}
-HIP_RTOL["multilorentz7_noise"] = 2e-8
+HIP_RTOL["multilorentz7_noise"] = 1e-6
+
+# Absolute floor on particles right after a resample, in units of eps*sqrt(largest
+# covariance eigenvalue): the nudge z @ (u sqrt(s)).T comes from an SVD whose entries
+# carry LAPACK round-off of that size *regardless of the parameter's own scale*.
+# Measured on the CPU by re-summing the reference's covariance in reverse order
+# (same experiment as above): 5-75 units on the 3/4-parameter trajectories, 530 units at
+# the first resample of the 10-parameter one, growing as the two runs drift apart.
+NUDGE_FLOOR_UNITS = {name: 256 for name in TRAJECTORIES}
+NUDGE_FLOOR_UNITS["multilorentz7_noise"] = 20000
 
 
 def load(name):
@@ -71,7 +82,7 @@ def close(actual, desired, rtol, what, scale=None):
                     atol=rtol * 1e-3 * ref_scale, err_msg=what)
 
 
-def replay(fx, obe, rtol, get_draw_idx=None, get_utility=None, check_moments=True):
+def replay(fx, obe, rtol, get_draw_idx=None, get_utility=None, check_moments=True, floor_units=256):
     """Drive ``obe`` through the recorded cycles.  ``get_draw_idx(obe)`` returns the
     particle indices of the most recent utility draw (implementation-specific
     accessor); ``get_utility(obe)`` the most recent utility vector."""
@@ -114,13 +125,15 @@ def replay(fx, obe, rtol, get_draw_idx=None, get_utility=None, check_moments=Tru
             # The nudge is z @ (u sqrt(s)).T from an SVD of the covariance: its entries carry
             # an absolute LAPACK round-off of ~eps*sqrt(s_max) whatever the parameter's own
             # scale, so that is the floor below which the reference itself is noise.
-            floor = 256 * 2.3e-16 * np.sqrt(np.max(np.diag(fx["cov"][cyc])))
+            floor = floor_units * 2.3e-16 * np.sqrt(np.max(np.diag(fx["cov"][cyc])))
             for d in range(snap.shape[0]):
                 assert_allclose(got[d], snap[d], rtol=rtol, atol=floor,
                                 err_msg=f"particles[{d}] after resample, cycle {cyc}")
         if check_moments:
-            close(obe.mean(), fx["mean"][cyc], rtol, f"mean, cycle {cyc}",
-                  scale=np.max(np.abs(fx["mean"][cyc]) + fx["std"][cyc]))
+            # a mean is known to within a fraction of the spread: tolerance rtol*(|mean|+std)
+            mtol = rtol * (np.abs(fx["mean"][cyc]) + fx["std"][cyc])
+            merr = np.abs(np.asarray(obe.mean()) - fx["mean"][cyc])
+            assert np.all(merr <= mtol), f"mean, cycle {cyc}: err {merr} tol {mtol}"
             sd = fx["std"][cyc]
             # std() is the one-pass <x^2> - <x>^2 (particlepdf.py:209-214): its
             # attainable accuracy is ~eps * <x^2> / var relative, whatever the

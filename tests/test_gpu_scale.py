@@ -1,0 +1,148 @@
+"""HIP path at BASELINE.json's full sizes (GPU).  The oracle cannot sweep 65 536 x
+1 048 576 in reasonable time, so parity at these sizes is checked (i) against the
+oracle on a sample of settings with the *whole* particle cloud, and (ii) through
+size-independent properties of the domain: permutation invariance of the cloud, exact
+power-of-two scaling, duplication invariance, shard-union == full sweep, bit-exact
+resample indices."""
+import warnings
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose, assert_array_equal
+
+import oracle
+from oracle import models as omodels
+import bench
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def obe(hip):
+    import optbayesexpt_amd
+    return optbayesexpt_amd
+
+
+def _updated(o, true, cons, sigma, n=3, noise=True):
+    """A few real cycles so that the weights are non-uniform."""
+    sim = np.random.default_rng(9)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        for _ in range(n):
+            x = o.opt_setting()
+            y = float(o.model_function(x, true, cons)) + sigma * sim.standard_normal()
+            o.pdf_update((x, y, sigma) if noise else (x, y))
+
+
+def _sample_check(o, fn, settings, cons, n_sample, seed=0):
+    g = np.random.default_rng(seed)
+    ns = settings[0].size
+    pick = np.sort(g.choice(ns, size=n_sample, replace=False))
+    yvar = o.yvar_from_parameter_draws()
+    ref = oracle.yvar_full_sweep(fn, oracle.flatten_settings((settings[0][pick],)), o.particles,
+                                 o.particle_weights, cons, chunk=8192)
+    assert_allclose(yvar[:, pick], ref, rtol=RTOL)
+    return yvar
+
+
+@pytest.mark.parametrize("cfg,n_sample", [("c2", 24), ("c3", 10)])
+def test_full_sweep_at_baseline_size_matches_oracle_on_sampled_settings(obe, cfg, n_sample):
+    settings, prior, cons, true, sigma = bench.make_workload(cfg)
+    o = bench.build_obe(cfg, None, settings, prior.copy(), cons)
+    o.rng = np.random.default_rng(5)
+    o.tuning_parameters["auto_resample"] = False
+    _updated(o, true, cons, sigma)
+    w = o.particle_weights
+    assert 0.01 < 1.0 / np.sum(w * w) / w.size < 0.99          # genuinely non-uniform
+    yvar = _sample_check(o, omodels.lorentzian, settings, cons, n_sample)
+    util = o.utility()
+    assert_allclose(util, yvar[0] / sigma ** 2, rtol=1e-14)
+    o.opt_setting()
+    assert o.last_setting_index == int(np.argmax(util))
+
+
+def test_c5_ten_parameter_noise_model_matches_oracle_on_sampled_settings(obe):
+    settings, prior, cons, true, sigma = bench.make_workload("c5")
+    o = bench.build_obe("c5", None, settings, prior.copy(), cons)
+    o.rng = np.random.default_rng(5)
+    o.tuning_parameters["auto_resample"] = False
+    _updated(o, true, cons, sigma, noise=False)
+    yvar = _sample_check(o, omodels.multi_lorentzian(7), settings, cons, 8)
+    nv = oracle.mean_noise_variance(o.particles, 9, o.particle_weights)
+    assert_allclose(o.yvar_noise_model(), nv, rtol=1e-12)
+    assert_allclose(o.utility(), yvar[0] / nv[0, 0], rtol=1e-12)
+
+
+def test_sweep_invariances_at_c2_size(obe):
+    settings, prior, cons, true, sigma = bench.make_workload("c2")
+    g = np.random.default_rng(12)
+    n = prior.shape[1]
+    w = g.exponential(1.0, n)
+    w /= w.sum()
+
+    def sweep(p, wts, **kw):
+        o = obe.OptBayesExpt(obe.models.lorentzian(), settings, p, cons, utility_method="variance_full",
+                             default_noise_std=sigma, auto_resample=False, **kw)
+        o.particle_weights = wts
+        return o, (None if "settings_shard" in kw else o.yvar_from_parameter_draws()[0])
+
+    _, base = sweep(prior.copy(), w)
+    # (1) the cloud is a set: any permutation of the particles gives the same variance
+    perm = g.permutation(n)
+    _, permuted = sweep(prior[:, perm].copy(), w[perm])
+    assert_allclose(permuted, base, rtol=RTOL)
+    # (2) amplitude and background scaled by 2 (exact in binary): variance scales by exactly 4
+    scaled = prior.copy()
+    scaled[1:] *= 2.0
+    _, four = sweep(scaled, w)
+    assert_allclose(four, 4.0 * base, rtol=1e-13)
+    # (3) every particle duplicated with half its weight: same distribution, same variance
+    _, dup = sweep(np.concatenate([prior, prior], axis=1), np.concatenate([w, w]) / 2)
+    assert_allclose(dup, base, rtol=RTOL)
+    # (4) settings sharded 3 ways: the union of the slices is the full sweep, and the
+    #     first-max over the rank winners is the global argmax
+    from optbayesexpt_amd.dist import SettingsShard, first_max
+    vals, idxs, parts = [], [], []
+    for r in range(3):
+        o, _ = sweep(prior.copy(), w, settings_shard=SettingsShard(rank=r, world_size=3))
+        v, i = o._sweep_device(True)
+        vals.append(v)
+        idxs.append(i)
+        parts.append(o._yvar_dev.cpu().numpy()[0])
+    assert_allclose(np.concatenate(parts), base, rtol=1e-13)      # only the chunk partial-sum order differs
+    k = first_max(np.array(vals), np.array(idxs))
+    assert idxs[k] == int(np.argmax(base))
+
+
+def test_update_and_resample_at_one_million_particles(obe):
+    settings, prior, cons, true, sigma = bench.make_workload("c3")
+    n = prior.shape[1]
+    sv = (settings[0][::1024],)                     # 64 settings: this test is about the cloud
+    a = obe.OptBayesExpt(obe.models.lorentzian(), sv, prior.copy(), cons, scale=False, auto_resample=False)
+    b = oracle.OracleOptBayesExpt(omodels.lorentzian, sv, prior.copy(), cons, scale=False, auto_resample=False,
+                                  n_channels=1)
+    for o in (a, b):
+        o.rng = np.random.default_rng(2024)
+        for x, y in (((3.05,), 49300.0), ((2.9,), 49500.0), ((3.0,), 49000.0)):
+            o.pdf_update((x, y, 300.0))
+    assert_allclose(a.particle_weights, b.particle_weights, rtol=RTOL, atol=1e-13 * b.particle_weights.max())
+    assert_allclose(a.mean(), b.mean(), rtol=RTOL)
+    assert_allclose(a.covariance(), b.covariance(), rtol=RTOL)
+    for strict in (False, True):
+        a.tuning_parameters["strict_cdf"] = strict
+        a.rng, b.rng = np.random.default_rng(7), np.random.default_rng(7)
+        wa = a.particle_weights.copy()
+        b2 = oracle.OracleParticlePDF(np.array(b.particles), scale=False)
+        b2.particle_weights = b.particle_weights.copy()
+        b2.rng = b.rng
+        a2 = obe.ParticlePDF(np.array(a.particles), scale=False)
+        a2.tuning_parameters["strict_cdf"] = strict
+        a2.particle_weights = wa
+        a2.rng = a.rng
+        a2.resample()
+        b2.resample()
+        assert_array_equal(a2.last_draw_indices, b2.last_draw_indices)       # 1 048 576 exact indices
+        for i in range(3):
+            assert_allclose(a2.particles[i], b2.particles[i], rtol=RTOL)
+        assert_array_equal(a2.particle_weights, b2.particle_weights)

@@ -34,7 +34,8 @@ def test_trajectory_matches_reference(hip, name):
                           device_models()[fx["meta"]["model"]])
     stats = _replay.replay(fx, o, _replay.HIP_RTOL[name],
                            get_draw_idx=lambda x: x.last_draw_indices,
-                           get_utility=lambda x: x._utility_dev.cpu().numpy())
+                           get_utility=lambda x: x._utility_dev.cpu().numpy(),
+                           floor_units=_replay.NUDGE_FLOOR_UNITS[name])
     assert stats["cycles"] == fx["meta"]["n_cycles"]
     assert stats["resamples"] == int(np.sum(fx["resampled"])) >= 5
 

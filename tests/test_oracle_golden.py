@@ -36,7 +36,7 @@ def test_trajectory_matches_reference(name):
 
 
 def test_reference_conditioning_10_parameters(monkeypatch):
-    """Why the HIP tolerance on the 10-parameter trajectory is 2e-8 and not 1e-10: the
+    """Why the HIP tolerance on the 10-parameter trajectory is 1e-6 and not 1e-10: the
     reference algorithm, run on the CPU with its weighted covariance summed in reverse
     particle order (an equally valid float64 evaluation), no longer reproduces its own
     golden utilities to 1e-10 once a resample has happened."""
@@ -49,14 +49,14 @@ def test_reference_conditioning_10_parameters(monkeypatch):
                             ORACLE_MODELS["multi_lorentzian_7"])
     worst = 0.0
     import warnings
-    for cyc in range(8):
+    for cyc in range(fx["meta"]["n_cycles"]):
         x = obe.opt_setting()
         assert obe.last_setting_index == fx["chosen_index"][cyc]
         worst = max(worst, np.abs(obe.last_utility / fx["utility"][cyc] - 1).max())
         with warnings.catch_warnings():
             warnings.simplefilter("ignore", RuntimeWarning)
             obe.pdf_update((x, float(fx["y_meas"][cyc][0])))
-    assert 1e-10 < worst < _replay.HIP_RTOL["multilorentz7_noise"]
+    assert 2e-8 < worst < _replay.HIP_RTOL["multilorentz7_noise"]
 
 
 def test_unit_cases():
