@@ -40,8 +40,9 @@ struct SweepPlan {
 };
 
 // Tuned on MI355X at 65 536 x 1 048 576 (tools/tune_sweep.sh): 8 settings per lane (one
-// batched reciprocal per 8 evaluations) and ~3000 workgroups (12 per CU, 3 resident at
-// 161 VGPRs) gave the shortest kernel; fewer, larger workgroups lose 3-5 % to the tail.
+// batched reciprocal per 8 evaluations); 768 resident workgroups (3 per CU at 161 VGPRs).
+// 1536 workgroups = two full rounds: within 1 % of the best time (3072) with half the
+// chunk partials to write and re-read; 768 loses 5 % to the tail.
 static SweepPlan plan_sweep(int64_t ns, int64_t nd) {
     static const int force_spt = getenv("OBE_SWEEP_SPT") ? atoi(getenv("OBE_SWEEP_SPT")) : 0;         // tuning aids
     static const int force_blocks = getenv("OBE_SWEEP_BLOCKS") ? atoi(getenv("OBE_SWEEP_BLOCKS")) : 0;
@@ -49,7 +50,7 @@ static SweepPlan plan_sweep(int64_t ns, int64_t nd) {
     p.spt = ns >= 4096 ? 8 : (ns >= 1024 ? 4 : (ns >= 512 ? 2 : 1));
     if (force_spt == 1 || force_spt == 2 || force_spt == 4 || force_spt == 8) p.spt = force_spt;
     p.tiles_x = static_cast<int>((ns + (int64_t)kBlock * p.spt - 1) / ((int64_t)kBlock * p.spt));
-    const int target_blocks = force_blocks > 0 ? force_blocks : 3072;
+    const int target_blocks = force_blocks > 0 ? force_blocks : 1536;
     int64_t want = (target_blocks + p.tiles_x - 1) / p.tiles_x;
     int64_t cap = std::min<int64_t>(kMaxChunks, (nd + 511) / 512);     // >= 512 draws per chunk
     if (cap < 1) cap = 1;
@@ -79,6 +80,7 @@ struct SweepArgs {
     double uniform_w;          // 1/nd in draws mode
     const double* moments;     // obe_moments output: mean parameters at +2
     int64_t chunk;
+    int tiles_x, nchunks;      // logical grid: setting tiles x particle chunks
     int tile;                  // particles per LDS tile
     double* part1;
     double* part2;
@@ -90,6 +92,15 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(SweepArgs a) {
     constexpr int NPKW = (NPK + 1 + 1) & ~1;   // packed particle + sqrt(weight), padded to 16 B
     extern __shared__ __attribute__((aligned(16))) double tile[];
 
+    // XCD-aware block -> (setting tile, particle chunk) map.  Workgroup b is dispatched to
+    // XCD b % 8 (observed placement; only speed depends on it): give XCD x the chunks
+    // {x, x+8, ...}, so each 4 MiB L2 streams 1/8 of the cloud instead of all of it
+    // (rocprofv3 FETCH_SIZE before: 8 x the cloud per launch).
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int chunk_id = (slot / a.tiles_x) * 8 + xcd;
+    const int tile_x = slot % a.tiles_x;
+    if (chunk_id >= a.nchunks) return;
+
     double xs[SPT][NXS], cs[SPT][NC], s1[SPT][NC], s2[SPT][NC];
     const double* __restrict__ thbar = a.moments + 2;   // weighted-mean parameters (K3 output)
 
@@ -98,7 +109,7 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(SweepArgs a) {
         M::pack(ParamRef{thbar, 1}, thbar, a.m, 1.0, pkbar);
 #pragma unroll
         for (int j = 0; j < SPT; ++j) {
-            int64_t s = ((int64_t)blockIdx.x * SPT + j) * kBlock + threadIdx.x;
+            int64_t s = ((int64_t)tile_x * SPT + j) * kBlock + threadIdx.x;
             if (s >= a.ns) s = a.ns - 1;
             double x[M::NS];
 #pragma unroll
@@ -110,7 +121,7 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(SweepArgs a) {
         M::template sweep_eval<SPT>(xs, pkbar, 1.0, a.m, cs);
     }
 
-    const int64_t p_begin = (int64_t)blockIdx.y * a.chunk;
+    const int64_t p_begin = (int64_t)chunk_id * a.chunk;
     const int64_t p_end = p_begin + a.chunk < a.nd ? p_begin + a.chunk : a.nd;
     for (int64_t t0 = p_begin; t0 < p_end; t0 += a.tile) {
         const int n = static_cast<int>(p_end - t0 < a.tile ? p_end - t0 : a.tile);
@@ -156,11 +167,11 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(SweepArgs a) {
 
 #pragma unroll
     for (int j = 0; j < SPT; ++j) {
-        const int64_t s = ((int64_t)blockIdx.x * SPT + j) * kBlock + threadIdx.x;
+        const int64_t s = ((int64_t)tile_x * SPT + j) * kBlock + threadIdx.x;
         if (s < a.ns) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                const int64_t o = ((int64_t)blockIdx.y * NC + c) * a.ns + s;
+                const int64_t o = ((int64_t)chunk_id * NC + c) * a.ns + s;
                 a.part1[o] = s1[j][c];
                 a.part2[o] = s2[j][c];
             }
@@ -331,7 +342,9 @@ static int launch_sweep(const SweepPlan& p, SweepArgs& a, hipStream_t st) {
     tile = tile / 64 * 64;
     a.tile = tile;
     const size_t lds = (size_t)tile * NPKW * sizeof(double);
-    dim3 grid(p.tiles_x, p.nchunks);
+    a.tiles_x = p.tiles_x;
+    a.nchunks = p.nchunks;
+    const unsigned grid = (unsigned)p.tiles_x * (unsigned)((p.nchunks + 7) / 8 * 8);
     switch (p.spt) {
         case 8: sweep_kernel<M, 8><<<grid, kBlock, lds, st>>>(a); break;
         case 4: sweep_kernel<M, 4><<<grid, kBlock, lds, st>>>(a); break;

@@ -1,0 +1,86 @@
+"""Turn the rocprofv3 (rocpd sqlite) outputs under gpurun_out/prof into the small text
+summaries that are committed under profiles/ (developer aid; run in the build container
+after tools/profile_rocprof.sh has run on the GPU box)."""
+import json
+import os
+import sqlite3
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "prof")
+DST = os.path.join(ROOT, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+cfg = sys.argv[2] if len(sys.argv) > 2 else "c3"
+n_p, n_s, d = (1048576, 65536, 3) if cfg == "c3" else (262144, 4096, 3)
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "").strip()
+
+
+# 1. kernel-trace --stats summary
+c = sqlite3.connect(os.path.join(SRC, "trace", "bench_results.db"))
+rows = list(c.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+with open(os.path.join(DST, f"{tag}_kernel_stats_{cfg}.txt"), "w") as f:
+    f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline ({cfg})\n")
+    f.write("# durations in microseconds; bench.py's own JSON line for this profiled run follows the table\n")
+    f.write(f"{'kernel':70s} {'calls':>6s} {'total_us':>12s} {'avg_us':>12s} {'pct':>7s}\n")
+    for name, calls, total, avg, pct in rows:
+        f.write(f"{short(name)[:70]:70s} {calls:6d} {total:12.1f} {avg:12.2f} {pct:7.2f}\n")
+    log = os.path.join(SRC, "trace_stdout.log")
+    if os.path.exists(log):
+        for line in open(log):
+            if line.startswith("{"):
+                f.write("\n# bench.py output under the profiler:\n" + line)
+print(open(os.path.join(DST, f"{tag}_kernel_stats_{cfg}.txt")).read()[:3000])
+
+
+# 2. PMC passes: FETCH_SIZE / WRITE_SIZE are in KiB per dispatch
+def per_kernel(db, counter):
+    c = sqlite3.connect(db)
+    out = {}
+    q = ("select kernel_name, count(*), avg(value), min(value), max(value) from counters_collection "
+         "where counter_name = ? group by kernel_name")
+    for name, n, avg, lo, hi in c.execute(q, (counter,)):
+        out[short(name)] = dict(dispatches=n, avg_kib=avg, min_kib=lo, max_kib=hi)
+    return out
+
+
+fetch = per_kernel(os.path.join(SRC, "pmc_fetch", "bench_results.db"), "FETCH_SIZE")
+write = per_kernel(os.path.join(SRC, "pmc_write", "bench_results.db"), "WRITE_SIZE")
+summary = {"config": cfg, "units": "KiB per dispatch as reported by rocprofv3 (uncorrected)", "kernels": {}}
+for k in sorted(set(fetch) | set(write)):
+    if k.startswith("obe::"):
+        summary["kernels"][k] = {"FETCH_SIZE": fetch.get(k), "WRITE_SIZE": write.get(k)}
+
+# Calibration on a stream with a known byte count and the same access width (8 B per lane):
+# pass A of the Bayes update reads (D+1) rows and writes one row of N_p doubles.
+upd = [k for k in summary["kernels"] if "update_model_kernel" in k]
+corr = None
+if upd:
+    u = summary["kernels"][upd[0]]
+    known_read = 8 * (d + 1) * n_p
+    known_write = 8 * n_p
+    corr = {"kernel": upd[0], "known_read_bytes": known_read, "known_write_bytes": known_write,
+            "fetch_reported_bytes": u["FETCH_SIZE"]["avg_kib"] * 1024,
+            "write_reported_bytes": u["WRITE_SIZE"]["avg_kib"] * 1024}
+    corr["fetch_factor"] = known_read / corr["fetch_reported_bytes"]
+    corr["write_factor"] = known_write / corr["write_reported_bytes"]
+summary["calibration"] = corr
+sw = [k for k in summary["kernels"] if "sweep_kernel" in k]
+if sw and corr:
+    s = summary["kernels"][sw[0]]
+    rd = s["FETCH_SIZE"]["avg_kib"] * 1024 * corr["fetch_factor"]
+    wr = s["WRITE_SIZE"]["avg_kib"] * 1024 * corr["write_factor"]
+    summary["sweep_kernel_hbm_bytes_per_launch"] = rd + wr
+    summary["sweep_kernel_note"] = ("calibrated FETCH+WRITE per launch; compulsory bytes are "
+                                    f"{8 * (d + 1) * n_p + 16 * n_s} (cloud + settings) plus the chunk partials")
+path = os.path.join(DST, f"{tag}_pmc_hbm_{cfg}.json")
+json.dump(summary, open(path, "w"), indent=1)
+print(json.dumps(summary, indent=1)[:4000])
+# bench.py reads this file for roofline.traffic
+tpath = os.path.join(DST, "pmc_traffic.json")
+allcfg = json.load(open(tpath)) if os.path.exists(tpath) else {}
+allcfg[cfg] = {"sweep_kernel_hbm_bytes_per_launch": summary.get("sweep_kernel_hbm_bytes_per_launch"),
+               "source": os.path.basename(path)}
+json.dump(allcfg, open(tpath, "w"), indent=1)
