@@ -73,30 +73,34 @@ def build_obe(cfg, shard, settings, prior, cons):
                                           settings_shard=shard)
 
 
-def cpu_baseline(cfg, settings, prior, cons, true, sigma, n_sub=128):
+def cpu_baseline(cfg, settings, prior, cons, true, sigma, target_s=12.0):
     """The oracle (NumPy, one core) on a bounded sample of the same workload: the full
-    particle cloud against ``n_sub`` evenly spaced settings for the sweep, plus the full
-    update.  Throughput = algorithmic evals / time, to be read as evals/s of the
-    reference-style NumPy path on this host."""
+    particle cloud against a sub-grid of evenly spaced settings for the sweep, plus the
+    full update.  A short probe sizes the sub-grid for ~``target_s`` seconds of CPU work.
+    Throughput = algorithmic evals / time: the evals/s of the reference-style NumPy path
+    on this host (it scales linearly in the number of settings)."""
     import oracle
     from oracle import models as om
     fn = om.lorentzian if CONFIGS[cfg][2] == "lorentzian" else om.multi_lorentzian(7)
     ns, n_p = CONFIGS[cfg][0], CONFIGS[cfg][1]
-    sub = (np.ascontiguousarray(settings[0][:: max(1, ns // n_sub)][:n_sub]),)
     w = np.full(n_p, 1.0 / n_p)
-    t0 = time.perf_counter()
-    yvar = oracle.yvar_full_sweep(fn, oracle.flatten_settings(sub), prior, w, cons, chunk=4096)
-    util = oracle.utility_from_yvar(yvar, sigma ** 2, 1.0)
-    best = int(np.argmax(util))
-    x = (sub[0][best],)
-    y_model = fn(x, prior, cons)
-    lik = oracle.gauss_likelihood(y_model, float(fn(x, true, cons)), sigma)
-    w2 = oracle.normalized_product(w, lik)
-    oracle.effective_particles(w2)
-    dt = time.perf_counter() - t0
-    evals = len(sub[0]) * n_p + n_p
+
+    def cycle(n_sub):
+        sub = (np.ascontiguousarray(settings[0][:: max(1, ns // n_sub)][:n_sub]),)
+        t0 = time.perf_counter()
+        yvar = oracle.yvar_full_sweep(fn, oracle.flatten_settings(sub), prior, w, cons, chunk=4096)
+        util = oracle.utility_from_yvar(yvar, sigma ** 2, 1.0)
+        x = (sub[0][int(np.argmax(util))],)
+        lik = oracle.gauss_likelihood(fn(x, prior, cons), float(fn(x, true, cons)), sigma)
+        oracle.effective_particles(oracle.normalized_product(w, lik))
+        return len(sub[0]), time.perf_counter() - t0
+
+    n0, dt0 = cycle(min(32, ns))
+    n_sub = int(min(ns, max(n0, n0 * target_s / max(dt0, 1e-3))))
+    n_used, dt = cycle(n_sub)
+    evals = n_used * n_p + n_p
     return {"value": evals / dt, "unit": "model-evals/s", "cores": 1, "kind": "port",
-            "sample": f"{len(sub[0])} of {ns} settings x all {n_p} particles (two-pass weighted variance, "
+            "sample": f"{n_used} of {ns} settings x all {n_p} particles (two-pass weighted variance, "
                       f"chunked) + full {n_p}-particle update, {dt:.1f} s; NumPy ufuncs are single-threaded",
             "host_cpus": os.cpu_count()}
 
