@@ -217,6 +217,23 @@ int obe_utility_argmax(const double* d_yvar, int32_t n_channels, int64_t n_setti
 int obe_argmax(const double* d_v, int64_t n, double* h_best, int64_t* h_best_idx,
                void* d_ws, int64_t ws_bytes, void* stream);
 
+/* ---- device-side continuation of the caller's numpy PCG64 stream ----
+ * Replaces the host calls inside resample(): rng.random(n) (the uniforms Generator.choice
+ * draws, particlepdf.py:330) and rng.standard_normal((n, d)) (inside multivariate_normal,
+ * particlepdf.py:300).  h_state4 = {state_hi, state_lo, inc_hi, inc_lo} of
+ * rng.bit_generator.state; d_raw[i] = the (i+1)-th next_uint64 of that generator. */
+int obe_pcg64_raw(const uint64_t* h_state4, int64_t n_raw, uint64_t* d_raw, void* stream);
+/* d_out[i] = (d_raw[i] >> 11) * 2^-53  (numpy next_double / Generator.random). */
+int obe_pcg64_uniform(const uint64_t* d_raw, int64_t n, double* d_out, void* stream);
+/* n standard normals by numpy's ziggurat from d_raw[offset...]: bit-identical values and
+ * the exact number of raw values consumed (*h_consumed; sync), so the host generator can
+ * be advanced to where numpy would have left it.  d_tables = ki[256] (uint64) | wi[256] |
+ * fi[256] (float64).  Returns 1 if n_raw is too short (retry with a longer buffer). */
+int64_t obe_ziggurat_workspace_bytes(int64_t n_raw);
+int obe_ziggurat_normal(const uint64_t* d_raw, int64_t n_raw, int64_t offset, const void* d_tables,
+                        int64_t n, double* d_out, int64_t* h_consumed,
+                        void* d_ws, int64_t ws_bytes, void* stream);
+
 /* ---- timing on the launch stream (bench.py roofline leg) ---- */
 int obe_timer_create(void** timer);
 int obe_timer_start(void* timer, void* stream);

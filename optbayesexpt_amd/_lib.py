@@ -76,6 +76,10 @@ _SIGNATURES = {
     "obe_yspace_variance": (c_int, [_P, c_int64, c_int32, c_int64, _P, _P]),
     "obe_utility_argmax": (c_int, [_P, c_int32, c_int64, _P, c_int64, _P, c_double, _P, _P, _P, _P, c_int64, _P]),
     "obe_argmax": (c_int, [_P, c_int64, _P, _P, _P, c_int64, _P]),
+    "obe_pcg64_raw": (c_int, [_P, c_int64, _P, _P]),
+    "obe_pcg64_uniform": (c_int, [_P, c_int64, _P, _P]),
+    "obe_ziggurat_workspace_bytes": (c_int64, [c_int64]),
+    "obe_ziggurat_normal": (c_int, [_P, c_int64, c_int64, _P, c_int64, _P, _P, _P, c_int64, _P]),
     "obe_timer_create": (c_int, [ctypes.POINTER(c_void_p)]),
     "obe_timer_start": (c_int, [_P, _P]),
     "obe_timer_stop": (c_int, [_P, _P, ctypes.POINTER(ctypes.c_float)]),

@@ -1,0 +1,339 @@
+// Device-side continuation of the caller's NumPy random stream.
+//
+// resample() needs N uniforms (Generator.choice) and N*D standard normals
+// (Generator.multivariate_normal) from the object's `rng`; for seeded runs to reproduce the
+// reference they must be the *same numbers* numpy would have produced.  Generating them on
+// one host core costs 25 ms at 1M particles (more than the whole utility sweep); here the
+// same stream is produced on the GPU:
+//
+//   pcg64_raw_kernel     PCG64 = 128-bit LCG + XSL-RR output.  Thread g jumps ahead to
+//                        stream position g in O(log g) 128-bit multiplies, then strides by
+//                        the grid size with a precomputed (A, C) jump: coalesced 8-byte
+//                        stores, no serial dependence between threads.
+//   uniform              (raw >> 11) * 2^-53, numpy's next_double.
+//   normals              numpy's ziggurat consumes a *variable* number of raw values per
+//                        normal (1 for 98.8 % of them), so "which raw value starts the k-th
+//                        normal" is a serial question.  It is answered in parallel:
+//                          classify  every raw position i as if a normal started there:
+//                                    value[i] and length[i] (raw values consumed);
+//                          starts    position i is a real start iff the chain of jumps
+//                                    i -> i + length[i] from the first position hits it;
+//                                    each thread finds a nearby position that no jump can
+//                                    skip (an anchor) and follows the chain from there;
+//                          compact   prefix sum over the start flags = index of the normal;
+//                                    scatter value[i] to out[rank[i]].
+//   The ziggurat tables (ki, wi, fi) are data supplied by the host
+//   (optbayesexpt_amd/data/ziggurat_tables.npz, see tools/make_ziggurat_tables.py).
+#include "obe_common.h"
+
+namespace obe {
+
+struct U128 {
+    uint64_t hi, lo;
+};
+
+__host__ __device__ __forceinline__ U128 mul128(U128 a, U128 b) {
+    U128 r;
+#if defined(__HIP_DEVICE_COMPILE__)
+    r.hi = __umul64hi(a.lo, b.lo) + a.lo * b.hi + a.hi * b.lo;
+#else
+    r.hi = (uint64_t)(((unsigned __int128)a.lo * b.lo) >> 64) + a.lo * b.hi + a.hi * b.lo;
+#endif
+    r.lo = a.lo * b.lo;
+    return r;
+}
+
+__host__ __device__ __forceinline__ U128 add128(U128 a, U128 b) {
+    U128 r;
+    r.lo = a.lo + b.lo;
+    r.hi = a.hi + b.hi + (r.lo < a.lo ? 1 : 0);
+    return r;
+}
+
+// PCG_DEFAULT_MULTIPLIER_128
+__host__ __device__ __forceinline__ U128 pcg_mult() { return U128{0x2360ed051fc65da4ULL, 0x4385df649fccf645ULL}; }
+
+// (A, C) with  state_after_delta_steps = A * state + C   (LCG jump-ahead, O(log delta))
+__host__ __device__ inline void lcg_jump(U128 inc, uint64_t delta, U128& A, U128& C) {
+    U128 acc_mult{0, 1}, acc_plus{0, 0}, cur_mult = pcg_mult(), cur_plus = inc;
+    while (delta > 0) {
+        if (delta & 1) {
+            acc_mult = mul128(acc_mult, cur_mult);
+            acc_plus = add128(mul128(acc_plus, cur_mult), cur_plus);
+        }
+        cur_plus = mul128(add128(cur_mult, U128{0, 1}), cur_plus);
+        cur_mult = mul128(cur_mult, cur_mult);
+        delta >>= 1;
+    }
+    A = acc_mult;
+    C = acc_plus;
+}
+
+// XSL-RR 128 -> 64
+__device__ __forceinline__ uint64_t pcg_output(U128 s) {
+    const uint64_t x = s.hi ^ s.lo;
+    const unsigned rot = (unsigned)(s.hi >> 58);
+    return (x >> rot) | (x << ((64 - rot) & 63));
+}
+
+struct PcgArgs {
+    U128 state, inc;     // generator state before the first value of this call
+    U128 strideA, strideC;   // jump by gridDim.x * blockDim.x
+};
+
+// raw[i] = output(step^(i+1)(state))
+__global__ __launch_bounds__(kBlock) void pcg64_raw_kernel(PcgArgs a, int64_t n, uint64_t* __restrict__ raw) {
+    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    if (g >= n) return;
+    U128 A, C;
+    lcg_jump(a.inc, (uint64_t)g + 1, A, C);
+    U128 s = add128(mul128(A, a.state), C);
+    for (int64_t i = g; i < n; i += stride) {
+        raw[i] = pcg_output(s);
+        s = add128(mul128(a.strideA, s), a.strideC);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void uniform_kernel(const uint64_t* __restrict__ raw, int64_t n,
+                                                         double* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        out[i] = (double)(raw[i] >> 11) * (1.0 / 9007199254740992.0);
+}
+
+constexpr int kMaxLen = 32;          // longest ziggurat draw handled on the device
+constexpr double kZigR = 3.6541528853610087963519472518;      // ziggurat tail start, 256 layers
+constexpr double kZigInvR = 0.27366123732975827203338247596;   // 1/r, as published with r
+
+struct ZigTables {
+    const uint64_t* ki;
+    const double* wi;
+    const double* fi;
+};
+
+__device__ __forceinline__ double next_double(uint64_t r) { return (double)(r >> 11) * (1.0 / 9007199254740992.0); }
+
+// numpy/random/src/distributions: random_standard_normal (ziggurat), as if a normal
+// started at raw[i].  length = raw values consumed (0 = ran off the buffer / too long).
+__global__ __launch_bounds__(kBlock) void zig_classify_kernel(const uint64_t* __restrict__ raw, int64_t n_raw,
+                                                              ZigTables t, double* __restrict__ val,
+                                                              uint8_t* __restrict__ len) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n_raw; i += (int64_t)gridDim.x * kBlock) {
+        int64_t pos = i;
+        double x = 0.0;
+        bool done = false, bad = false;
+        while (!done) {
+            if (pos >= n_raw || pos - i >= kMaxLen) { bad = true; break; }
+            uint64_t r = raw[pos++];
+            const int idx = (int)(r & 0xff);
+            r >>= 8;
+            const int sign = (int)(r & 0x1);
+            const uint64_t rabs = (r >> 1) & 0x000fffffffffffffULL;
+            x = (double)rabs * t.wi[idx];
+            if (sign) x = -x;
+            if (rabs < t.ki[idx]) break;                       // 99.3 %: inside the rectangle
+            if (idx == 0) {                                    // tail of the base strip
+                for (;;) {
+                    if (pos + 1 >= n_raw || pos + 2 - i > kMaxLen) { bad = true; break; }
+                    const double xx = -kZigInvR * log1p(-next_double(raw[pos]));
+                    const double yy = -log1p(-next_double(raw[pos + 1]));
+                    pos += 2;
+                    if (yy + yy > xx * xx) {
+                        x = ((rabs >> 8) & 0x1) ? -(kZigR + xx) : kZigR + xx;
+                        done = true;
+                        break;
+                    }
+                }
+                if (bad) break;
+            } else {                                           // wedge
+                if (pos >= n_raw) { bad = true; break; }
+                const double u = next_double(raw[pos++]);
+                if ((t.fi[idx - 1] - t.fi[idx]) * u + t.fi[idx] < exp(-0.5 * x * x)) done = true;
+            }
+        }
+        val[i] = x;
+        len[i] = bad ? 0 : (uint8_t)(pos - i);
+    }
+}
+
+// flag[i] = 1 iff a normal really starts at raw position i (i >= first).
+__global__ __launch_bounds__(kBlock) void zig_starts_kernel(const uint8_t* __restrict__ len, int64_t n_raw,
+                                                            int64_t first, uint32_t* __restrict__ flag) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n_raw; i += (int64_t)gridDim.x * kBlock) {
+        if (i < first) { flag[i] = 0; continue; }
+        // anchor: the nearest a <= i that no earlier position can jump over
+        int64_t a = i;
+        for (;;) {
+            if (a == first) break;
+            bool skipped = false;
+            const int64_t lo = a - (kMaxLen - 1) > first ? a - (kMaxLen - 1) : first;
+            for (int64_t q = a - 1; q >= lo; --q) {
+                if (q + (int64_t)len[q] > a) { skipped = true; break; }
+            }
+            if (!skipped) break;
+            --a;
+        }
+        int64_t p = a;
+        bool ok = true;
+        while (p < i) {
+            const int l = len[p];
+            if (l == 0) { ok = false; break; }
+            p += l;
+        }
+        flag[i] = (ok && p == i) ? 1u : 0u;   // chains only break within kMaxLen of the buffer end
+    }
+}
+
+// ---- uint32 exclusive scan of the flags (reduce-then-scan, 2048 per block) ----
+constexpr int kFlagItems = 8;
+constexpr int kFlagTile = kBlock * kFlagItems;
+
+__device__ __forceinline__ uint32_t flag_tile_scan(uint32_t (&v)[kFlagItems], uint32_t* lds) {
+#pragma unroll
+    for (int k = 1; k < kFlagItems; ++k) v[k] += v[k - 1];
+    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+    uint32_t incl = v[kFlagItems - 1];
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o, kWave);
+        if (lane >= o) incl += up;
+    }
+    __syncthreads();
+    if (lane == kWave - 1) lds[wid] = incl;
+    __syncthreads();
+    uint32_t wave_off = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / kWave; ++w) {
+        if (w < wid) wave_off += lds[w];
+        total += lds[w];
+    }
+    const uint32_t thread_off = wave_off + incl - v[kFlagItems - 1];
+#pragma unroll
+    for (int k = 0; k < kFlagItems; ++k) v[k] += thread_off;      // inclusive
+    return total;
+}
+
+__global__ __launch_bounds__(kBlock) void flag_block_sums(const uint32_t* __restrict__ flag, int64_t n,
+                                                          uint32_t* __restrict__ sums) {
+    __shared__ uint32_t lds[kBlock / kWave];
+    uint32_t v[kFlagItems];
+    const int64_t i0 = (int64_t)blockIdx.x * kFlagTile + (int64_t)threadIdx.x * kFlagItems;
+#pragma unroll
+    for (int k = 0; k < kFlagItems; ++k) v[k] = (i0 + k < n) ? flag[i0 + k] : 0u;
+    const uint32_t total = flag_tile_scan(v, lds);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+__global__ void flag_scan_offsets(uint32_t* __restrict__ sums, int64_t nb) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t run = 0;
+    for (int64_t b = 0; b < nb; ++b) {
+        const uint32_t s = sums[b];
+        sums[b] = run;
+        run += s;
+    }
+}
+
+// out[rank] = val[i] for the first n starts; result[0] = raw consumed by them (relative to `first`),
+// result[1] = number of starts found.
+__global__ __launch_bounds__(kBlock) void zig_compact_kernel(const uint32_t* __restrict__ flag,
+                                                             const uint32_t* __restrict__ block_off,
+                                                             const double* __restrict__ val,
+                                                             const uint8_t* __restrict__ len, int64_t n_raw,
+                                                             int64_t first, int64_t n, double* __restrict__ out,
+                                                             int64_t* __restrict__ result) {
+    __shared__ uint32_t lds[kBlock / kWave];
+    uint32_t v[kFlagItems], f[kFlagItems];
+    const int64_t i0 = (int64_t)blockIdx.x * kFlagTile + (int64_t)threadIdx.x * kFlagItems;
+#pragma unroll
+    for (int k = 0; k < kFlagItems; ++k) f[k] = v[k] = (i0 + k < n_raw) ? flag[i0 + k] : 0u;
+    const uint32_t total = flag_tile_scan(v, lds);
+    const uint32_t off = block_off[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < kFlagItems; ++k) {
+        if (f[k]) {
+            const int64_t rank = (int64_t)off + v[k] - 1;      // v is inclusive
+            const int64_t i = i0 + k;
+            if (rank < n) out[rank] = val[i];
+            if (rank == n - 1) result[0] = i + (int64_t)len[i] - first;
+        }
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) result[1] = (int64_t)off + total;
+}
+
+}  // namespace obe
+
+using namespace obe;
+
+extern "C" {
+
+int obe_pcg64_raw(const uint64_t* h_state4, int64_t n_raw, uint64_t* d_raw, void* stream) {
+    if (!h_state4 || !d_raw || n_raw <= 0) return bad_arg("obe_pcg64_raw: bad pointer/size");
+    PcgArgs a;
+    a.state = U128{h_state4[0], h_state4[1]};
+    a.inc = U128{h_state4[2], h_state4[3]};
+    if ((a.inc.lo & 1) == 0) return bad_arg("obe_pcg64_raw: PCG64 increment must be odd");
+    int blocks = static_cast<int>(std::min<int64_t>(512, (n_raw + kBlock - 1) / kBlock));
+    lcg_jump(a.inc, (uint64_t)blocks * kBlock, a.strideA, a.strideC);
+    pcg64_raw_kernel<<<blocks, kBlock, 0, as_stream(stream)>>>(a, n_raw, d_raw);
+    OBE_CHECK_LAUNCH("pcg64_raw_kernel");
+    return 0;
+}
+
+int obe_pcg64_uniform(const uint64_t* d_raw, int64_t n, double* d_out, void* stream) {
+    if (!d_raw || !d_out || n <= 0) return bad_arg("obe_pcg64_uniform: bad pointer/size");
+    uniform_kernel<<<stream_blocks(n, kBlock), kBlock, 0, as_stream(stream)>>>(d_raw, n, d_out);
+    OBE_CHECK_LAUNCH("uniform_kernel");
+    return 0;
+}
+
+int64_t obe_ziggurat_workspace_bytes(int64_t n_raw) {
+    if (n_raw < 1) n_raw = 1;
+    const int64_t nb = (n_raw + kFlagTile - 1) / kFlagTile;
+    return n_raw * (8 + 4 + 1) + nb * 4 + 1024;
+}
+
+int obe_ziggurat_normal(const uint64_t* d_raw, int64_t n_raw, int64_t offset, const void* d_tables, int64_t n,
+                        double* d_out, int64_t* h_consumed, void* d_ws, int64_t ws_bytes, void* stream) {
+    if (!d_raw || !d_tables || !d_out || !h_consumed || n <= 0 || offset < 0 || offset >= n_raw)
+        return bad_arg("obe_ziggurat_normal: bad pointer/size");
+    if (!d_ws || ws_bytes < obe_ziggurat_workspace_bytes(n_raw)) return bad_arg("obe_ziggurat_normal: workspace too small");
+    if (n_raw >= (int64_t)1 << 31) return bad_arg("obe_ziggurat_normal: n_raw must be < 2^31");
+    hipStream_t st = as_stream(stream);
+    const int64_t nb = (n_raw + kFlagTile - 1) / kFlagTile;
+    char* base = static_cast<char*>(d_ws);
+    int64_t* result = reinterpret_cast<int64_t*>(base);             // [0] consumed [1] starts found
+    double* val = reinterpret_cast<double*>(base + 64);
+    uint32_t* flag = reinterpret_cast<uint32_t*>(base + 64 + n_raw * 8);
+    uint32_t* sums = flag + n_raw;
+    uint8_t* len = reinterpret_cast<uint8_t*>(sums + nb);
+    ZigTables t;
+    t.ki = static_cast<const uint64_t*>(d_tables);
+    t.wi = reinterpret_cast<const double*>(t.ki + 256);
+    t.fi = t.wi + 256;
+    OBE_HIP_TRY(hipMemsetAsync(base, 0, 64, st));
+    zig_classify_kernel<<<stream_blocks(n_raw, kBlock), kBlock, 0, st>>>(d_raw, n_raw, t, val, len);
+    OBE_CHECK_LAUNCH("zig_classify_kernel");
+    zig_starts_kernel<<<stream_blocks(n_raw, kBlock), kBlock, 0, st>>>(len, n_raw, offset, flag);
+    OBE_CHECK_LAUNCH("zig_starts_kernel");
+    flag_block_sums<<<(unsigned)nb, kBlock, 0, st>>>(flag, n_raw, sums);
+    OBE_CHECK_LAUNCH("flag_block_sums");
+    flag_scan_offsets<<<1, kWave, 0, st>>>(sums, nb);
+    OBE_CHECK_LAUNCH("flag_scan_offsets");
+    zig_compact_kernel<<<(unsigned)nb, kBlock, 0, st>>>(flag, sums, val, len, n_raw, offset, n, d_out, result);
+    OBE_CHECK_LAUNCH("zig_compact_kernel");
+    int64_t host[2];
+    OBE_HIP_TRY(hipMemcpyAsync(host, result, sizeof(host), hipMemcpyDeviceToHost, st));
+    OBE_HIP_TRY(hipStreamSynchronize(st));
+    // the n-th normal must exist and end well inside the buffer (positions within
+    // kMaxLen of the end may be unclassifiable and would break the chain)
+    if (host[1] < n || host[0] <= 0 || host[0] > n_raw - offset - 2 * kMaxLen) {
+        *h_consumed = -1;
+        set_error("obe_ziggurat_normal: raw buffer too short for the requested normals");
+        return 1;      /* OBE_RNG_NEED_MORE */
+    }
+    *h_consumed = host[0];
+    return 0;
+}
+
+}  // extern "C"

@@ -13,7 +13,7 @@ import warnings
 import numpy as np
 import torch
 
-from . import _lib
+from . import _devrng, _lib
 from ._mirror import Mirror
 
 _P = ctypes.c_void_p
@@ -251,14 +251,31 @@ class ParticlePDF:
             self._cdf_key = key
         return self._cdf_dev
 
-    def _draw_indices(self, n_draws):
-        """Device int64 indices of ``n_draws`` weighted draws: uniforms from self.rng
-        (host, same stream as Generator.choice), CDF search on the device."""
+    def _device_stream(self, n_uniform, n_normal):
+        """A device-side continuation of self.rng for this many draws, or None when the
+        generator is not PCG64 / the request is small / tuning_parameters['device_rng']
+        is False (then self.rng is called on the host, as the reference does)."""
+        if not self.tuning_parameters.get("device_rng", True):
+            return None
+        if n_uniform + n_normal < _devrng.MIN_DEVICE_DRAWS or _devrng.pcg64_state(self.rng) is None:
+            return None
+        return _devrng.DeviceStream(self._lib, self._device, self._stream(), self.rng, n_uniform, n_normal)
+
+    def _draw_indices(self, n_draws, stream=None):
+        """Device int64 indices of ``n_draws`` weighted draws: the uniforms
+        Generator.choice would take from self.rng, CDF search on the device."""
         if self._weights.shape[0] != self.n_particles:
             raise ValueError("a and p must have same size")
         cdf = self._cdf()
-        u = self.rng.random(n_draws)
-        u_dev = torch.from_numpy(np.atleast_1d(u)).to(self._device)
+        own = stream is None
+        if own:
+            stream = self._device_stream(n_draws, 0)
+        if stream is not None:
+            u_dev = stream.uniforms()
+            if own:
+                stream.finish_uniform_only()
+        else:
+            u_dev = torch.from_numpy(np.atleast_1d(self.rng.random(n_draws))).to(self._device)
         idx = torch.empty(n_draws, dtype=torch.int64, device=self._device)
         self._lib.call("obe_cdf_search", _ptr(cdf), self.n_particles, _ptr(u_dev), n_draws, _ptr(idx),
                        self._stream())
@@ -285,7 +302,8 @@ class ParticlePDF:
         (particlepdf.py:260-310).  RNG order as in the reference: N uniforms, then
         N x D standard normals."""
         n, d = self.n_particles, self.n_dims
-        idx = self._draw_indices(n)
+        rstream = self._device_stream(n, n * d)       # exact continuation of self.rng, or None
+        idx = self._draw_indices(n, rstream)
         m = self._moments(True)                       # pre-resample weights (:290-291)
         mean = m[2:2 + d].copy()
         cov = m[2 + 4 * d:2 + 4 * d + d * d].reshape((d, d))
@@ -296,8 +314,10 @@ class ParticlePDF:
         if not np.allclose(np.dot(vh.T * s, vh), newcov, rtol=1e-8, atol=1e-8):
             warnings.warn("covariance is not symmetric positive-semidefinite.", RuntimeWarning)
         factor = np.ascontiguousarray(u * np.sqrt(s))
-        z = self.rng.standard_normal((n, d))
-        z_dev = torch.from_numpy(z).to(self._device)
+        if rstream is not None:
+            z_dev = rstream.normals()                 # (n*d,) row-major (n, d); advances self.rng
+        else:
+            z_dev = torch.from_numpy(self.rng.standard_normal((n, d))).to(self._device)
         old = self._particles.tensor()
         new = torch.empty((d, n), dtype=torch.float64, device=self._device)
         w = self._weights.tensor()

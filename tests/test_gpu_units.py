@@ -400,3 +400,47 @@ def test_set_pdf_keeps_stale_parameters_alias(obe):
     for o in (a, b):
         o.pdf_update(((0.25,), 0.1, 0.3))
     assert_allclose(a.particle_weights, b.particle_weights, rtol=RTOL)
+
+
+# ------------------------------------------- device continuation of the numpy stream
+@pytest.mark.parametrize("seed,n_uniform,n_normal", [(1, 5000, 15000), (2, 1, 70000), (3, 1048576, 3145728),
+                                                     (99, 4096, 4096 * 10), (12345, 333, 100001)])
+def test_device_rng_is_bitwise_numpy(obe, hip, seed, n_uniform, n_normal):
+    """PCG64 uniforms and ziggurat normals generated on the device are the numbers numpy
+    would have produced, and the host generator ends in numpy's state."""
+    import torch
+    from optbayesexpt_amd import _devrng
+    rng = np.random.default_rng(seed)
+    rng.random(7)                                  # start somewhere inside the stream
+    ref = np.random.default_rng(seed)
+    ref.random(7)
+    ds = _devrng.DeviceStream(hip, torch.device("cuda", 0), None, rng, n_uniform, n_normal)
+    u = ds.uniforms().cpu().numpy()
+    z = ds.normals().cpu().numpy()
+    assert_array_equal(u, ref.random(n_uniform))
+    zr = ref.standard_normal(n_normal)
+    body = np.abs(zr) <= 3.6541528853610088
+    assert_array_equal(z[body], zr[body])                       # 99.97 % of draws: bit-identical
+    # ziggurat tail draws go through libm's log1p on the host (device: ocml log1p):
+    # same draw, at most the last bit differs
+    assert_allclose(z[~body], zr[~body], rtol=2.3e-16, atol=0)
+    assert np.sum(z != zr) <= max(8, n_normal // 100000)
+    assert rng.bit_generator.state == ref.bit_generator.state
+    assert_array_equal(rng.random(5), ref.random(5))           # and the streams stay in step
+
+
+def test_device_rng_is_used_and_can_be_disabled(obe, unit):
+    """Same resample through the device stream and through host calls on self.rng."""
+    out = {}
+    for dev in (True, False):
+        pdf = obe.ParticlePDF(unit["rs_s0_x"].copy(), scale=False)
+        pdf.tuning_parameters["device_rng"] = dev
+        pdf.particle_weights = unit["rs_s0_w"].copy()
+        pdf.rng = np.random.default_rng(4242)
+        pdf.randdraw(30)
+        pdf.resample()
+        out[dev] = (pdf.last_draw_indices, np.array(pdf.particles), pdf.rng.bit_generator.state)
+    assert_array_equal(out[True][0], out[False][0])
+    assert_allclose(out[True][1], out[False][1], rtol=1e-15)     # tail normals: last bit (libm log1p)
+    assert out[True][2] == out[False][2]
+    assert_array_equal(out[True][0], unit["rs_s0_resample_idx"])
