@@ -177,8 +177,9 @@ def main():
     ms = ctypes.c_float(0.0)
     stream = obe._stream()
     s_ptr = ctypes.c_void_p(obe._settings_dev.data_ptr() + 8 * obe._s_begin)
+    shifted = bool(obe.last_sweep["shifted"])           # the variant the timed cycles ended on
     lib.call("obe_sweep_kernel_time", obe._model_struct, s_ptr, ns, n_local, _ptr(p), p.shape[1], n_p,
-             _ptr(w), _ptr(mom), _ptr(obe._ws), obe._ws_bytes, 5, ctypes.byref(ms), stream)
+             _ptr(w), _ptr(mom), 1 if shifted else 0, _ptr(obe._ws), obe._ws_bytes, 5, ctypes.byref(ms), stream)
     k1_s = ms.value * 1e-3
     flop = FLOP_PER_EVAL[model] * n_local * n_p
     d = prior.shape[0]
@@ -194,7 +195,8 @@ def main():
                 "achieved": flop / k1_s / 1e12, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": flop / k1_s / 1e12 / FP64_VALU_PEAK_TFLOPS,
                 "flop_per_eval": FLOP_PER_EVAL[model], "evals_per_launch": n_local * n_p,
-                "launch_ms": ms.value, "traffic": traffic,
+                "launch_ms": ms.value, "variant": "shifted" if shifted else "unshifted",
+                "kappa": obe.last_sweep["kappa"], "traffic": traffic,
                 "hbm_algorithmic": {"bytes": k1_bytes, "achieved": k1_bytes / k1_s / 1e9, "peak": HBM_PEAK_GBS,
                                     "unit": "GB/s", "frac": k1_bytes / k1_s / 1e9 / HBM_PEAK_GBS,
                                     "note": "compute-bound kernel: ~1e4 flop per compulsory byte"}}

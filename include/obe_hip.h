@@ -186,6 +186,12 @@ int obe_power_normalize(const double* d_u, int64_t n, double exponent, double* d
  *                        ddof=0 variance (np.var over utility_y_space, obe_base.py:488)
  * d_moments: output of obe_moments for the same particles/weights (mean parameters are
  * used as the variance shift, sum w as the normaliser).
+ * shifted != 0: moments are accumulated about a per-setting shift (always safe).
+ * shifted == 0: one instruction fewer per evaluation, accurate only while the predicted
+ * mean does not dominate the spread; *h_kappa (nullable) returns the worst
+ * (mean of y)^2 / var over settings and channels — the factor by which an unshifted sweep
+ * amplifies rounding — so the caller can choose the mode for the next sweep, or repeat
+ * this one with shifted = 1 if an unshifted result came back with a large factor.
  * Then utility[s] = sum_c yvar[c,s] / noise_var[c(,s)] / cost[(s)]   (obe_base.py:650-655)
  * with d_noise_var (C) if noise_ld == 0 else (C, n_settings) rows noise_ld apart, and
  * cost = cost_scalar if d_cost == NULL else d_cost[s]; and the first-maximum argmax
@@ -196,11 +202,11 @@ int obe_sweep_utility(const obe_model* m,
                       const double* d_settings, int64_t ld_s, int64_t n_settings,
                       const double* d_particles, int64_t ld_p, int64_t n_particles,
                       const double* d_weights, const int64_t* d_draw_idx, int64_t n_draws,
-                      const double* d_moments,
+                      const double* d_moments, int32_t shifted,
                       const double* d_noise_var, int64_t noise_ld,
                       const double* d_cost, double cost_scalar,
                       double* d_yvar, double* d_utility,
-                      double* h_best, int64_t* h_best_idx,
+                      double* h_best, int64_t* h_best_idx, double* h_kappa,
                       void* d_ws, int64_t ws_bytes, void* stream);
 
 /* Variance over the draw axis of a caller-filled y-space (N_d, C, N_s) — the
@@ -244,7 +250,7 @@ int obe_timer_destroy(void* timer);
 int obe_sweep_kernel_time(const obe_model* m,
                           const double* d_settings, int64_t ld_s, int64_t n_settings,
                           const double* d_particles, int64_t ld_p, int64_t n_particles,
-                          const double* d_weights, const double* d_moments,
+                          const double* d_weights, const double* d_moments, int32_t shifted,
                           void* d_ws, int64_t ws_bytes, int32_t iters, float* h_ms_avg,
                           void* stream);
 

@@ -71,8 +71,8 @@ _SIGNATURES = {
     "obe_noise_var_from_moments": (c_int, [_P, c_int32, _P, c_int32, _P, _P]),
     "obe_power_normalize": (c_int, [_P, c_int64, c_double, _P, _P, c_int64, _P]),
     "obe_sweep_utility": (c_int, [ctypes.POINTER(ObeModelStruct), _P, c_int64, c_int64, _P, c_int64, c_int64,
-                                  _P, _P, c_int64, _P, _P, c_int64, _P, c_double, _P, _P, _P, _P, _P,
-                                  c_int64, _P]),
+                                  _P, _P, c_int64, _P, c_int32, _P, c_int64, _P, c_double, _P, _P, _P, _P, _P,
+                                  _P, c_int64, _P]),
     "obe_yspace_variance": (c_int, [_P, c_int64, c_int32, c_int64, _P, _P]),
     "obe_utility_argmax": (c_int, [_P, c_int32, c_int64, _P, c_int64, _P, c_double, _P, _P, _P, _P, c_int64, _P]),
     "obe_argmax": (c_int, [_P, c_int64, _P, _P, _P, c_int64, _P]),
@@ -85,7 +85,7 @@ _SIGNATURES = {
     "obe_timer_stop": (c_int, [_P, _P, ctypes.POINTER(ctypes.c_float)]),
     "obe_timer_destroy": (c_int, [_P]),
     "obe_sweep_kernel_time": (c_int, [ctypes.POINTER(ObeModelStruct), _P, c_int64, c_int64, _P, c_int64, c_int64,
-                                      _P, _P, _P, c_int64, c_int32, ctypes.POINTER(ctypes.c_float), _P]),
+                                      _P, _P, c_int32, _P, c_int64, c_int32, ctypes.POINTER(ctypes.c_float), _P]),
 }
 
 

@@ -64,7 +64,8 @@ static SweepPlan plan_sweep(int64_t ns, int64_t nd) {
 static int64_t sweep_ws_doubles(int64_t ns, int64_t nd, int nc) {
     const SweepPlan p = plan_sweep(ns, nd);
     return 2 * (int64_t)p.nchunks * nc * ns      // partial S1, S2
-           + 2 * (int64_t)kMaxBlocks + 16;        // argmax partials + scalars
+           + (int64_t)nc * ns                      // per-setting shift
+           + 3 * (int64_t)kMaxBlocks + 16;         // argmax / kappa partials + scalars
 }
 
 struct SweepArgs {
@@ -84,9 +85,10 @@ struct SweepArgs {
     int tile;                  // particles per LDS tile
     double* part1;
     double* part2;
+    double* cs_out;            // (C, ns): the shift each setting used (0 when unshifted)
 };
 
-template <class M, int SPT>
+template <class M, int SPT, bool SHIFT>
 __global__ __launch_bounds__(kBlock) void sweep_kernel(SweepArgs a) {
     constexpr int NC = M::NC, NXS = M::NXS, NPK = M::NPK;
     constexpr int NPKW = (NPK + 1 + 1) & ~1;   // packed particle + sqrt(weight), padded to 16 B
@@ -119,6 +121,22 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(SweepArgs a) {
             for (int c = 0; c < NC; ++c) s1[j][c] = s2[j][c] = 0.0;
         }
         M::template sweep_eval<SPT>(xs, pkbar, 1.0, a.m, cs);
+        if (!SHIFT) {
+#pragma unroll
+            for (int j = 0; j < SPT; ++j)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) cs[j][c] = 0.0;
+        }
+        if (chunk_id == 0) {
+#pragma unroll
+            for (int j = 0; j < SPT; ++j) {
+                const int64_t s = ((int64_t)tile_x * SPT + j) * kBlock + threadIdx.x;
+                if (s < a.ns) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) a.cs_out[(int64_t)c * a.ns + s] = cs[j][c];
+                }
+            }
+        }
     }
 
     const int64_t p_begin = (int64_t)chunk_id * a.chunk;
@@ -157,7 +175,7 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(SweepArgs a) {
             for (int j = 0; j < SPT; ++j) {
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
-                    const double u = fma(-cs[j][c], sw, v[j][c]);        // sqrt(w) * (y' - c_s)
+                    const double u = SHIFT ? fma(-cs[j][c], sw, v[j][c]) : v[j][c];   // sqrt(w) * (y' - c_s)
                     s1[j][c] = fma(sw, u, s1[j][c]);                     // sum w (y' - c_s)
                     s2[j][c] = fma(u, u, s2[j][c]);                      // sum w (y' - c_s)^2
                 }
@@ -222,11 +240,15 @@ __device__ __forceinline__ void block_argmax(Best b, double* bv, int64_t* bi) {
 __global__ __launch_bounds__(kBlock) void sweep_finalize(const double* __restrict__ part1,
                                                          const double* __restrict__ part2, int nchunks, int nc,
                                                          int64_t ns, const double* __restrict__ moments,
-                                                         int full_mode, UtilArgs ua, double* __restrict__ yvar,
+                                                         int full_mode, UtilArgs ua,
+                                                         const double* __restrict__ cs,
+                                                         double* __restrict__ yvar,
                                                          double* __restrict__ utility, double* __restrict__ bv,
-                                                         int64_t* __restrict__ bi) {
+                                                         int64_t* __restrict__ bi, double* __restrict__ bk) {
+    __shared__ double red[kBlock];
     const double W = full_mode ? moments[0] : 1.0;
     Best best{-INFINITY, INT64_MAX};
+    double kappa = 0.0;     // worst (mean of y')^2 / var: the cancellation an UNSHIFTED sweep would suffer
     for (int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x; s < ns; s += (int64_t)gridDim.x * kBlock) {
         double var[OBE_MAX_CHANNELS];
         for (int c = 0; c < nc; ++c) {
@@ -241,6 +263,9 @@ __global__ __launch_bounds__(kBlock) void sweep_finalize(const double* __restric
             v = v > 0.0 ? v : 0.0;
             var[c] = v;
             yvar[(int64_t)c * ns + s] = v;
+            const double m = cs[(int64_t)c * ns + s] + mu;
+            const double k = v > 0.0 ? (m * m) / v : (m == 0.0 ? 0.0 : INFINITY);
+            if (!(k <= kappa)) kappa = k;                  // NaN counts as "too large"
         }
         const double u = utility_of(var, nc, s, ua);
         utility[s] = u;
@@ -248,6 +273,13 @@ __global__ __launch_bounds__(kBlock) void sweep_finalize(const double* __restric
         if (better(cand, best)) best = cand;
     }
     block_argmax(best, bv, bi);
+    red[threadIdx.x] = kappa;
+    __syncthreads();
+    for (int o = kBlock / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o && !(red[threadIdx.x + o] <= red[threadIdx.x])) red[threadIdx.x] = red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bk[blockIdx.x] = red[0];
 }
 
 __global__ __launch_bounds__(kBlock) void utility_kernel(const double* __restrict__ yvar, int nc, int64_t ns,
@@ -277,7 +309,8 @@ __global__ __launch_bounds__(kBlock) void argmax_kernel(const double* __restrict
 
 // one block: first-max over the block partials -> scalars {value, index (as int64 bits)}
 __global__ __launch_bounds__(kBlock) void argmax_fold(const double* __restrict__ bv, const int64_t* __restrict__ bi,
-                                                      int nb, double* __restrict__ out_v,
+                                                      int nb, const double* __restrict__ bk,
+                                                      double* __restrict__ out_v,
                                                       int64_t* __restrict__ out_i) {
     Best best{-INFINITY, INT64_MAX};
     for (int b = threadIdx.x; b < nb; b += kBlock) {
@@ -285,6 +318,12 @@ __global__ __launch_bounds__(kBlock) void argmax_fold(const double* __restrict__
         if (better(cand, best)) best = cand;
     }
     block_argmax(best, out_v, out_i);   // gridDim.x == 1 -> writes element 0
+    if (bk && threadIdx.x == 0) {       // worst cancellation factor (nb <= 2048: serial fold is fine)
+        double k = 0.0;
+        for (int b = 0; b < nb; ++b)
+            if (!(bk[b] <= k)) k = bk[b];
+        out_v[1] = k;
+    }
 }
 
 // np.var(utility_y_space, axis=0): two-pass over the (small) draw axis
@@ -310,33 +349,39 @@ struct SweepWs {
     int64_t* bi;
     double* out_v;
     int64_t* out_i;
+    double* bk;
+    double* cs;
 };
 
-static int carve_sweep_ws(void* d_ws, int64_t ws_bytes, int64_t part_doubles, SweepWs& w) {
-    const int64_t need = (2 * part_doubles + 2 * (int64_t)kMaxBlocks + 16) * sizeof(double);
+static int carve_sweep_ws(void* d_ws, int64_t ws_bytes, int64_t part_doubles, int64_t cs_doubles, SweepWs& w) {
+    const int64_t need = (2 * part_doubles + cs_doubles + 3 * (int64_t)kMaxBlocks + 16) * sizeof(double);
     if (!d_ws || ws_bytes < need) return bad_arg("sweep workspace too small");
     double* base = static_cast<double*>(d_ws);
-    w.out_v = base;                                     // [0]
+    w.out_v = base;                                     // [0] best value, [1] worst cancellation factor
     w.out_i = reinterpret_cast<int64_t*>(base + 8);     // [8]
     w.bv = base + 16;
     w.bi = reinterpret_cast<int64_t*>(base + 16 + kMaxBlocks);
-    w.part1 = base + 16 + 2 * kMaxBlocks;
+    w.bk = base + 16 + 2 * kMaxBlocks;
+    w.cs = base + 16 + 3 * kMaxBlocks;
+    w.part1 = w.cs + cs_doubles;
     w.part2 = w.part1 + part_doubles;
     return 0;
 }
 
-static int read_best(const SweepWs& w, double* h_best, int64_t* h_best_idx, hipStream_t st) {
-    if (!h_best && !h_best_idx) return 0;
+static int read_best(const SweepWs& w, double* h_best, int64_t* h_best_idx, hipStream_t st,
+                     double* h_kappa = nullptr) {
+    if (!h_best && !h_best_idx && !h_kappa) return 0;
     double tmp[9];
     OBE_HIP_TRY(hipMemcpyAsync(tmp, w.out_v, 9 * sizeof(double), hipMemcpyDeviceToHost, st));
     OBE_HIP_TRY(hipStreamSynchronize(st));
     if (h_best) *h_best = tmp[0];
+    if (h_kappa) *h_kappa = tmp[1];
     if (h_best_idx) memcpy(h_best_idx, &tmp[8], sizeof(int64_t));
     return 0;
 }
 
 template <class M>
-static int launch_sweep(const SweepPlan& p, SweepArgs& a, hipStream_t st) {
+static int launch_sweep(const SweepPlan& p, SweepArgs& a, bool shifted, hipStream_t st) {
     constexpr int NPKW = (M::NPK + 2) & ~1;
     int tile = kSweepLdsDoubles / NPKW;
     tile = tile / 64 * 64;
@@ -345,11 +390,20 @@ static int launch_sweep(const SweepPlan& p, SweepArgs& a, hipStream_t st) {
     a.tiles_x = p.tiles_x;
     a.nchunks = p.nchunks;
     const unsigned grid = (unsigned)p.tiles_x * (unsigned)((p.nchunks + 7) / 8 * 8);
-    switch (p.spt) {
-        case 8: sweep_kernel<M, 8><<<grid, kBlock, lds, st>>>(a); break;
-        case 4: sweep_kernel<M, 4><<<grid, kBlock, lds, st>>>(a); break;
-        case 2: sweep_kernel<M, 2><<<grid, kBlock, lds, st>>>(a); break;
-        default: sweep_kernel<M, 1><<<grid, kBlock, lds, st>>>(a); break;
+    if (shifted) {
+        switch (p.spt) {
+            case 8: sweep_kernel<M, 8, true><<<grid, kBlock, lds, st>>>(a); break;
+            case 4: sweep_kernel<M, 4, true><<<grid, kBlock, lds, st>>>(a); break;
+            case 2: sweep_kernel<M, 2, true><<<grid, kBlock, lds, st>>>(a); break;
+            default: sweep_kernel<M, 1, true><<<grid, kBlock, lds, st>>>(a); break;
+        }
+    } else {
+        switch (p.spt) {
+            case 8: sweep_kernel<M, 8, false><<<grid, kBlock, lds, st>>>(a); break;
+            case 4: sweep_kernel<M, 4, false><<<grid, kBlock, lds, st>>>(a); break;
+            case 2: sweep_kernel<M, 2, false><<<grid, kBlock, lds, st>>>(a); break;
+            default: sweep_kernel<M, 1, false><<<grid, kBlock, lds, st>>>(a); break;
+        }
     }
     OBE_CHECK_LAUNCH("sweep_kernel");
     return 0;
@@ -367,7 +421,8 @@ static int prepare_sweep(const obe_model* m, obe_model& mm, const double* d_sett
     if (nd <= 0) return bad_arg("sweep: n_draws must be positive");
     plan = plan_sweep(ns, nd);
     const int64_t part = (int64_t)plan.nchunks * mm.n_channels * ns;
-    if (int rc = carve_sweep_ws(d_ws, ws_bytes, part, w)) return rc;
+    if (int rc = carve_sweep_ws(d_ws, ws_bytes, part, (int64_t)mm.n_channels * ns, w)) return rc;
+    a.cs_out = w.cs;
     a.m = mm;
     a.settings = d_settings;
     a.ld_s = ld_s;
@@ -407,10 +462,10 @@ int64_t obe_workspace_bytes(int64_t n_particles, int64_t n_settings, int32_t n_c
 
 int obe_sweep_utility(const obe_model* m, const double* d_settings, int64_t ld_s, int64_t n_settings,
                       const double* d_particles, int64_t ld_p, int64_t n_particles, const double* d_weights,
-                      const int64_t* d_draw_idx, int64_t n_draws, const double* d_moments,
+                      const int64_t* d_draw_idx, int64_t n_draws, const double* d_moments, int32_t shifted,
                       const double* d_noise_var, int64_t noise_ld, const double* d_cost, double cost_scalar,
-                      double* d_yvar, double* d_utility, double* h_best, int64_t* h_best_idx, void* d_ws,
-                      int64_t ws_bytes, void* stream) {
+                      double* d_yvar, double* d_utility, double* h_best, int64_t* h_best_idx, double* h_kappa,
+                      void* d_ws, int64_t ws_bytes, void* stream) {
     if (!d_noise_var || !d_yvar || !d_utility) return bad_arg("obe_sweep_utility: bad output/noise pointer");
     obe_model mm;
     SweepPlan plan;
@@ -420,22 +475,22 @@ int obe_sweep_utility(const obe_model* m, const double* d_settings, int64_t ld_s
                                d_draw_idx, n_draws, d_moments, d_ws, ws_bytes, plan, a, w))
         return rc;
     hipStream_t st = as_stream(stream);
-    int rc = dispatch_model(mm, [&](auto M) -> int { return launch_sweep<decltype(M)>(plan, a, st); });
+    int rc = dispatch_model(mm, [&](auto M) -> int { return launch_sweep<decltype(M)>(plan, a, shifted != 0, st); });
     if (rc) return rc;
     UtilArgs ua{d_noise_var, noise_ld, d_cost, cost_scalar};
     const int nb = stream_blocks(n_settings, kBlock);
     sweep_finalize<<<nb, kBlock, 0, st>>>(w.part1, w.part2, plan.nchunks, mm.n_channels, n_settings, d_moments,
-                                          d_draw_idx == nullptr, ua, d_yvar, d_utility, w.bv, w.bi);
+                                          d_draw_idx == nullptr, ua, w.cs, d_yvar, d_utility, w.bv, w.bi, w.bk);
     OBE_CHECK_LAUNCH("sweep_finalize");
-    argmax_fold<<<1, kBlock, 0, st>>>(w.bv, w.bi, nb, w.out_v, w.out_i);
+    argmax_fold<<<1, kBlock, 0, st>>>(w.bv, w.bi, nb, w.bk, w.out_v, w.out_i);
     OBE_CHECK_LAUNCH("argmax_fold");
-    return read_best(w, h_best, h_best_idx, st);
+    return read_best(w, h_best, h_best_idx, st, h_kappa);
 }
 
 int obe_sweep_kernel_time(const obe_model* m, const double* d_settings, int64_t ld_s, int64_t n_settings,
                           const double* d_particles, int64_t ld_p, int64_t n_particles, const double* d_weights,
-                          const double* d_moments, void* d_ws, int64_t ws_bytes, int32_t iters, float* h_ms_avg,
-                          void* stream) {
+                          const double* d_moments, int32_t shifted, void* d_ws, int64_t ws_bytes, int32_t iters,
+                          float* h_ms_avg, void* stream) {
     if (!h_ms_avg || iters < 1) return bad_arg("obe_sweep_kernel_time: bad arguments");
     obe_model mm;
     SweepPlan plan;
@@ -448,11 +503,12 @@ int obe_sweep_kernel_time(const obe_model* m, const double* d_settings, int64_t 
     hipEvent_t e0, e1;
     OBE_HIP_TRY(hipEventCreate(&e0));
     OBE_HIP_TRY(hipEventCreate(&e1));
-    int rc = dispatch_model(mm, [&](auto M) -> int { return launch_sweep<decltype(M)>(plan, a, st); });   // warm
+    const bool sh = shifted != 0;
+    int rc = dispatch_model(mm, [&](auto M) -> int { return launch_sweep<decltype(M)>(plan, a, sh, st); });   // warm
     if (!rc) {
         (void)hipEventRecord(e0, st);
         for (int i = 0; i < iters && !rc; ++i)
-            rc = dispatch_model(mm, [&](auto M) -> int { return launch_sweep<decltype(M)>(plan, a, st); });
+            rc = dispatch_model(mm, [&](auto M) -> int { return launch_sweep<decltype(M)>(plan, a, sh, st); });
         (void)hipEventRecord(e1, st);
         hipError_t e = hipEventSynchronize(e1);
         float ms = 0.f;
@@ -481,13 +537,13 @@ int obe_utility_argmax(const double* d_yvar, int32_t n_channels, int64_t n_setti
     if (!d_yvar || !d_noise_var || !d_utility || n_settings <= 0 || n_channels < 1 || n_channels > OBE_MAX_CHANNELS)
         return bad_arg("obe_utility_argmax: bad pointer/size");
     SweepWs w;
-    if (int rc = carve_sweep_ws(d_ws, ws_bytes, 0, w)) return rc;
+    if (int rc = carve_sweep_ws(d_ws, ws_bytes, 0, 0, w)) return rc;
     hipStream_t st = as_stream(stream);
     UtilArgs ua{d_noise_var, noise_ld, d_cost, cost_scalar};
     const int nb = stream_blocks(n_settings, kBlock);
     utility_kernel<<<nb, kBlock, 0, st>>>(d_yvar, n_channels, n_settings, ua, d_utility, w.bv, w.bi);
     OBE_CHECK_LAUNCH("utility_kernel");
-    argmax_fold<<<1, kBlock, 0, st>>>(w.bv, w.bi, nb, w.out_v, w.out_i);
+    argmax_fold<<<1, kBlock, 0, st>>>(w.bv, w.bi, nb, nullptr, w.out_v, w.out_i);
     OBE_CHECK_LAUNCH("argmax_fold");
     return read_best(w, h_best, h_best_idx, st);
 }
@@ -496,12 +552,12 @@ int obe_argmax(const double* d_v, int64_t n, double* h_best, int64_t* h_best_idx
                void* stream) {
     if (!d_v || n <= 0) return bad_arg("obe_argmax: bad pointer/size");
     SweepWs w;
-    if (int rc = carve_sweep_ws(d_ws, ws_bytes, 0, w)) return rc;
+    if (int rc = carve_sweep_ws(d_ws, ws_bytes, 0, 0, w)) return rc;
     hipStream_t st = as_stream(stream);
     const int nb = stream_blocks(n, kBlock);
     argmax_kernel<<<nb, kBlock, 0, st>>>(d_v, n, w.bv, w.bi);
     OBE_CHECK_LAUNCH("argmax_kernel");
-    argmax_fold<<<1, kBlock, 0, st>>>(w.bv, w.bi, nb, w.out_v, w.out_i);
+    argmax_fold<<<1, kBlock, 0, st>>>(w.bv, w.bi, nb, nullptr, w.out_v, w.out_i);
     OBE_CHECK_LAUNCH("argmax_fold");
     return read_best(w, h_best, h_best_idx, st);
 }

@@ -444,3 +444,51 @@ def test_device_rng_is_used_and_can_be_disabled(obe, unit):
     assert_allclose(out[True][1], out[False][1], rtol=1e-15)     # tail normals: last bit (libm log1p)
     assert out[True][2] == out[False][2]
     assert_array_equal(out[True][0], unit["rs_s0_resample_idx"])
+
+
+def test_adaptive_variance_shift(obe):
+    """The unshifted sweep (one instruction fewer per evaluation) is used only while the
+    reported cancellation factor kappa is small; both variants agree with the oracle and
+    a badly centred cloud forces the shifted one."""
+    g = np.random.default_rng(31)
+    n, ns = 6000, 300
+    sv = (np.linspace(1.5, 4.5, ns),)
+    w = g.exponential(1.0, n)
+    w /= w.sum()
+    # broad prior: the spread dominates the mean (kappa small)
+    broad = np.array([g.uniform(2, 4, n), g.uniform(-2000, -400, n), g.normal(50000, 1000, n)])
+    # tight posterior: amplitude and centre almost known, tiny background spread (kappa huge)
+    tight = np.array([g.normal(3.0, 1e-4, n), g.normal(-1000, 0.01, n), g.normal(50000, 0.001, n)])
+    for cloud, expect_unshifted in ((broad, True), (tight, False)):
+        ref = oracle.yvar_full_sweep(omodels.lorentzian, oracle.flatten_settings(sv), cloud, w, (0.1,))
+        res = {}
+        for mode in ("always", "never", "auto"):
+            o = obe.OptBayesExpt(obe.models.lorentzian(), sv, cloud.copy(), (0.1,),
+                                 utility_method="variance_full", auto_resample=False)
+            o.tuning_parameters["sweep_shift"] = mode
+            o.particle_weights = w
+            first = o.yvar_from_parameter_draws()
+            assert o.last_sweep["shifted"] == (mode != "never")     # auto starts shifted
+            second = o.yvar_from_parameter_draws()
+            res[mode] = (first, second, dict(o.last_sweep))
+        kappa = res["always"][2]["kappa"]
+        assert (kappa < obe.OptBayesExpt.KAPPA_ENTER) == expect_unshifted
+        assert res["auto"][2]["shifted"] == (not expect_unshifted)
+        for mode in ("always", "auto"):
+            for got in res[mode][:2]:
+                assert_allclose(got, ref, rtol=RTOL, atol=1e-13 * ref.max())
+        if expect_unshifted:
+            assert_allclose(res["never"][1], ref, rtol=RTOL, atol=1e-13 * ref.max())
+        else:   # what the guard protects against: unshifted accumulation on this cloud is off
+            assert np.abs(res["never"][1] / ref - 1).max() > 1e-9
+    # the guard also catches a cloud that changes under an unshifted object
+    o = obe.OptBayesExpt(obe.models.lorentzian(), sv, broad.copy(), (0.1,), utility_method="variance_full",
+                         auto_resample=False)
+    o.particle_weights = w
+    o.yvar_from_parameter_draws()
+    assert o._sweep_unshifted
+    o.set_pdf(tight.copy(), weights=w)
+    got = o.yvar_from_parameter_draws()                  # starts unshifted, sees kappa, redoes shifted
+    assert o.last_sweep["shifted"] and not o._sweep_unshifted
+    ref = oracle.yvar_full_sweep(omodels.lorentzian, oracle.flatten_settings(sv), tight, w, (0.1,))
+    assert_allclose(got, ref, rtol=RTOL, atol=1e-13 * ref.max())
