@@ -90,7 +90,7 @@ def test_strict_cdf_is_bitwise_numpy_cumsum(obe, hip):
         w /= w.sum()
         ref = oracle.weight_cdf(w)
         wd = torch.from_numpy(w).cuda()
-        ws = torch.empty(hip.workspace_bytes(n, 1, 1, 1) // 8 + 1, dtype=torch.float64, device="cuda")
+        ws = torch.zeros(hip.workspace_bytes(n, 1, 1, 1) // 8 + 1, dtype=torch.float64, device="cuda")
         out = {}
         for strict in (1, 0):
             cdf = torch.empty(n, dtype=torch.float64, device="cuda")
@@ -317,7 +317,7 @@ def test_argmax_semantics(obe, hip):
     from optbayesexpt_amd import _lib
     from optbayesexpt_amd.particlepdf import _ptr
     g = np.random.default_rng(1)
-    ws = torch.empty(hip.workspace_bytes(1, 1 << 20, 1, 1) // 8 + 1, dtype=torch.float64, device="cuda")
+    ws = torch.zeros(hip.workspace_bytes(1, 1 << 20, 1, 1) // 8 + 1, dtype=torch.float64, device="cuda")
     cases = []
     for n in (1, 2, 255, 256, 257, 70001):
         v = g.normal(size=n)
@@ -492,3 +492,31 @@ def test_adaptive_variance_shift(obe):
     assert o.last_sweep["shifted"] and not o._sweep_unshifted
     ref = oracle.yvar_full_sweep(omodels.lorentzian, oracle.flatten_settings(sv), tight, w, (0.1,))
     assert_allclose(got, ref, rtol=RTOL, atol=1e-13 * ref.max())
+
+
+def test_update_back_to_back_stress(obe, hip):
+    """2000 back-to-back Bayes updates whose totals differ by orders of magnitude: the
+    partial sums of one launch must never leak into the next (workspace reuse, kernel-boundary
+    visibility across XCDs).  Checked through an independent reduction."""
+    import torch
+    from optbayesexpt_amd import _lib
+    from optbayesexpt_amd.particlepdf import _ptr
+    g = np.random.default_rng(17)
+    n = 524288 + 77
+    ws = torch.zeros(hip.workspace_bytes(n, 1, 1, 1) // 8 + 1, dtype=torch.float64, device="cuda")
+    w = torch.empty(n, dtype=torch.float64, device="cuda")
+    liks = [torch.from_numpy(g.exponential(1.0, n) * 10.0 ** g.integers(-30, 30)).cuda() for _ in range(16)]
+    w0 = torch.from_numpy(g.exponential(1.0, n)).cuda()
+    out, sums = np.zeros(4), np.zeros(4)
+    bad = 0
+    for it in range(2000):
+        w.copy_(w0)
+        lik = liks[it % 16]
+        hip.call("obe_bayes_update_lik", _ptr(lik), n, _ptr(w), _ptr(ws), ws.numel() * 8,
+                 _lib.host_ptr(out), None)
+        if it % 10 == 0:                      # independent check through separate launches
+            hip.call("obe_weight_sums", _ptr(w), n, _ptr(ws), ws.numel() * 8, _lib.host_ptr(sums), None)
+            expect_total = float(torch.sum(w0 * lik))
+            bad += not (abs(sums[1] - 1.0) < 1e-12 and abs(out[0] / expect_total - 1.0) < 1e-12
+                        and abs(out[1] / sums[0] - 1.0) < 1e-12)
+    assert bad == 0
