@@ -89,6 +89,38 @@ __device__ __forceinline__ double block_sum_array(const double* a, int n, double
     return block_sum_all(v, red);
 }
 
+// Exclusive scan, in place, of a short array (block sums of a reduce-then-scan) by ONE
+// workgroup: each thread owns a contiguous segment, the segment totals are scanned through
+// LDS in thread order.  Fixed association => deterministic.  Returns the grand total in
+// every thread.  `lds` = blockDim.x elements of T.
+template <class T>
+__device__ __forceinline__ T block_exclusive_scan_inplace(T* __restrict__ data, int64_t n, T* lds) {
+    const int t = threadIdx.x, nt = blockDim.x;
+    const int64_t per = (n + nt - 1) / nt;
+    const int64_t b = (int64_t)t * per, e = b + per < n ? b + per : n;
+    T sum = T(0);
+    for (int64_t i = b; i < e; ++i) sum = sum + data[i];
+    lds[t] = sum;
+    __syncthreads();
+    if (t == 0) {                       // <= 256 serial adds in LDS: ~1 us
+        T run = T(0);
+        for (int k = 0; k < nt; ++k) {
+            const T s = lds[k];
+            lds[k] = run;
+            run = run + s;
+        }
+        lds[nt] = run;
+    }
+    __syncthreads();
+    T run = lds[t];
+    for (int64_t i = b; i < e; ++i) {
+        const T s = data[i];
+        data[i] = run;
+        run = run + s;
+    }
+    return lds[nt];
+}
+
 // Strided view of one particle's parameters: th(i) = particles[i*ld + p].
 struct ParamRef {
     const double* base;

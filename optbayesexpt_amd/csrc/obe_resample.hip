@@ -63,17 +63,13 @@ __global__ __launch_bounds__(kBlock) void scan_block_sums(const double* __restri
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
-// Exclusive scan of the block sums, serial in block order (nb is N/2048: 512 at 1M
-// particles), written in place; scalars[0] = total = offset[last] + sum[last].
-__global__ void scan_offsets(double* __restrict__ block_sums, int64_t nb, double* __restrict__ scalars) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double run = 0.0;
-    for (int64_t b = 0; b < nb; ++b) {
-        const double s = block_sums[b];
-        block_sums[b] = run;
-        run = run + s;
-    }
-    scalars[0] = run;
+// Exclusive scan of the block sums (nb = N/2048: 512 at 1M particles) by one workgroup,
+// written in place; scalars[0] = total = offset[last] + sum[last].
+__global__ __launch_bounds__(kBlock) void scan_offsets(double* __restrict__ block_sums, int64_t nb,
+                                                       double* __restrict__ scalars) {
+    __shared__ double lds[kBlock + 1];
+    const double total = block_exclusive_scan_inplace<double>(block_sums, nb, lds);
+    if (threadIdx.x == 0) scalars[0] = total;
 }
 
 __global__ __launch_bounds__(kBlock) void scan_write_cdf(const double* __restrict__ w, int64_t n,
@@ -206,7 +202,7 @@ int obe_weight_cdf(const double* d_weights, int64_t n_particles, int32_t strict_
     } else {
         scan_block_sums<<<(unsigned)nb, kBlock, 0, st>>>(d_weights, n_particles, block_sums);
         OBE_CHECK_LAUNCH("scan_block_sums");
-        scan_offsets<<<1, kWave, 0, st>>>(block_sums, nb, scalars);
+        scan_offsets<<<1, kBlock, 0, st>>>(block_sums, nb, scalars);
         OBE_CHECK_LAUNCH("scan_offsets");
         scan_write_cdf<<<(unsigned)nb, kBlock, 0, st>>>(d_weights, n_particles, block_sums, scalars, d_cdf);
         OBE_CHECK_LAUNCH("scan_write_cdf");

@@ -224,14 +224,9 @@ __global__ __launch_bounds__(kBlock) void flag_block_sums(const uint32_t* __rest
     if (threadIdx.x == 0) sums[blockIdx.x] = total;
 }
 
-__global__ void flag_scan_offsets(uint32_t* __restrict__ sums, int64_t nb) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    uint32_t run = 0;
-    for (int64_t b = 0; b < nb; ++b) {
-        const uint32_t s = sums[b];
-        sums[b] = run;
-        run += s;
-    }
+__global__ __launch_bounds__(kBlock) void flag_scan_offsets(uint32_t* __restrict__ sums, int64_t nb) {
+    __shared__ uint32_t lds[kBlock + 1];
+    block_exclusive_scan_inplace<uint32_t>(sums, nb, lds);
 }
 
 // out[rank] = val[i] for the first n starts; result[0] = raw consumed by them (relative to `first`),
@@ -318,7 +313,7 @@ int obe_ziggurat_normal(const uint64_t* d_raw, int64_t n_raw, int64_t offset, co
     OBE_CHECK_LAUNCH("zig_starts_kernel");
     flag_block_sums<<<(unsigned)nb, kBlock, 0, st>>>(flag, n_raw, sums);
     OBE_CHECK_LAUNCH("flag_block_sums");
-    flag_scan_offsets<<<1, kWave, 0, st>>>(sums, nb);
+    flag_scan_offsets<<<1, kBlock, 0, st>>>(sums, nb);
     OBE_CHECK_LAUNCH("flag_scan_offsets");
     zig_compact_kernel<<<(unsigned)nb, kBlock, 0, st>>>(flag, sums, val, len, n_raw, offset, n, d_out, result);
     OBE_CHECK_LAUNCH("zig_compact_kernel");

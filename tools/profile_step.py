@@ -6,14 +6,22 @@ import torch
 import bench
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
+world = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 settings, prior, cons, true, sigma = bench.make_workload(cfg)
-obe = bench.build_obe(cfg, None, settings, prior.copy(), cons)
+shard = None
+if world > 1:      # rank 0 of `world`, collectives stubbed: what one rank of an N-GPU run computes
+    from optbayesexpt_amd.dist import SettingsShard
+    class _Solo(SettingsShard):
+        def combine_best(self, value, global_index, device="cpu"):
+            return value, global_index
+    shard = _Solo(rank=0, world_size=world)
+obe = bench.build_obe(cfg, shard, settings, prior.copy(), cons)
 obe.rng = np.random.default_rng(1234)
 sim = np.random.default_rng(4321)
 T = {}
 def tick(name, t0):
     torch.cuda.synchronize(); T.setdefault(name, []).append(time.perf_counter() - t0)
-for cyc in range(12):
+for cyc in range(24):
     t0 = time.perf_counter(); x = obe.opt_setting(); tick("opt_setting", t0)
     y = float(obe.model_function(x, true, cons)) + sigma * sim.standard_normal()
     rec = (x, y, sigma) if cfg != "c5" else (x, y)
