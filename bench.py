@@ -124,7 +124,20 @@ def main():
     shard = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL prints a version banner on stdout when the communicator comes up; keep
+        # stdout for the one JSON line by pointing fd 1 at stderr until it is up
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            warm = torch.zeros(4, dtype=torch.float64, device="cuda")
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
         from optbayesexpt_amd import SettingsShard
         shard = SettingsShard()
 

@@ -198,6 +198,11 @@ int obe_power_normalize(const double* d_u, int64_t n, double exponent, double* d
  * (np.argmax, obe_base.py:748): h_best[0] = value, h_best_idx[0] = index relative to
  * s_begin (sync) when h_best != NULL.  d_yvar (C, n_settings) and d_utility
  * (n_settings) stay on the device. */
+/* After obe_sweep_utility / obe_utility_argmax / obe_argmax the workspace holds the result
+ * as one 32-byte record at d_ws + OBE_WS_RESULT_OFFSET doubles:
+ * {best value (f64), best local index (i64 bits), kappa (f64), 0} — what a sharded caller
+ * all-gathers across ranks (RCCL) without copying it to the host first. */
+#define OBE_WS_RESULT_OFFSET 2
 int obe_sweep_utility(const obe_model* m,
                       const double* d_settings, int64_t ld_s, int64_t n_settings,
                       const double* d_particles, int64_t ld_p, int64_t n_particles,

@@ -318,11 +318,20 @@ __global__ __launch_bounds__(kBlock) void argmax_fold(const double* __restrict__
         if (better(cand, best)) best = cand;
     }
     block_argmax(best, out_v, out_i);   // gridDim.x == 1 -> writes element 0
-    if (bk && threadIdx.x == 0) {       // worst cancellation factor (nb <= 2048: serial fold is fine)
-        double k = 0.0;
-        for (int b = 0; b < nb; ++b)
-            if (!(bk[b] <= k)) k = bk[b];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double k = 0.0;                 // worst cancellation factor (nb <= 2048: serial fold is fine)
+        if (bk)
+            for (int b = 0; b < nb; ++b)
+                if (!(bk[b] <= k)) k = bk[b];
         out_v[1] = k;
+        // the same result as one contiguous 32-byte record {value, index bits, kappa, 0} at
+        // OBE_WS_RESULT_OFFSET, so that a sharded caller can all-gather it straight from
+        // device memory without a host round trip
+        out_v[2] = out_v[0];
+        reinterpret_cast<int64_t*>(out_v)[3] = out_i[0];
+        out_v[4] = k;
+        out_v[5] = 0.0;
     }
 }
 

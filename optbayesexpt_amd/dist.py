@@ -5,8 +5,8 @@ rank r sweeps the contiguous slice ``[r*N_s/G, (r+1)*N_s/G)`` of the flattened s
 and the cloud (34 MB at 1M particles) is replicated: each rank applies the same Bayes
 update and the same seeded resample, so replicas stay bit-identical and no particle
 data ever crosses xGMI.  The only data-path collective is the arg-max combine of
-``opt_setting``: one all-gather of 16 bytes per rank ``(best value, global index)``
-over RCCL (``torch.distributed`` backend "nccl"), followed by a local first-max —
+``opt_setting``: one all-gather of a 32-byte record per rank ``(best value, local index,
+kappa, 0)`` straight from device memory over RCCL (``torch.distributed`` backend "nccl"), followed by a local first-max —
 the message is latency-bound (tens of microseconds), irrelevant next to a
 multi-millisecond sweep.  With backend "gloo" the same code runs on CPU tensors, which
 is how the N>1 logic is tested without GPUs.
@@ -61,22 +61,37 @@ class SettingsShard:
         backend = dist.get_backend(self.group)
         return torch.device(device) if backend == "nccl" else torch.device("cpu")
 
-    def combine_best(self, value, global_index, device="cpu"):
-        """Global first-maximum from each rank's local (value, global index)."""
-        if self.world_size == 1:
-            return value, global_index
-        dev = self._comm_device(device)
-        # 16 B per rank: the index travels as the bit pattern of an int64 inside a f64 slot
-        mine = torch.tensor([value, 0.0], dtype=torch.float64)
-        mine[1:].view(torch.int64)[0] = int(global_index)
-        mine = mine.to(dev)
-        gathered = torch.empty(2 * self.world_size, dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(gathered, mine, group=self.group)
-        g = gathered.cpu().reshape(self.world_size, 2)
+    def combine_records(self, record, n_settings):
+        """Global first-maximum from each rank's 32-byte device record {value, local index
+        (int64 bits), kappa, 0} (include/obe_hip.h: OBE_WS_RESULT_OFFSET): one all-gather
+        straight from device memory, one copy to the host.  Returns (value, global index,
+        this rank's kappa)."""
+        w = self.world_size
+        g = self._gather_records(record)
         vals = g[:, 0].numpy()
-        idxs = g[:, 1].contiguous().view(torch.int64).numpy()
-        k = first_max(vals, idxs)
-        return float(vals[k]), int(idxs[k])
+        local = g[:, 1].contiguous().view(torch.int64).numpy()
+        starts = np.array([shard_bounds(n_settings, r, w)[0] for r in range(w)], dtype=np.int64)
+        gidx = local + starts
+        k = first_max(vals, gidx)
+        return float(vals[k]), int(gidx[k]), float(g[self.rank, 2])
+
+    def _gather_records(self, record):
+        """(world, 4) host tensor of every rank's record."""
+        w = self.world_size
+        if w == 1:
+            return record.cpu().reshape(1, 4)
+        gathered = torch.empty(4 * w, dtype=torch.float64, device=record.device)
+        dist.all_gather_into_tensor(gathered, record.contiguous(), group=self.group)
+        return gathered.cpu().reshape(w, 4)
+
+    @staticmethod
+    def make_record(value, local_index, kappa=0.0, device="cpu"):
+        """A record as the sweep kernels leave it in the workspace (for tests / host paths)."""
+        rec = torch.zeros(4, dtype=torch.float64)
+        rec[0] = value
+        rec[1:2].view(torch.int64)[0] = int(local_index)
+        rec[2] = kappa
+        return rec.to(device)
 
     def gather_rows(self, local, n_settings):
         """All ranks' (rows, n_local) slices assembled into a host (rows, n_settings) array."""

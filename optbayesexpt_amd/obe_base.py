@@ -398,14 +398,28 @@ class OptBayesExpt(ParticlePDF):
         kappa = np.zeros(1)
         s_ptr = _P(self._settings_dev.data_ptr() + 8 * self._s_begin)
 
+        sharded = want_best and self._shard is not None
+        result = {}
+
         def launch(shifted):
+            # sharded: no host read here — the 32-byte result record is all-gathered from
+            # device memory and read back once, together with the other ranks' records
             self._lib.call("obe_sweep_utility", self._model_struct, s_ptr, self._n_settings, n_local,
                            _ptr(p), p.shape[1], self.n_particles, _ptr(w),
                            None if idx is None else _ptr(idx), n_draws, _ptr(mom), 1 if shifted else 0,
                            _ptr(noise), noise_ld, None if cost_t is None else _ptr(cost_t), cost_s,
                            _ptr(self._yvar_dev), _ptr(self._utility_dev),
-                           _lib.host_ptr(best), _lib.host_ptr(best_idx), _lib.host_ptr(kappa),
+                           None if sharded else _lib.host_ptr(best),
+                           None if sharded else _lib.host_ptr(best_idx),
+                           None if sharded else _lib.host_ptr(kappa),
                            _ptr(self._ws), self._ws_bytes, self._stream())
+            if sharded:
+                off = _lib.OBE_WS_RESULT_OFFSET
+                val, gidx, k = self._shard.combine_records(self._ws[off:off + 4], self._n_settings)
+                result["best"] = (val, gidx)
+                kappa[0] = k
+            else:
+                result["best"] = (float(best[0]), int(best_idx[0]) + self._s_begin)
 
         # Shift policy (full sweep only).  The unshifted kernel saves one FP64 instruction
         # per evaluation (11 % of the sweep) but loses ~eps*kappa*sqrt(N) relative accuracy,
@@ -424,7 +438,7 @@ class OptBayesExpt(ParticlePDF):
                 launch(True)
         self.last_sweep = dict(shifted=shifted, kappa=float(kappa[0]))
         if want_best:
-            return float(best[0]), int(best_idx[0]) + self._s_begin
+            return result["best"]
         return None
 
     def yvar_from_parameter_draws(self):
@@ -477,9 +491,7 @@ class OptBayesExpt(ParticlePDF):
     def opt_setting(self):
         """The setting with maximum utility (obe_base.py:733-756)."""
         if self._utility_fusable():
-            val, bestindex = self._sweep_device(True)
-            if self._shard is not None:
-                val, bestindex = self._shard.combine_best(val, bestindex, self._device)
+            val, bestindex = self._sweep_device(True)      # global over all ranks when sharded
         else:
             utility = np.asarray(self.utility(), dtype=np.float64)       # user-overridden utility
             u = torch.from_numpy(np.ascontiguousarray(utility)).to(self._device)

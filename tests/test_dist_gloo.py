@@ -58,10 +58,11 @@ def _worker(rank, world, port, ret):
             local = u[b:e]
             if e > b:
                 k = int(np.argmax(local))
-                val, gidx = float(local[k]), b + k
+                rec = SettingsShard.make_record(float(local[k]), k, kappa=float(rank))
             else:
-                val, gidx = -np.inf, np.iinfo(np.int64).max
-            best_val, best_idx = shard.combine_best(val, gidx)
+                rec = SettingsShard.make_record(-np.inf, np.iinfo(np.int64).max // 2)
+            best_val, best_idx, kappa = shard.combine_records(rec, u.size)
+            assert kappa == float(rank) or e == b
             rows = np.zeros((2, max(e - b, 1)))
             rows[0, :e - b] = local
             rows[1, :e - b] = 2 * local

@@ -102,10 +102,19 @@ def test_sweep_invariances_at_c2_size(obe):
     assert_allclose(dup, base, rtol=RTOL)
     # (4) settings sharded 3 ways: the union of the slices is the full sweep, and the
     #     first-max over the rank winners is the global argmax
+    import torch
     from optbayesexpt_amd.dist import SettingsShard, first_max
+
+    class OneRank(SettingsShard):
+        """A shard without a process group: the gather sees only this rank's record."""
+        def _gather_records(self, record):
+            g = torch.full((self.world_size, 4), float("-inf"), dtype=torch.float64)
+            g[self.rank] = record.cpu()
+            return g
+
     vals, idxs, parts = [], [], []
     for r in range(3):
-        o, _ = sweep(prior.copy(), w, settings_shard=SettingsShard(rank=r, world_size=3))
+        o, _ = sweep(prior.copy(), w, settings_shard=OneRank(rank=r, world_size=3))
         v, i = o._sweep_device(True)
         vals.append(v)
         idxs.append(i)
@@ -146,3 +155,35 @@ def test_update_and_resample_at_one_million_particles(obe):
         for i in range(3):
             assert_allclose(a2.particles[i], b2.particles[i], rtol=RTOL)
         assert_array_equal(a2.particle_weights, b2.particle_weights)
+
+
+def test_sharded_path_through_rccl_world_of_one(obe):
+    """The sharded opt_setting code path with a real NCCL (= RCCL) process group of one rank:
+    the device-side all-gather of the result record, the row gather and the barrier run on
+    the GPU exactly as they do with N ranks (N > 1 is covered with gloo on the CPU)."""
+    import torch
+    import torch.distributed as dist
+    import bench as bench_mod
+    created = False
+    if not dist.is_initialized():
+        import os
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        settings, prior, cons, true, sigma = bench_mod.make_workload("c2")
+        sharded = bench_mod.build_obe("c2", obe.SettingsShard(), settings, prior.copy(), cons)
+        plain = bench_mod.build_obe("c2", None, settings, prior.copy(), cons)
+        for o in (sharded, plain):
+            o.rng = np.random.default_rng(3)
+        for _ in range(3):
+            xs, xp = sharded.opt_setting(), plain.opt_setting()
+            assert xs == xp and sharded.last_setting_index == plain.last_setting_index
+            for o in (sharded, plain):
+                o.pdf_update((xs, 49500.0, sigma))
+        assert_allclose(sharded.utility(), plain.utility(), rtol=1e-14)
+        dist.barrier()
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -7,8 +7,10 @@ import bench
 from optbayesexpt_amd.dist import SettingsShard
 
 class _Solo(SettingsShard):
-    def combine_best(self, value, global_index, device="cpu"):
-        return value, global_index
+    def _gather_records(self, record):          # no communication: only this rank's record counts
+        g = torch.full((self.world_size, 4), float("-inf"), dtype=torch.float64)
+        g[self.rank] = record.cpu()
+        return g
 
 settings, prior, cons, true, sigma = bench.make_workload("c3")
 obe = bench.build_obe("c3", _Solo(rank=0, world_size=8), settings, prior.copy(), cons)

@@ -12,8 +12,11 @@ shard = None
 if world > 1:      # rank 0 of `world`, collectives stubbed: what one rank of an N-GPU run computes
     from optbayesexpt_amd.dist import SettingsShard
     class _Solo(SettingsShard):
-        def combine_best(self, value, global_index, device="cpu"):
-            return value, global_index
+        def _gather_records(self, record):          # no communication: only this rank's record counts
+            import torch
+            g = torch.full((self.world_size, 4), float("-inf"), dtype=torch.float64)
+            g[self.rank] = record.cpu()
+            return g
     shard = _Solo(rank=0, world_size=world)
 obe = bench.build_obe(cfg, shard, settings, prior.copy(), cons)
 obe.rng = np.random.default_rng(1234)
