@@ -157,30 +157,55 @@ __global__ __launch_bounds__(kBlock) void zig_classify_kernel(const uint64_t* __
 }
 
 // flag[i] = 1 iff a normal really starts at raw position i (i >= first).
+// A workgroup stages the lengths of its 2048 positions plus a 32-position halo in LDS.
+// Position a is an *anchor* (certainly a start) iff no earlier position reaches past it:
+// max_{q<a} (q + len[q]) <= a, and only the 31 predecessors can (len <= kMaxLen).  Each
+// thread finds the nearest anchor at or before its first position and then follows the
+// chain i -> i + len[i] once across its 8 positions.
+constexpr int kStartItems = 8;
+constexpr int kStartTile = kBlock * kStartItems;
+constexpr int kHalo = 2 * kMaxLen;        // room to step back over a few non-anchors
+
 __global__ __launch_bounds__(kBlock) void zig_starts_kernel(const uint8_t* __restrict__ len, int64_t n_raw,
                                                             int64_t first, uint32_t* __restrict__ flag) {
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n_raw; i += (int64_t)gridDim.x * kBlock) {
-        if (i < first) { flag[i] = 0; continue; }
-        // anchor: the nearest a <= i that no earlier position can jump over
-        int64_t a = i;
-        for (;;) {
-            if (a == first) break;
-            bool skipped = false;
-            const int64_t lo = a - (kMaxLen - 1) > first ? a - (kMaxLen - 1) : first;
-            for (int64_t q = a - 1; q >= lo; --q) {
-                if (q + (int64_t)len[q] > a) { skipped = true; break; }
-            }
-            if (!skipped) break;
-            --a;
-        }
-        int64_t p = a;
-        bool ok = true;
-        while (p < i) {
-            const int l = len[p];
-            if (l == 0) { ok = false; break; }
-            p += l;
-        }
-        flag[i] = (ok && p == i) ? 1u : 0u;   // chains only break within kMaxLen of the buffer end
+    __shared__ uint8_t sl[kStartTile + kHalo];
+    const int64_t tile0 = (int64_t)blockIdx.x * kStartTile;
+    for (int k = threadIdx.x; k < kStartTile + kHalo; k += kBlock) {
+        const int64_t g = tile0 - kHalo + k;
+        sl[k] = (g >= first && g < n_raw) ? len[g] : (uint8_t)1;      // before `first`: harmless 1s
+    }
+    __syncthreads();
+    const int base = kHalo + threadIdx.x * kStartItems;              // LDS index of my first position
+    const int64_t i0 = tile0 + (int64_t)threadIdx.x * kStartItems;
+    // nearest anchor a <= base (LDS index); the global position `first` is always one
+    int a = base;
+    for (;;) {
+        const int64_t ga = tile0 - kHalo + a;
+        if (ga <= first || a <= kMaxLen) break;
+        bool skipped = false;
+        for (int k = 1; k < kMaxLen; ++k)
+            if (sl[a - k] > k) { skipped = true; break; }
+        if (!skipped) break;
+        --a;
+    }
+    int p = a;
+    {   // positions before `first` are not starts; begin the chain at `first` if it is inside my reach
+        const int64_t gp = tile0 - kHalo + p;
+        if (gp < first) p += (int)(first - gp);
+    }
+    uint32_t out[kStartItems];
+#pragma unroll
+    for (int k = 0; k < kStartItems; ++k) out[k] = 0u;
+    while (p < base + kStartItems) {
+        if (p >= base) out[p - base] = 1u;
+        const int l = sl[p];
+        if (l == 0) break;                 // unclassifiable (only within kMaxLen of the buffer end)
+        p += l;
+    }
+#pragma unroll
+    for (int k = 0; k < kStartItems; ++k) {
+        const int64_t i = i0 + k;
+        if (i < n_raw) flag[i] = (i >= first) ? out[k] : 0u;
     }
 }
 
@@ -309,7 +334,7 @@ int obe_ziggurat_normal(const uint64_t* d_raw, int64_t n_raw, int64_t offset, co
     OBE_HIP_TRY(hipMemsetAsync(base, 0, 64, st));
     zig_classify_kernel<<<stream_blocks(n_raw, kBlock), kBlock, 0, st>>>(d_raw, n_raw, t, val, len);
     OBE_CHECK_LAUNCH("zig_classify_kernel");
-    zig_starts_kernel<<<stream_blocks(n_raw, kBlock), kBlock, 0, st>>>(len, n_raw, offset, flag);
+    zig_starts_kernel<<<(unsigned)((n_raw + kStartTile - 1) / kStartTile), kBlock, 0, st>>>(len, n_raw, offset, flag);
     OBE_CHECK_LAUNCH("zig_starts_kernel");
     flag_block_sums<<<(unsigned)nb, kBlock, 0, st>>>(flag, n_raw, sums);
     OBE_CHECK_LAUNCH("flag_block_sums");

@@ -318,12 +318,19 @@ __global__ __launch_bounds__(kBlock) void argmax_fold(const double* __restrict__
         if (better(cand, best)) best = cand;
     }
     block_argmax(best, out_v, out_i);   // gridDim.x == 1 -> writes element 0
+    __shared__ double kred[kBlock];
+    double kmax = 0.0;                  // worst cancellation factor; NaN counts as "too large"
+    if (bk)
+        for (int b = threadIdx.x; b < nb; b += kBlock)
+            if (!(bk[b] <= kmax)) kmax = bk[b];
+    kred[threadIdx.x] = kmax;
     __syncthreads();
+    for (int o = kBlock / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o && !(kred[threadIdx.x + o] <= kred[threadIdx.x])) kred[threadIdx.x] = kred[threadIdx.x + o];
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
-        double k = 0.0;                 // worst cancellation factor (nb <= 2048: serial fold is fine)
-        if (bk)
-            for (int b = 0; b < nb; ++b)
-                if (!(bk[b] <= k)) k = bk[b];
+        const double k = kred[0];
         out_v[1] = k;
         // the same result as one contiguous 32-byte record {value, index bits, kappa, 0} at
         // OBE_WS_RESULT_OFFSET, so that a sharded caller can all-gather it straight from
