@@ -228,6 +228,27 @@ int obe_utility_argmax(const double* d_yvar, int32_t n_channels, int64_t n_setti
 int obe_argmax(const double* d_v, int64_t n, double* h_best, int64_t* h_best_idx,
                void* d_ws, int64_t ws_bytes, void* stream);
 
+/* ---- the non-default utilities on the explicit y-space ----
+ * d_yspace (N_d, C, N_s) row-major = utility_y_space of the reference (obe_base.py:293-295). */
+/* y[d][c][s] = model(setting s; particle d_draw_idx[d]) — the loop of obe_base.py:483-484
+ * (eval_over_all_settings per drawn parameter set), exact NumPy operation order. */
+int obe_eval_draws(const obe_model* m, const double* d_settings, int64_t ld_s, int64_t n_settings,
+                   const double* d_particles, int64_t ld_p, int64_t n_particles,
+                   const int64_t* d_draw_idx, int64_t n_draws, double* d_yspace, void* stream);
+/* y[d][c][:] += d_noise[d][c]  (utility_full_kld, obe_base.py:714-715). */
+int obe_yspace_add_noise(double* d_yspace, int64_t n_draws, int32_t n_channels, int64_t n_settings,
+                         const double* d_noise, void* stream);
+/* yvar_max_min (obe_base.py:520-535): (max - min)^2 over the draws, per column (C*N_s columns). */
+int obe_yspace_maxmin(const double* d_yspace, int64_t n_draws, int64_t n_columns, double* d_span2, void* stream);
+/* scipy.stats.differential_entropy(axis=0, method='auto') per column (obe_base.py:516, 717-718);
+ * as_variance != 0 returns exp(2H)/(2 pi e) (yvar_from_entropy, obe_base.py:517).
+ * d_scratch: n_draws * n_columns doubles.  n_draws <= 2048. */
+int obe_yspace_entropy(const double* d_yspace, int64_t n_draws, int64_t n_columns, int32_t as_variance,
+                       double* d_scratch, double* d_out, void* stream);
+/* utility_full_kld (obe_base.py:720): exp(H_y[c,s] - H_noise[c]) - 1. */
+int obe_kld_utility(const double* d_entropy_y, int32_t n_channels, int64_t n_settings,
+                    const double* d_entropy_noise, double* d_utility, void* stream);
+
 /* ---- device-side continuation of the caller's numpy PCG64 stream ----
  * Replaces the host calls inside resample(): rng.random(n) (the uniforms Generator.choice
  * draws, particlepdf.py:330) and rng.standard_normal((n, d)) (inside multivariate_normal,

@@ -77,6 +77,12 @@ _SIGNATURES = {
     "obe_yspace_variance": (c_int, [_P, c_int64, c_int32, c_int64, _P, _P]),
     "obe_utility_argmax": (c_int, [_P, c_int32, c_int64, _P, c_int64, _P, c_double, _P, _P, _P, _P, c_int64, _P]),
     "obe_argmax": (c_int, [_P, c_int64, _P, _P, _P, c_int64, _P]),
+    "obe_eval_draws": (c_int, [ctypes.POINTER(ObeModelStruct), _P, c_int64, c_int64, _P, c_int64, c_int64, _P,
+                               c_int64, _P, _P]),
+    "obe_yspace_add_noise": (c_int, [_P, c_int64, c_int32, c_int64, _P, _P]),
+    "obe_yspace_maxmin": (c_int, [_P, c_int64, c_int64, _P, _P]),
+    "obe_yspace_entropy": (c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P]),
+    "obe_kld_utility": (c_int, [_P, c_int32, c_int64, _P, _P, _P]),
     "obe_pcg64_raw": (c_int, [_P, c_int64, _P, _P]),
     "obe_pcg64_uniform": (c_int, [_P, c_int64, _P, _P]),
     "obe_ziggurat_workspace_bytes": (c_int64, [c_int64]),

@@ -154,10 +154,12 @@ class OptBayesExpt(ParticlePDF):
             if self._device_model is None:
                 raise ValueError("utility_method='variance_full' needs a DeviceModel")
             _utility = self.utility_variance
-        elif utility_method in ("pseudo_utility", "max_min", "full_kld_utility"):
-            raise NotImplementedError(
-                f"utility_method {utility_method!r} is outside the accelerated hot path "
-                "(SURVEY.md §8f); use 'variance_approx' or 'variance_full'")
+        elif utility_method == "pseudo_utility":
+            _utility = self.utility_pseudo
+        elif utility_method == "max_min":
+            _utility = self.utility_max_min
+        elif utility_method == "full_kld_utility":
+            _utility = self.utility_full_kld
         else:
             raise SyntaxError(f"Unknown utility method, {utility_method}. "
                               f"Valid utility methods are: {UTILITY_METHODS}")
@@ -199,7 +201,7 @@ class OptBayesExpt(ParticlePDF):
             self.N_DRAWS = DEFAULT_N_DRAWS
         elif n_draws:
             self.N_DRAWS = n_draws
-        if self._device_model is None:
+        if self._device_model is None:     # device models keep the y-space on the GPU
             self.utility_y_space = np.zeros((self.N_DRAWS, self.n_channels, self._n_settings))
         return self.N_DRAWS
 
@@ -466,19 +468,88 @@ class OptBayesExpt(ParticlePDF):
         return self._utility_from_host_yvar(var_p)
 
     def _utility_from_host_yvar(self, var_p):
-        """sum_c var_p / var_n / cost on the device from a host (C, N_s) variance."""
-        yv = torch.from_numpy(np.ascontiguousarray(var_p, dtype=np.float64)).to(self._device)
+        """sum_c var_p / var_n / cost on the device from a (C, N_s) variance (host array or
+        device tensor)."""
+        if isinstance(var_p, torch.Tensor):
+            yv = var_p
+        else:
+            yv = torch.from_numpy(np.array(np.broadcast_to(np.asarray(var_p, dtype=np.float64),
+                                                           (self.n_channels, self._n_settings)))).to(self._device)
+        if self._shard is not None:
+            raise NotImplementedError("this utility method with a sharded settings axis (SURVEY.md §8e, next)")
         noise, noise_ld = self._noise_var_device()
-        if noise_ld:
-            raise NotImplementedError("per-setting noise model with a host-computed variance")
-        cost = self.cost_estimate()
-        cost_t = None if np.ndim(cost) == 0 else \
-            torch.from_numpy(np.array(np.broadcast_to(np.asarray(cost, np.float64),
-                                                      (self._n_settings,)))).to(self._device)
+        cost_t, cost_s = self._cost_device()
         util = torch.empty(self._n_settings, dtype=torch.float64, device=self._device)
-        self._lib.call("obe_utility_argmax", _ptr(yv), self.n_channels, self._n_settings, _ptr(noise), 0,
-                       None if cost_t is None else _ptr(cost_t), float(cost) if cost_t is None else 1.0,
+        self._lib.call("obe_utility_argmax", _ptr(yv), self.n_channels, self._n_settings, _ptr(noise), noise_ld,
+                       None if cost_t is None else _ptr(cost_t), cost_s,
                        _ptr(util), None, None, _ptr(self._ws), self._ws_bytes, self._stream())
+        return util.cpu().numpy()
+
+    # ---- the y-space utilities (obe_base.py:491-535, 602-626, 657-720; SURVEY.md §8f-3) ----
+    def _yspace_device(self):
+        """utility_y_space on the device, (N_DRAWS, C, N_s): the model over all settings for
+        N_DRAWS fresh weighted draws (consumes N_DRAWS uniforms of self.rng)."""
+        nd, c, ns = self.N_DRAWS, self.n_channels, self._n_settings
+        if self._device_model is not None and not _overridden(self, "eval_over_all_settings", OptBayesExpt):
+            idx = self._draw_indices(nd)
+            p = self._particles.tensor()
+            ysp = torch.empty((nd, c, ns), dtype=torch.float64, device=self._device)
+            self._lib.call("obe_eval_draws", self._model_struct, _ptr(self._settings_dev), ns, ns, _ptr(p),
+                           p.shape[1], self.n_particles, _ptr(idx), nd, _ptr(ysp), self._stream())
+            return ysp
+        paramsets = self.randdraw(nd).T              # host-callable model: the user's function fills it
+        for i, oneparamset in enumerate(paramsets):
+            self.utility_y_space[i] = self.eval_over_all_settings(oneparamset)
+        return torch.from_numpy(np.ascontiguousarray(self.utility_y_space)).to(self._device)
+
+    def _column_entropy(self, ysp, as_variance):
+        """scipy.stats.differential_entropy(ysp, axis=0) per column, on the device."""
+        nd = ysp.shape[0]
+        cols = ysp[0].numel()
+        m = int(np.floor(np.sqrt(nd) + 0.5))
+        if not 2 <= 2 * m < nd:
+            raise ValueError(f"Window length ({m}) must be positive and less "
+                             f"than half the sample size ({nd}).")
+        out = torch.empty(ysp.shape[1:], dtype=torch.float64, device=self._device)
+        scratch = torch.empty(nd * cols, dtype=torch.float64, device=self._device)
+        self._lib.call("obe_yspace_entropy", _ptr(ysp), nd, cols, 1 if as_variance else 0, _ptr(scratch),
+                       _ptr(out), self._stream())
+        return out
+
+    def yvar_from_entropy(self):
+        """Variance of the normal distribution with the model outputs' differential entropy,
+        per setting (obe_base.py:491-518)."""
+        return self._column_entropy(self._yspace_device(), True).cpu().numpy()
+
+    def yvar_max_min(self):
+        """(max - min)^2 of the model outputs over the draws (obe_base.py:520-535)."""
+        ysp = self._yspace_device()
+        out = torch.empty(ysp.shape[1:], dtype=torch.float64, device=self._device)
+        self._lib.call("obe_yspace_maxmin", _ptr(ysp), ysp.shape[0], ysp[0].numel(), _ptr(out), self._stream())
+        return out.cpu().numpy()
+
+    def utility_max_min(self):
+        """obe_base.py:602-626."""
+        return self._utility_from_host_yvar(self.yvar_max_min())
+
+    def utility_pseudo(self):
+        """obe_base.py:657-686."""
+        return self._utility_from_host_yvar(self.yvar_from_entropy())
+
+    def utility_full_kld(self):
+        """exp(H(y + noise) - H(noise)) - 1, shape (C, N_s) (obe_base.py:688-720).  The
+        N_DRAWS*C standard normals come from the module-level ``rng`` as in the reference."""
+        nd, c = self.N_DRAWS, self.n_channels
+        ysp = self._yspace_device()
+        nva = rng.normal(0, 1.0, nd * c)
+        nvb = nva.reshape((c, nd))
+        noisevalues = np.ascontiguousarray((nvb * np.sqrt(self.yvar_noise_model())).T)     # (N_d, C) glue
+        noise_dev = torch.from_numpy(noisevalues).to(self._device)
+        self._lib.call("obe_yspace_add_noise", _ptr(ysp), nd, c, self._n_settings, _ptr(noise_dev), self._stream())
+        h_y = self._column_entropy(ysp, False)                          # (C, N_s)
+        h_n = self._column_entropy(noise_dev.reshape(nd, c, 1), False)  # (C, 1)
+        util = torch.empty((c, self._n_settings), dtype=torch.float64, device=self._device)
+        self._lib.call("obe_kld_utility", _ptr(h_y), c, self._n_settings, _ptr(h_n), _ptr(util), self._stream())
         return util.cpu().numpy()
 
     def _gather_settings(self, local):
@@ -493,8 +564,9 @@ class OptBayesExpt(ParticlePDF):
         if self._utility_fusable():
             val, bestindex = self._sweep_device(True)      # global over all ranks when sharded
         else:
-            utility = np.asarray(self.utility(), dtype=np.float64)       # user-overridden utility
-            u = torch.from_numpy(np.ascontiguousarray(utility)).to(self._device)
+            utility = np.asarray(self.utility(), dtype=np.float64)       # overridden / y-space utility
+            self.last_utility = utility
+            u = torch.from_numpy(np.ascontiguousarray(utility).reshape(-1)).to(self._device)
             best = np.zeros(1)
             best_idx = np.zeros(1, dtype=np.int64)
             self._lib.call("obe_argmax", _ptr(u), u.numel(), _lib.host_ptr(best), _lib.host_ptr(best_idx),
@@ -514,7 +586,7 @@ class OptBayesExpt(ParticlePDF):
             self._sweep_device(False)
             u = self._utility_dev
         else:
-            u = torch.from_numpy(np.ascontiguousarray(self.utility(), dtype=np.float64)).to(self._device)
+            u = torch.from_numpy(np.ascontiguousarray(self.utility(), dtype=np.float64).reshape(-1)).to(self._device)
         n = u.numel()
         prob = torch.empty(n, dtype=torch.float64, device=self._device)
         cdf = torch.empty(n, dtype=torch.float64, device=self._device)

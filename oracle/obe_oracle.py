@@ -294,9 +294,11 @@ class OracleOptBayesExpt(OracleParticlePDF):
             n_channels = len(np.atleast_1d(probe))
         self.n_channels = n_channels
         self.default_noise_std = np.ones((self.n_channels, 1)) * default_noise_std
-        if utility_method not in ("variance_approx", "variance_full"):
+        if utility_method not in ("variance_approx", "variance_full", "max_min", "pseudo_utility",
+                                  "full_kld_utility"):
             raise SyntaxError(f"Unknown utility method, {utility_method}.")
         self.utility_method = utility_method
+        self.noise_rng = np.random.default_rng()     # the reference's module-level obe_base.rng
         if selection_method not in ("optimal", "good"):
             raise SyntaxError(f"Unknown selection_method, {selection_method}.")
         self.get_setting = self.opt_setting if selection_method == "optimal" else self.good_setting
@@ -351,9 +353,33 @@ class OracleOptBayesExpt(OracleParticlePDF):
         draws = self.randdraw(self.N_DRAWS)
         return yvar_from_draws(self.model_function, self.allsettings, draws, self.cons)
 
+    def _y_space(self):
+        """obe_base.py:480-484 — the model over all settings for N_DRAWS drawn parameter sets."""
+        draws = self.randdraw(self.N_DRAWS)
+        ys = []
+        for i in range(self.N_DRAWS):
+            y = np.atleast_2d(np.asarray(self.model_function(self.allsettings, draws[:, i], self.cons),
+                                         dtype=np.float64))
+            ys.append(np.broadcast_to(y, (y.shape[0], self.allsettings.shape[1])))
+        return np.array(ys)
+
     def utility(self):
-        return utility_from_yvar(self.yvar_from_parameter_draws(),
-                                 self.yvar_noise_model(), self.cost_estimate())
+        from scipy.stats import differential_entropy as diffent        # as obe_base.py:7-10
+        if self.utility_method == "max_min":                           # obe_base.py:520-535, 621-626
+            ysp = self._y_space()
+            var_p = (np.max(ysp, axis=0) - np.min(ysp, axis=0)) ** 2
+        elif self.utility_method == "pseudo_utility":                  # obe_base.py:508-518, 681-686
+            var_p = np.exp(2 * diffent(self._y_space(), axis=0)) / (2 * np.pi * np.e)
+        elif self.utility_method == "full_kld_utility":                # obe_base.py:707-720
+            draws = self.randdraw(self.N_DRAWS)
+            nva = self.noise_rng.normal(0, 1.0, self.N_DRAWS * self.n_channels)
+            noise = (nva.reshape((self.n_channels, self.N_DRAWS)) * np.sqrt(self.yvar_noise_model())).T
+            ysp = np.array([np.atleast_2d(self.model_function(self.allsettings, draws[:, i], self.cons))
+                            + noise[i] for i in range(self.N_DRAWS)])
+            return np.exp(diffent(ysp, axis=0) - diffent(noise, axis=0)) - 1.0
+        else:
+            var_p = self.yvar_from_parameter_draws()
+        return utility_from_yvar(var_p, self.yvar_noise_model(), self.cost_estimate())
 
     def opt_setting(self):
         """obe_base.py:733-756 — first maximum wins."""

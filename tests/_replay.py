@@ -30,7 +30,9 @@ TRAJECTORIES = ["lorentz3_opt", "lorentz3_scale_choke", "lorentz3_good",
 # SVD-based nudge amplifies last-bit differences of a 10x10 covariance whose eigenvalues
 # span six decades, and every resample compounds it.  No implementation with a
 # different summation order can do better; integer outputs are still compared exactly.
-HIP_RTOL = {name: 1e-10 for name in TRAJECTORIES}
+UTILITY_TRAJECTORIES = ["util_maxmin2", "util_maxmin7", "util_pseudo30", "util_pseudo9", "util_fullkld"]
+
+HIP_RTOL = {name: 1e-10 for name in TRAJECTORIES + UTILITY_TRAJECTORIES}
 HIP_RTOL["multilorentz7_noise"] = 1e-6
 
 # Absolute floor on particles right after a resample, in units of eps*sqrt(largest
@@ -39,7 +41,7 @@ HIP_RTOL["multilorentz7_noise"] = 1e-6
 # Measured on the CPU by re-summing the reference's covariance in reverse order
 # (same experiment as above): 5-75 units on the 3/4-parameter trajectories, 530 units at
 # the first resample of the 10-parameter one, growing as the two runs drift apart.
-NUDGE_FLOOR_UNITS = {name: 256 for name in TRAJECTORIES}
+NUDGE_FLOOR_UNITS = {name: 256 for name in TRAJECTORIES + UTILITY_TRAJECTORIES}
 NUDGE_FLOOR_UNITS["multilorentz7_noise"] = 20000
 
 
@@ -70,6 +72,11 @@ def construct(fx, base_cls, noise_cls, model, extra=None):
     obe = cls(model, setting_values(fx), fx["prior"].copy(), cons, **ctor)
     obe.rng = np.random.default_rng(meta["seed"])        # seeding recipe, SURVEY §8c
     return obe
+
+
+def noise_rng(fx):
+    """The generator the fixture's run used as the reference's module-level obe_base.rng."""
+    return np.random.default_rng(fx["meta"]["seed"] + 2)
 
 
 def close(actual, desired, rtol, what, scale=None):

@@ -76,6 +76,8 @@ def run_trajectory(name, model, setting_values, prior, cons, true_pars, sigma_me
         obe = ref.OptBayesExptNoiseParameter(fn, setting_values, prior.copy(), cons, **ctor)
     rng = RecordingRNG(seed)
     obe.rng = rng
+    import optbayesexpt.obe_base as ref_base
+    ref_base.rng = np.random.default_rng(seed + 2)        # module-level generator (full_kld noise)
     sim = np.random.default_rng(seed + 1)
     n_s = obe.allsettings.shape[1]
     C, D, Np = obe.n_channels, obe.n_dims, obe.n_particles
@@ -112,7 +114,7 @@ def run_trajectory(name, model, setting_values, prior, cons, true_pars, sigma_me
             obe.pdf_update(rec)
         out["chosen_index"].append(best)
         out["y_meas"].append(y)
-        out["utility"].append(util if util is not None else np.full(n_s, np.nan))
+        out["utility"].append(np.asarray(util).reshape(-1)[:n_s] if util is not None else np.full(n_s, np.nan))
         out["draw_idx"].append(draw_idx)
         out["resampled"].append(bool(obe.just_resampled))
         out["mean"].append(obe.mean())
@@ -200,6 +202,20 @@ def trajectories():
                    prior, (0.1,), (2.2, 2.5, 2.8, 3.1, 3.4, 3.7, 3.9, 1000.0, 500.0, 1000.0),
                    1000.0, 24, 707, cls="noise", ctor=dict(scale=False, noise_parameter_index=9),
                    max_particle_snaps=2)
+
+
+def yspace_utilities():
+    """max_min (n_draws = 2 and 7), pseudo_utility (Ebrahimi window at 30 draws,
+    van Es at 9), full_kld_utility."""
+    g = np.random.default_rng(4711)
+    x64 = np.linspace(1.5, 4.5, 64)
+    for name, method, nd, seed in (("maxmin2", "max_min", 2, 811), ("maxmin7", "max_min", 7, 812),
+                                   ("pseudo30", "pseudo_utility", 30, 813), ("pseudo9", "pseudo_utility", 9, 814),
+                                   ("fullkld", "full_kld_utility", 30, 815)):
+        run_trajectory(f"util_{name}", "lorentzian", (x64,), lorentz_prior(g, 2048), (0.1,),
+                       (3.0, -1000.0, 50000.0), 100.0, 15, seed,
+                       ctor=dict(scale=False, utility_method=method, n_draws=nd, default_noise_std=100.0),
+                       max_particle_snaps=1)
 
 
 def unit_cases():
@@ -336,5 +352,6 @@ def full_sweep_cases():
 
 if __name__ == "__main__":
     trajectories()
+    yspace_utilities()
     unit_cases()
     full_sweep_cases()

@@ -62,3 +62,20 @@ def test_trajectory_host_callable_model(hip, name):
     o = _replay.construct(fx, obe.OptBayesExpt, obe.OptBayesExptNoiseParameter, fns[fx["meta"]["model"]])
     assert o._device_model is None
     _replay.replay(fx, o, RTOL, get_draw_idx=lambda x: x.last_draw_indices)
+
+
+@pytest.mark.parametrize("name", _replay.UTILITY_TRAJECTORIES)
+@pytest.mark.parametrize("host_model", [False, True])
+def test_yspace_utility_trajectory_matches_reference(hip, name, host_model):
+    """utility_max_min / utility_pseudo / utility_full_kld on the device
+    (sort + spacing-entropy estimators over the draws), device model and host-callable model."""
+    import optbayesexpt_amd as obe
+    import optbayesexpt_amd.obe_base as obe_base
+    from oracle import models as host_models
+    fx = _replay.load_traj(name)
+    model = host_models.lorentzian if host_model else device_models()[fx["meta"]["model"]]
+    o = _replay.construct(fx, obe.OptBayesExpt, obe.OptBayesExptNoiseParameter, model)
+    obe_base.rng = _replay.noise_rng(fx)            # the module-level generator, as in the reference
+    stats = _replay.replay(fx, o, _replay.HIP_RTOL[name], get_draw_idx=lambda x: x.last_draw_indices,
+                           get_utility=lambda x: np.asarray(x.last_utility).reshape(-1))
+    assert stats["resamples"] == int(np.sum(fx["resampled"])) >= 5

@@ -35,6 +35,19 @@ def test_trajectory_matches_reference(name):
     assert stats["resamples"] == int(np.sum(fx["resampled"])) >= 5
 
 
+@pytest.mark.parametrize("name", _replay.UTILITY_TRAJECTORIES)
+def test_yspace_utility_trajectory_matches_reference(name):
+    """max_min, pseudo_utility (van Es / Ebrahimi windows), full_kld_utility."""
+    fx = _replay.load_traj(name)
+    obe = _replay.construct(fx, oracle.OracleOptBayesExpt, oracle.OracleOptBayesExptNoiseParameter,
+                            ORACLE_MODELS[fx["meta"]["model"]])
+    obe.noise_rng = _replay.noise_rng(fx)
+    stats = _replay.replay(fx, obe, ORACLE_RTOL,
+                           get_draw_idx=lambda o: o.last_draw_indices,
+                           get_utility=lambda o: np.asarray(o.last_utility).reshape(-1))
+    assert stats["resamples"] == int(np.sum(fx["resampled"])) >= 5
+
+
 def test_reference_conditioning_10_parameters(monkeypatch):
     """Why the HIP tolerance on the 10-parameter trajectory is 1e-6 and not 1e-10: the
     reference algorithm, run on the CPU with its weighted covariance summed in reverse
