@@ -194,7 +194,7 @@ def main():
     stream = obe._stream()
     s_ptr = ctypes.c_void_p(obe._settings_dev.data_ptr() + 8 * obe._s_begin)
     shifted = bool(obe.last_sweep["shifted"])           # the variant the timed cycles ended on
-    lib.call("obe_sweep_kernel_time", obe._model_struct, s_ptr, ns, n_local, _ptr(p), p.shape[1], n_p,
+    obe._mlib.call("obe_sweep_kernel_time", obe._model_struct, s_ptr, ns, n_local, _ptr(p), p.shape[1], n_p,
              _ptr(w), _ptr(mom), 1 if shifted else 0, _ptr(obe._ws), obe._ws_bytes, 5, ctypes.byref(ms), stream)
     k1_s = ms.value * 1e-3
     flop = FLOP_PER_EVAL[model] * n_local * n_p          # K1 timed in full-sweep form
@@ -234,7 +234,7 @@ def main():
         if timed:
             lib.call("obe_timer_start", timer, stream)
         for _ in range(reps):
-            lib.call("obe_bayes_update_model", obe._model_struct, _ptr(p), p.shape[1], n_p, _ptr(wcopy),
+            obe._mlib.call("obe_bayes_update_model", obe._model_struct, _ptr(p), p.shape[1], n_p, _ptr(wcopy),
                      _lib.host_ptr(st_arr), _lib.host_ptr(yy), _lib.host_ptr(ss) if rows is None else None,
                      None if rows is None else _lib.host_ptr(rows), 1, float("nan"), _ptr(obe._ws),
                      obe._ws_bytes, None, stream)

@@ -49,7 +49,9 @@ enum obe_model_id {
     OBE_MODEL_LINE_MB = 3,      /* y = p0*x + p1          demos/line_plus_noise/line_plus_noise.py:36-53 */
     OBE_MODEL_FIRST_PARAM = 4,  /* y = p0                 tests/test_zinference.py:21-26 */
     OBE_MODEL_RABI = 5,         /* demos/pipulse/pipulse.py:18-49; 2 settings, 2 params, 3 consts */
-    OBE_MODEL_COIL = 6          /* demos/lockin/lockin_of_coil.py:63-102; 2 channels */
+    OBE_MODEL_COIL = 6,         /* demos/lockin/lockin_of_coil.py:63-102; 2 channels */
+    OBE_MODEL_PLUGIN = 100      /* a model generated from a user expression: served by its own
+                                   plugin library (same entry points, compiled for that model) */
 };
 
 typedef struct obe_model {

@@ -96,10 +96,15 @@ _SIGNATURES = {
 }
 
 
+# entry points whose code depends on the model: a plugin library serves these
+MODEL_ENTRY_POINTS = ("obe_model_validate", "obe_bayes_update_model", "obe_eval_over_particles",
+                      "obe_eval_over_settings", "obe_sweep_utility", "obe_sweep_kernel_time", "obe_eval_draws")
+
+
 class HipLib:
     """Loaded library with typed entry points; ``call(name, *args)`` raises on error."""
 
-    def __init__(self, path=LIB_PATH):
+    def __init__(self, path=LIB_PATH, plugin=False):
         if not os.path.exists(path):
             raise ImportError(
                 f"{path} not found: the HIP library has not been built.  Run "
@@ -107,8 +112,10 @@ class HipLib:
                 "no CPU fallback.")
         import torch  # noqa: F401  (loads the HIP runtime the library will bind to)
         self.path = path
-        self.cdll = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
-        for name, (restype, argtypes) in _SIGNATURES.items():
+        self.cdll = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL if plugin else ctypes.RTLD_GLOBAL)
+        names = MODEL_ENTRY_POINTS + ("obe_abi_version", "obe_last_error") if plugin else tuple(_SIGNATURES)
+        for name in names:
+            restype, argtypes = _SIGNATURES[name]
             fn = getattr(self.cdll, name)
             fn.restype = restype
             fn.argtypes = argtypes
@@ -140,6 +147,14 @@ class HipLib:
 
 
 _LIB = None
+_PLUGINS = {}
+
+
+def load_plugin(path):
+    """A per-model plugin library (optbayesexpt_amd.build.build_plugin), loaded once."""
+    if path not in _PLUGINS:
+        _PLUGINS[path] = HipLib(path, plugin=True)
+    return _PLUGINS[path]
 
 
 def load():

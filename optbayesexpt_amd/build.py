@@ -71,5 +71,62 @@ def build(force=False, verbose=False):
     return LIB
 
 
+PLUGIN_DIR = os.path.join(OUT_DIR, "plugins")
+PLUGIN_SOURCES = ["obe_capi.hip", "obe_update.hip", "obe_sweep.hip", "obe_yspace.hip"]   # model-dependent
+
+
+def _source_fingerprint():
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(CSRC)) + [os.path.join(INCLUDE, "obe_hip.h")]:
+        path = f if os.path.isabs(f) else os.path.join(CSRC, f)
+        h.update(open(path, "rb").read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()[:12]
+
+
+def plugin_path(model_digest):
+    return os.path.join(PLUGIN_DIR, f"libobe_model_{model_digest}_{_source_fingerprint()}.so")
+
+
+def build_plugin(header_text, model_digest, verbose=False):
+    """Compile the model-dependent kernel sources for ONE generated model
+    (``OBE_PLUGIN_MODEL_HEADER``) into a plugin library with the same entry points as
+    libobe_hip.so.  Cached by the hash of the model header and of the kernel sources."""
+    lib = plugin_path(model_digest)
+    if os.path.exists(lib):
+        return lib
+    if not os.path.exists(HIPCC):
+        raise RuntimeError(f"{lib} is not built and hipcc ({HIPCC}) is not available to build it")
+    os.makedirs(PLUGIN_DIR, exist_ok=True)
+    stem = os.path.basename(lib)[3:-3]
+    header = os.path.join(PLUGIN_DIR, stem + ".h")
+    with open(header, "w") as f:
+        f.write(header_text)
+    define = f'-DOBE_PLUGIN_MODEL_HEADER="{header}"'
+
+    def one(src):
+        obj = os.path.join(PLUGIN_DIR, f"{stem}_{src[:-4]}.o")
+        r = subprocess.run([HIPCC] + FLAGS + [define, "-c", os.path.join(CSRC, src), "-o", obj],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for the generated model ({src}):\n{r.stdout}\n{r.stderr}")
+        return obj
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(one, PLUGIN_SOURCES))
+    # -Bsymbolic: calls between the plugin's own entry points must not be interposed by
+    # the same-named symbols of libobe_hip.so already loaded in the process
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic"] + objs + ["-o", lib],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"plugin link failed:\n{r.stdout}\n{r.stderr}")
+    for o in objs:
+        os.remove(o)
+    if verbose:
+        print(f"built {lib}")
+    return lib
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)

@@ -43,14 +43,10 @@ int obe_model_validate(obe_model* m) {
         info.n_setdims = Model::NS;
         info.n_channels = Model::NC;
         info.n_read = Model::NREAD;
+        info.n_consts = Model::NCONST;
         return 0;
     });
     if (rc) return rc;
-    switch (m->id) {
-        case OBE_MODEL_LORENTZ: info.n_consts = 1; break;
-        case OBE_MODEL_RABI: info.n_consts = 3; break;
-        default: info.n_consts = 0; break;
-    }
     if (m->n_setdims == 0) m->n_setdims = info.n_setdims;
     if (m->n_channels == 0) m->n_channels = info.n_channels;
     if (m->n_setdims != info.n_setdims) return bad_arg("model: n_setdims does not match the model");

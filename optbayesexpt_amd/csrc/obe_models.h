@@ -75,7 +75,7 @@ __device__ __forceinline__ void batch_rcp(const double (&q)[N], double (&r)[N]) 
 // demos/find_peak/sequentialLorentzian.py:53-75 (K = 1)
 template <int K>
 struct Lorentz {
-    static constexpr int NS = 1, NC = 1, NREAD = K + 2;
+    static constexpr int NS = 1, NC = 1, NREAD = K + 2, NCONST = 1;
     static constexpr int NXS = 1;        // prepared setting: x/d
     static constexpr int NPK = K + 2;    // packed particle: x0_k/d ..., sw*a, sw*(b - bbar)
 
@@ -124,7 +124,7 @@ struct Lorentz {
 
 // y = p0 + p1 * x        tests/test_optbayesexpt.py:11-14
 struct LineAB {
-    static constexpr int NS = 1, NC = 1, NREAD = 2, NXS = 1, NPK = 2;
+    static constexpr int NS = 1, NC = 1, NREAD = 2, NXS = 1, NPK = 2, NCONST = 0;
     __device__ static void eval(const double* x, const ParamRef& th, const obe_model&, double* y) {
         const double bx = th(1) * x[0];
         y[0] = th(0) + bx;
@@ -144,7 +144,7 @@ struct LineAB {
 
 // y = p0 * x + p1        demos/line_plus_noise/line_plus_noise.py:36-53
 struct LineMB {
-    static constexpr int NS = 1, NC = 1, NREAD = 2, NXS = 1, NPK = 2;
+    static constexpr int NS = 1, NC = 1, NREAD = 2, NXS = 1, NPK = 2, NCONST = 0;
     __device__ static void eval(const double* x, const ParamRef& th, const obe_model&, double* y) {
         const double mx = th(0) * x[0];
         y[0] = mx + th(1);
@@ -164,7 +164,7 @@ struct LineMB {
 
 // y = p0                 tests/test_zinference.py:21-26
 struct FirstParam {
-    static constexpr int NS = 1, NC = 1, NREAD = 1, NXS = 1, NPK = 1;
+    static constexpr int NS = 1, NC = 1, NREAD = 1, NXS = 1, NPK = 1, NCONST = 0;
     __device__ static void eval(const double*, const ParamRef& th, const obe_model&, double* y) { y[0] = th(0); }
     __device__ static void prep_setting(const double* x, const obe_model&, double* xs) { xs[0] = x[0]; }
     __device__ static void pack(const ParamRef& th, const double* thbar, const obe_model&, double sw, double* pk) {
@@ -181,7 +181,7 @@ struct FirstParam {
 // Rabi oscillation counts, demos/pipulse/pipulse.py:18-49
 // settings (pulsetime, delta_f); params (B1, f_center); consts (baseline, contrast, T1)
 struct Rabi {
-    static constexpr int NS = 2, NC = 1, NREAD = 2, NXS = 2, NPK = 2;
+    static constexpr int NS = 2, NC = 1, NREAD = 2, NXS = 2, NPK = 2, NCONST = 3;
     // the fraction removed from the baseline: y = baseline * (1 - frac)
     __device__ __forceinline__ static double frac(double tau, double df, double b1, double fc,
                                                    double contrast, double t1) {
@@ -220,7 +220,7 @@ struct Rabi {
 // Parallel RLC coil impedance, demos/lockin/lockin_of_coil.py:63-102
 // setting w; params (L, R, C [, noise]); channels (Re Z, Im Z)
 struct Coil {
-    static constexpr int NS = 1, NC = 2, NREAD = 3, NXS = 1, NPK = 3;
+    static constexpr int NS = 1, NC = 2, NREAD = 3, NXS = 1, NPK = 3, NCONST = 0;
     // (1 + 0j) / (c + dj) the way NumPy's complex divide loop does it (Smith's method,
     // numpy/_core/src/umath/loops.c.src, complex _divide)
     __device__ __forceinline__ static void crecip(double c, double d, double& re, double& im) {
@@ -265,6 +265,20 @@ struct Coil {
     }
 };
 
+#ifdef OBE_PLUGIN_MODEL_HEADER
+// ---- plugin build -------------------------------------------------------------------
+// The same kernel sources compiled once more for ONE model generated from a user's
+// expression (optbayesexpt_amd/models.py: from_expression): the header defines
+// obe::PluginModel with the interface of the structs above, and every entry point of the
+// resulting shared library serves that model whatever m.id says.
+}  // namespace obe
+#include OBE_PLUGIN_MODEL_HEADER
+namespace obe {
+template <class F>
+int dispatch_model(const obe_model&, F&& f) {
+    return f(PluginModel{});
+}
+#else
 // Host-side dispatch: f(ModelType{}) for the model named by m.id / m.aux.
 template <class F>
 int dispatch_model(const obe_model& m, F&& f) {
@@ -289,5 +303,6 @@ int dispatch_model(const obe_model& m, F&& f) {
         default: return bad_arg("unknown model id");
     }
 }
+#endif
 
 }  // namespace obe

@@ -23,6 +23,7 @@ MODEL_LINE_MB = 3
 MODEL_FIRST_PARAM = 4
 MODEL_RABI = 5
 MODEL_COIL = 6
+MODEL_PLUGIN = 100
 
 
 class DeviceModel:
@@ -35,7 +36,10 @@ class DeviceModel:
         n_setdims, n_channels, n_consts: shape of the model.
     """
 
-    def __init__(self, name, model_id, aux, n_read, n_setdims, n_channels, n_consts, numpy_form):
+    def __init__(self, name, model_id, aux, n_read, n_setdims, n_channels, n_consts, numpy_form,
+                 plugin_path=None):
+        #: path of the per-model plugin library (expression models), else None
+        self.plugin_path = plugin_path
         self.name = name
         self.model_id = model_id
         self.aux = aux
@@ -135,3 +139,24 @@ def coil():
         z = 1 / (1 / (R + 1j * w * L) + 1j * w * C)
         return np.array((np.real(z), np.imag(z)))
     return DeviceModel("coil", MODEL_COIL, 0, 3, 1, 2, 0, form)
+
+
+def from_expression(expression, settings, parameters, constants=(), name=None):
+    """A device model from a formula, e.g. ::
+
+        from_expression("b + a / (((x - x0) / d)**2 + 1)",
+                        settings=("x",), parameters=("x0", "a", "b"), constants=("d",))
+
+    ``expression`` is one string, or a tuple of strings for a multi-channel model.  Allowed:
+    ``+ - * / **``, parentheses, numbers, ``pi``, ``e``, the listed names and
+    exp/log/log1p/expm1/sqrt/sin/cos/tan/tanh/sinh/cosh/arctan/arctan2/hypot/abs/minimum/maximum.
+    The particle array may carry extra trailing rows (e.g. a noise parameter) that the
+    formula does not name.  The first use compiles the kernels for this model with hipcc
+    (tens of seconds) into ``optbayesexpt_amd/lib/plugins/``; later uses load the cached
+    library.  The returned object is also callable as ``model(sets, pars, cons)`` (NumPy)."""
+    from . import _exprmodel, build
+    header, numpy_form, digest = _exprmodel.translate(expression, settings, parameters, constants)
+    n_channels = 1 if isinstance(expression, str) else len(expression)
+    lib = build.build_plugin(header, digest)
+    return DeviceModel(name or f"expression[{digest}]", MODEL_PLUGIN, 0, len(parameters), len(settings),
+                       n_channels, len(constants), numpy_form, plugin_path=lib)

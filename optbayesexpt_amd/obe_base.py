@@ -113,7 +113,9 @@ class OptBayesExpt(ParticlePDF):
             if self.allsettings.shape[0] != dm.n_setdims:
                 raise ValueError(f"{dm.name} takes {dm.n_setdims} setting(s), got {self.allsettings.shape[0]}")
             self._model_struct = dm.struct(self.n_dims, constants)
-            self._lib.call("obe_model_validate", self._model_struct)
+            # expression models are served by their own plugin library (same entry points)
+            self._mlib = _lib.load_plugin(dm.plugin_path) if dm.plugin_path else self._lib
+            self._mlib.call("obe_model_validate", self._model_struct)
             self.n_channels = dm.n_channels
         else:
             self._model_struct = None
@@ -218,7 +220,7 @@ class OptBayesExpt(ParticlePDF):
         par = self._parameters.tensor()
         y = torch.empty((self.n_channels, par.shape[1]), dtype=torch.float64, device=self._device)
         st = self._setting_array(onesettingset)
-        self._lib.call("obe_eval_over_particles", self._model_struct, _ptr(par), par.shape[1], par.shape[1],
+        self._mlib.call("obe_eval_over_particles", self._model_struct, _ptr(par), par.shape[1], par.shape[1],
                        _lib.host_ptr(st), _ptr(y), par.shape[1], self._stream())
         return y
 
@@ -233,7 +235,7 @@ class OptBayesExpt(ParticlePDF):
         thp = np.zeros(_lib.OBE_MAX_DIMS)
         thp[:th.size] = th
         y = torch.empty((self.n_channels, self._n_settings), dtype=torch.float64, device=self._device)
-        self._lib.call("obe_eval_over_settings", self._model_struct, _ptr(self._settings_dev),
+        self._mlib.call("obe_eval_over_settings", self._model_struct, _ptr(self._settings_dev),
                        self._n_settings, self._n_settings, _lib.host_ptr(thp), _ptr(y), self._n_settings,
                        self._stream())
         return y.cpu().numpy()
@@ -283,7 +285,7 @@ class OptBayesExpt(ParticlePDF):
             w = self._weights.tensor()
             if par.shape[1] != w.shape[0]:
                 raise ValueError("parameters and particle_weights have different lengths")
-            self._lib.call("obe_bayes_update_model", self._model_struct, _ptr(par), par.shape[1],
+            self._mlib.call("obe_bayes_update_model", self._model_struct, _ptr(par), par.shape[1],
                            self.n_particles, _ptr(w), _lib.host_ptr(self._setting_array(onesetting)),
                            _lib.host_ptr(yy), None if s is None else _lib.host_ptr(s),
                            None if rows is None else _lib.host_ptr(rows), n, self._choke_value(),
@@ -406,7 +408,7 @@ class OptBayesExpt(ParticlePDF):
         def launch(shifted):
             # sharded: no host read here — the 32-byte result record is all-gathered from
             # device memory and read back once, together with the other ranks' records
-            self._lib.call("obe_sweep_utility", self._model_struct, s_ptr, self._n_settings, n_local,
+            self._mlib.call("obe_sweep_utility", self._model_struct, s_ptr, self._n_settings, n_local,
                            _ptr(p), p.shape[1], self.n_particles, _ptr(w),
                            None if idx is None else _ptr(idx), n_draws, _ptr(mom), 1 if shifted else 0,
                            _ptr(noise), noise_ld, None if cost_t is None else _ptr(cost_t), cost_s,
@@ -494,7 +496,7 @@ class OptBayesExpt(ParticlePDF):
             idx = self._draw_indices(nd)
             p = self._particles.tensor()
             ysp = torch.empty((nd, c, ns), dtype=torch.float64, device=self._device)
-            self._lib.call("obe_eval_draws", self._model_struct, _ptr(self._settings_dev), ns, ns, _ptr(p),
+            self._mlib.call("obe_eval_draws", self._model_struct, _ptr(self._settings_dev), ns, ns, _ptr(p),
                            p.shape[1], self.n_particles, _ptr(idx), nd, _ptr(ysp), self._stream())
             return ysp
         paramsets = self.randdraw(nd).T              # host-callable model: the user's function fills it

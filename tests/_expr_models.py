@@ -1,0 +1,21 @@
+"""Expression models used by the GPU tests (and pre-built by __graft_entry__.build() so that
+the plugin libraries travel with the repository snapshot)."""
+
+
+def expression_models():
+    from optbayesexpt_amd import models
+    den = "(R**2 + (w*L)**2)"
+    g = f"(R / {den})"
+    b = f"(w*C - w*L / {den})"
+    return {
+        # demos/find_peak/sequentialLorentzian.py:53-75 as a formula
+        "lorentzian": models.from_expression("b + a / (((x - x0) / d)**2 + 1)", settings=("x",),
+                                             parameters=("x0", "a", "b"), constants=("d",)),
+        # demos/pipulse/pipulse.py:18-49, same operation order as the NumPy function
+        "rabi": models.from_expression(
+            "baseline*(1 - exp(-t/T1)*contrast/2*(1 - cos(pi*2*hypot(df - fc, B1)*t))/(((df - fc)/B1)**2 + 1))",
+            settings=("t", "df"), parameters=("B1", "fc"), constants=("baseline", "contrast", "T1")),
+        # demos/lockin/lockin_of_coil.py:63-102 in real arithmetic: Z = (G - jB)/(G^2 + B^2)
+        "coil": models.from_expression((f"{g} / ({g}**2 + {b}**2)", f"-{b} / ({g}**2 + {b}**2)"),
+                                       settings=("w",), parameters=("L", "R", "C")),
+    }

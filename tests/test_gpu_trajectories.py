@@ -79,3 +79,23 @@ def test_yspace_utility_trajectory_matches_reference(hip, name, host_model):
     stats = _replay.replay(fx, o, _replay.HIP_RTOL[name], get_draw_idx=lambda x: x.last_draw_indices,
                            get_utility=lambda x: np.asarray(x.last_utility).reshape(-1))
     assert stats["resamples"] == int(np.sum(fx["resampled"])) >= 5
+
+
+@pytest.mark.parametrize("name,key", [("lorentz3_opt", "lorentzian"), ("lorentz3_scale_choke", "lorentzian"),
+                                      ("rabi_2set", "rabi"), ("coil_2ch_noise", "coil"),
+                                      ("util_pseudo30", "lorentzian"), ("util_maxmin2", "lorentzian")])
+def test_trajectory_expression_model(hip, name, key):
+    """Models given as a formula (models.from_expression): the kernels compiled for that model
+    in a plugin library reproduce the reference trajectories like the hand-written models."""
+    import optbayesexpt_amd as obe
+    import optbayesexpt_amd.obe_base as obe_base
+    import _expr_models
+    fx = _replay.load_traj(name)
+    model = _expr_models.expression_models()[key]
+    assert model.plugin_path is not None
+    o = _replay.construct(fx, obe.OptBayesExpt, obe.OptBayesExptNoiseParameter, model)
+    assert o._mlib is not o._lib
+    obe_base.rng = _replay.noise_rng(fx)
+    get_u = (lambda x: x._utility_dev.cpu().numpy()) if name.startswith(("lorentz3", "rabi", "coil")) else \
+        (lambda x: np.asarray(x.last_utility).reshape(-1))
+    _replay.replay(fx, o, _replay.HIP_RTOL[name], get_draw_idx=lambda x: x.last_draw_indices, get_utility=get_u)

@@ -520,3 +520,25 @@ def test_update_back_to_back_stress(obe, hip):
             bad += not (abs(sums[1] - 1.0) < 1e-12 and abs(out[0] / expect_total - 1.0) < 1e-12
                         and abs(out[1] / sums[0] - 1.0) < 1e-12)
     assert bad == 0
+
+
+def test_expression_model_full_sweep_matches_oracle(obe):
+    """variance_full through a plugin-compiled expression model, non-uniform weights, both
+    shift variants, against the oracle."""
+    import _expr_models
+    f = _replay.load("full_sweep_uniform.npz")
+    g = np.random.default_rng(5)
+    prior, sv = f["fs_lor_prior"], (f["fs_lor_x"],)
+    w = g.exponential(1.0, prior.shape[1]) ** 2
+    w /= w.sum()
+    ref = oracle.yvar_full_sweep(omodels.lorentzian, oracle.flatten_settings(sv), prior, w, (0.1,))
+    for mode in ("always", "never"):
+        o = obe.OptBayesExpt(_expr_models.expression_models()["lorentzian"], sv, prior.copy(), (0.1,),
+                             utility_method="variance_full", auto_resample=False, default_noise_std=500.0)
+        o.tuning_parameters["sweep_shift"] = mode
+        o.particle_weights = w
+        assert_allclose(o.yvar_from_parameter_draws(), ref, rtol=RTOL if mode == "always" else 1e-7)
+        o.opt_setting()
+        assert o.last_setting_index == int(np.argmax(ref[0]))
+    assert_array_equal(o.eval_over_all_settings([3.0, -1000.0, 50000.0]),
+                       np.atleast_2d(omodels.lorentzian(sv, (3.0, -1000.0, 50000.0), (0.1,))))
