@@ -28,8 +28,9 @@ _CONSTS = {"pi": float(np.pi), "e": float(np.e)}
 
 
 class _ToC(ast.NodeVisitor):
-    def __init__(self, names):
+    def __init__(self, names, fast_division=False):
         self.names = names
+        self.fast_division = fast_division
 
     def visit_Expression(self, node):
         return self.visit(node.body)
@@ -63,6 +64,8 @@ class _ToC(ast.NodeVisitor):
         if isinstance(node.op, ast.Mult):
             return f"({a} * {b})"
         if isinstance(node.op, ast.Div):
+            if self.fast_division:
+                return f"({a} * guarded_rcp({b}))"      # sweep form: ~10 issue slots instead of ~28
             return f"({a} / {b})"
         if isinstance(node.op, ast.Pow):
             if isinstance(node.right, ast.Constant) and node.right.value == 2:
@@ -102,11 +105,13 @@ def translate(expressions, settings, parameters, constants):
     names = set(settings + parameters + constants)
     trees = [ast.parse(e.strip(), mode="eval") for e in expressions]
     c_exprs = [_ToC(names).visit(t) for t in trees]
+    c_fast = [_ToC(names, fast_division=True).visit(t) for t in trees]
     ns, nc, npar, ncon = len(settings), len(expressions), len(parameters), len(constants)
     decl = [f"        const double u_{n} = x_[{i}];" for i, n in enumerate(settings)]
     decl += [f"        const double u_{n} = th_[{i}];" for i, n in enumerate(parameters)]
     decl += [f"        const double u_{n} = c_[{i}];" for i, n in enumerate(constants)]
     body = [f"        y_[{c}] = {e};" for c, e in enumerate(c_exprs)]
+    body_fast = [f"        y_[{c}] = {e};" for c, e in enumerate(c_fast)]
     nl = "\n"
     header = f"""// generated by optbayesexpt_amd.models.from_expression — do not edit
 // settings {settings}, parameters {parameters}, constants {constants}
@@ -121,6 +126,22 @@ struct PluginModel {{
 {nl.join(decl)}
         (void)x_; (void)th_; (void)c_;
 {nl.join(body)}
+    }}
+    // 1/b for the flop-bound sweep: v_rcp_f64 + one cubic correction (~1 ulp); falls back to the
+    // raw reciprocal for b = 0 / inf / NaN so that a/0 = inf and a/inf = 0 as in IEEE division
+    __device__ __forceinline__ static double guarded_rcp(double b) {{
+        const double r0 = __builtin_amdgcn_rcp(b);
+        const double e = fma(-b, r0, 1.0);
+        const double r = fma(r0, fma(e, e, e), r0);
+        return r == r ? r : r0;
+    }}
+    // the same formula with divisions as multiplications by guarded_rcp (sweep only; the
+    // Bayes update and eval_over_* use the exact IEEE form above)
+    __device__ __forceinline__ static void formula_fast(const double* x_, const double* th_, const double* c_,
+                                                        double* y_) {{
+{nl.join(decl)}
+        (void)x_; (void)th_; (void)c_;
+{nl.join(body_fast)}
     }}
     __device__ static void eval(const double* x, const ParamRef& th, const obe_model& m, double* y) {{
         double t[NREAD];
@@ -142,7 +163,7 @@ struct PluginModel {{
 #pragma unroll
         for (int j = 0; j < SPT; ++j) {{
             double y[NC];
-            formula(xs[j], pk, m.consts, y);
+            formula_fast(xs[j], pk, m.consts, y);
 #pragma unroll
             for (int c = 0; c < NC; ++c) v[j][c] = sw * y[c];
         }}

@@ -99,6 +99,10 @@ def build_plugin(header_text, model_digest, verbose=False):
     if not os.path.exists(HIPCC):
         raise RuntimeError(f"{lib} is not built and hipcc ({HIPCC}) is not available to build it")
     os.makedirs(PLUGIN_DIR, exist_ok=True)
+    fp = _source_fingerprint()
+    for f in os.listdir(PLUGIN_DIR):          # plugins of older kernel sources are dead weight
+        if not f.rsplit(".", 1)[0].endswith(fp):
+            os.remove(os.path.join(PLUGIN_DIR, f))
     stem = os.path.basename(lib)[3:-3]
     header = os.path.join(PLUGIN_DIR, stem + ".h")
     with open(header, "w") as f:
