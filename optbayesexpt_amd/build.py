@@ -94,15 +94,15 @@ def build_plugin(header_text, model_digest, verbose=False):
     (``OBE_PLUGIN_MODEL_HEADER``) into a plugin library with the same entry points as
     libobe_hip.so.  Cached by the hash of the model header and of the kernel sources."""
     lib = plugin_path(model_digest)
-    if os.path.exists(lib):
-        return lib
-    if not os.path.exists(HIPCC):
-        raise RuntimeError(f"{lib} is not built and hipcc ({HIPCC}) is not available to build it")
     os.makedirs(PLUGIN_DIR, exist_ok=True)
     fp = _source_fingerprint()
     for f in os.listdir(PLUGIN_DIR):          # plugins of older kernel sources are dead weight
         if not f.rsplit(".", 1)[0].endswith(fp):
             os.remove(os.path.join(PLUGIN_DIR, f))
+    if os.path.exists(lib):
+        return lib
+    if not os.path.exists(HIPCC):
+        raise RuntimeError(f"{lib} is not built and hipcc ({HIPCC}) is not available to build it")
     stem = os.path.basename(lib)[3:-3]
     header = os.path.join(PLUGIN_DIR, stem + ".h")
     with open(header, "w") as f:
