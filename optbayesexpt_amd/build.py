@@ -82,6 +82,7 @@ def _source_fingerprint():
         path = f if os.path.isabs(f) else os.path.join(CSRC, f)
         h.update(open(path, "rb").read())
     h.update(" ".join(FLAGS).encode())
+    h.update(open(os.path.join(HERE, "_exprmodel.py"), "rb").read())     # the header generator
     return h.hexdigest()[:12]
 
 
