@@ -582,11 +582,14 @@ class OptBayesExpt(ParticlePDF):
         """A setting drawn with probability ~ utility**pickiness (obe_base.py:758-789)."""
         if pickiness is None:
             pickiness = self.pickiness
-        if self._shard is not None:
-            raise NotImplementedError("good_setting with a sharded settings axis (SURVEY.md §8e, next)")
         if self._utility_fusable():
             self._sweep_device(False)
             u = self._utility_dev
+            if self._shard is not None:
+                # every rank assembles the full utility vector (N_s doubles over xGMI) and then
+                # draws from it exactly as a single GPU would: same sums, same index everywhere
+                full = self._gather_settings(self._utility_dev.reshape(1, -1))[0]
+                u = torch.from_numpy(np.ascontiguousarray(full)).to(self._device)
         else:
             u = torch.from_numpy(np.ascontiguousarray(self.utility(), dtype=np.float64).reshape(-1)).to(self._device)
         n = u.numel()

@@ -7,7 +7,17 @@ def expression_models():
     den = "(R**2 + (w*L)**2)"
     g = f"(R / {den})"
     b = f"(w*C - w*L / {den})"
+    # the device limits at once: 4 setting dimensions, 16 parameter rows (12 named + 4 noise
+    # parameters), 4 output channels
+    pn = tuple(f"p{i}" for i in range(12))
+    big = models.from_expression(
+        ("p0 + p1*s0 + p2*s1*s1 + p3*cos(s2 + p4)",
+         "p5*exp(-s3*abs(p6)) + p7*s0*s1",
+         "p8/(1 + (s2 - p9)**2) + p10",
+         "p11*s3 + p0*p1 - p2"),
+        settings=("s0", "s1", "s2", "s3"), parameters=pn, name="limits_4x16x4")
     return {
+        "limits": big,
         # demos/find_peak/sequentialLorentzian.py:53-75 as a formula
         "lorentzian": models.from_expression("b + a / (((x - x0) / d)**2 + 1)", settings=("x",),
                                              parameters=("x0", "a", "b"), constants=("d",)),

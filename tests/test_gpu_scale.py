@@ -183,6 +183,10 @@ def test_sharded_path_through_rccl_world_of_one(obe):
             for o in (sharded, plain):
                 o.pdf_update((xs, 49500.0, sigma))
         assert_allclose(sharded.utility(), plain.utility(), rtol=1e-14)
+        for o in (sharded, plain):
+            o.rng = np.random.default_rng(11)
+        for _ in range(3):                      # good_setting through the gathered utility vector
+            assert sharded.good_setting(pickiness=19) == plain.good_setting(pickiness=19)
         dist.barrier()
     finally:
         if created:

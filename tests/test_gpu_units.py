@@ -542,3 +542,36 @@ def test_expression_model_full_sweep_matches_oracle(obe):
         assert o.last_setting_index == int(np.argmax(ref[0]))
     assert_array_equal(o.eval_over_all_settings([3.0, -1000.0, 50000.0]),
                        np.atleast_2d(omodels.lorentzian(sv, (3.0, -1000.0, 50000.0), (0.1,))))
+
+
+def test_device_limits_4_settings_16_parameters_4_channels(obe):
+    """OBE_MAX_SETDIMS / OBE_MAX_DIMS / OBE_MAX_CHANNELS exercised together through an
+    expression model with a noise parameter per channel: cycles against the oracle."""
+    import _expr_models
+    model = _expr_models.expression_models()["limits"]
+    g = np.random.default_rng(404)
+    n = 3000
+    prior = np.vstack([g.normal(1.0, 0.3, (12, n)), g.uniform(0.5, 2.0, (4, n))])
+    sv = (np.linspace(0, 1, 3), np.linspace(-1, 1, 4), np.linspace(0, 3, 5), np.linspace(0.1, 2, 2))
+    kw = dict(scale=False, noise_parameter_index=(12, 13, 14, 15))
+    true = np.r_[np.ones(12), np.ones(4)]
+    for method in ("variance_approx", "variance_full"):
+        a = obe.OptBayesExptNoiseParameter(model, sv, prior.copy(), (), utility_method=method, **kw)
+        b = oracle.OracleOptBayesExptNoiseParameter(model, sv, prior.copy(), (), utility_method=method,
+                                                    n_channels=4, **kw)
+        assert a.allsettings.shape == (4, 120) and a.n_channels == 4 and a.n_dims == 16
+        a.rng, b.rng = np.random.default_rng(9), np.random.default_rng(9)
+        sim = np.random.default_rng(10)
+        for cyc in range(12):
+            xa, xb = a.opt_setting(), b.opt_setting()
+            assert a.last_setting_index == b.last_setting_index, (method, cyc)
+            assert_allclose(a._utility_dev.cpu().numpy(), b.last_utility, rtol=RTOL)
+            y = tuple(np.asarray(model(xb, true, ())) + sim.standard_normal(4))
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", RuntimeWarning)
+                a.pdf_update((xa, y))
+                b.pdf_update((xb, y))
+            assert a.just_resampled == b.just_resampled
+            assert_allclose(a.particle_weights, b.particle_weights, rtol=RTOL,
+                            atol=1e-13 * b.particle_weights.max())
+        assert_allclose(a.covariance(), b.covariance(), rtol=1e-9, atol=1e-12)
