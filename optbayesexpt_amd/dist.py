@@ -65,7 +65,8 @@ class SettingsShard:
         """Global first-maximum from each rank's 32-byte device record {value, local index
         (int64 bits), kappa, 0} (include/obe_hip.h: OBE_WS_RESULT_OFFSET): one all-gather
         straight from device memory, one copy to the host.  Returns (value, global index,
-        this rank's kappa)."""
+        worst kappa over ALL ranks) — the same triple on every rank, so that decisions taken
+        from it (repeat the sweep with the variance shift?) keep the ranks' collectives in step."""
         w = self.world_size
         g = self._gather_records(record)
         vals = g[:, 0].numpy()
@@ -73,7 +74,9 @@ class SettingsShard:
         starts = np.array([shard_bounds(n_settings, r, w)[0] for r in range(w)], dtype=np.int64)
         gidx = local + starts
         k = first_max(vals, gidx)
-        return float(vals[k]), int(gidx[k]), float(g[self.rank, 2])
+        kappas = g[:, 2].numpy()
+        worst = float("nan") if np.any(np.isnan(kappas)) else float(np.max(kappas))
+        return float(vals[k]), int(gidx[k]), worst
 
     def _gather_records(self, record):
         """(world, 4) host tensor of every rank's record."""

@@ -425,6 +425,8 @@ class OptBayesExpt(ParticlePDF):
             else:
                 result["best"] = (float(best[0]), int(best_idx[0]) + self._s_begin)
 
+        # (sharded: kappa is the worst over all ranks, so every rank takes the same branch and the
+        # collectives stay in step)
         # Shift policy (full sweep only).  The unshifted kernel saves one FP64 instruction
         # per evaluation (11 % of the sweep) but loses ~eps*kappa*sqrt(N) relative accuracy,
         # kappa = (mean of y)^2 / var being reported by every sweep.  It is used only while
