@@ -402,7 +402,7 @@ class OptBayesExpt(ParticlePDF):
         kappa = np.zeros(1)
         s_ptr = _P(self._settings_dev.data_ptr() + 8 * self._s_begin)
 
-        sharded = want_best and self._shard is not None
+        sharded = self._shard is not None     # every sweep of a sharded object gathers: ranks stay in lockstep
         result = {}
 
         def launch(shifted):
