@@ -172,8 +172,13 @@ def main():
     barrier()
     t0 = time.perf_counter()
     resamples = 0
+    step_ms, step_resampled = [], []
     for _ in range(args.steps):
-        resamples += one_step()
+        ts = time.perf_counter()                 # every step ends on pdf_update's device sync
+        r = one_step()
+        step_ms.append(1e3 * (time.perf_counter() - ts))
+        step_resampled.append(r)
+        resamples += r
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -258,7 +263,11 @@ def main():
                                   if obe.utility_method == "variance_full" else
                                   f"variance_approx (N_DRAWS = {obe.N_DRAWS} weighted draws, reference semantics)"),
                       "settings_per_rank": n_local, "sharding": f"settings axis / {world}",
-                      "resamples_in_timed_steps": resamples},
+                      "resamples_in_timed_steps": resamples,
+                      "median_ms_plain_cycle": (float(np.median([m for m, r in zip(step_ms, step_resampled) if not r]))
+                                                if resamples < args.steps else None),
+                      "median_ms_resample_cycle": (float(np.median([m for m, r in zip(step_ms, step_resampled) if r]))
+                                                   if resamples else None)},
            "roofline": roofline, "roofline_update": roofline_update}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, settings, prior, cons, true, sigma)

@@ -124,3 +124,29 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+
+
+def test_expression_translator():
+    """models.from_expression's translator (no compilation here): the NumPy form reproduces
+    the demo formulas bit for bit, the generated header has the model interface, and
+    anything outside the small expression language is rejected."""
+    from optbayesexpt_amd import _exprmodel
+    g = np.random.default_rng(3)
+    x = np.linspace(1.5, 4.5, 40)
+    header, form, digest = _exprmodel.translate("b + a / (((x - x0) / d)**2 + 1)", ("x",), ("x0", "a", "b"), ("d",))
+    pars = (g.uniform(2, 4, 1), g.uniform(-2000, -400, 1), g.normal(5e4, 1e3, 1))
+    assert_array_equal(form((x,), pars, (0.1,)), omodels.lorentzian((x,), pars, (0.1,)))
+    assert "struct PluginModel" in header and "NS = 1, NC = 1, NREAD = 3, NCONST = 1" in header
+    assert "sq(" in header and "guarded_rcp" in header and len(digest) == 16
+    assert _exprmodel.translate("b + a / (((x - x0) / d)**2 + 1)", ("x",), ("x0", "a", "b"), ("d",))[2] == digest
+    rabi = ("baseline*(1 - exp(-t/T1)*contrast/2*(1 - cos(pi*2*hypot(df - fc, B1)*t))/(((df - fc)/B1)**2 + 1))")
+    _, form2, _ = _exprmodel.translate(rabi, ("t", "df"), ("B1", "fc"), ("baseline", "contrast", "T1"))
+    sets = (x[:, None] / 5, x[None, :] - 3)
+    assert_array_equal(form2(sets, (2.0, 0.5), (1e5, 0.01, 2.0)), omodels.rabi(sets, (2.0, 0.5), (1e5, 0.01, 2.0)))
+    _, form3, _ = _exprmodel.translate(("cos(w*t)", "sin(w*t) + c0"), ("t",), ("w",), ("c0",))
+    assert form3((x,), (2.0,), (1.0,)).shape == (2, 40)
+    for bad in ("__import__('os')", "x if a else b", "a[0]", "lambda: 1", "foo(x)", "x @ a", "exp(x, a)", "y + 1"):
+        with pytest.raises((ValueError, SyntaxError)):
+            _exprmodel.translate(bad, ("x",), ("a", "b"), ())
+    with pytest.raises(ValueError):
+        _exprmodel.translate("x + exp", ("x",), ("exp",), ())      # a parameter may not shadow a function
