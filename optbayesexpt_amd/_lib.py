@@ -158,9 +158,15 @@ def load_plugin(path):
 
 
 def load():
-    """The process-wide library instance (loaded on first use)."""
+    """The process-wide library instance (loaded on first use).  If the in-tree library has
+    not been built yet and hipcc is present it is built now; otherwise HipLib raises —
+    there is no CPU fallback."""
     global _LIB
     if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            from . import build
+            if os.path.exists(build.HIPCC):
+                build.build(verbose=True)
         _LIB = HipLib()
     return _LIB
 

@@ -191,3 +191,34 @@ def test_sharded_path_through_rccl_world_of_one(obe):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_long_full_sweep_trajectory_matches_oracle(obe):
+    """30 select-and-update cycles in full-sweep mode at 262 144 particles (64 settings so that
+    the oracle keeps up): device RNG, adaptive shift, large-N resamples, all against the oracle
+    cycle by cycle — chosen settings and resample decisions exact, weights and moments 1e-10."""
+    settings, prior, cons, true, sigma = bench.make_workload("c2")
+    sv = (np.ascontiguousarray(settings[0][::64]),)
+    kw = dict(scale=False, utility_method="variance_full", default_noise_std=sigma)
+    a = obe.OptBayesExpt(obe.models.lorentzian(), sv, prior.copy(), cons, **kw)
+    b = oracle.OracleOptBayesExpt(omodels.lorentzian, sv, prior.copy(), cons, n_channels=1, **kw)
+    a.rng, b.rng = np.random.default_rng(77), np.random.default_rng(77)
+    sim = np.random.default_rng(78)
+    resamples, unshifted = 0, 0
+    for cyc in range(30):
+        xa, xb = a.opt_setting(), b.opt_setting()
+        assert a.last_setting_index == b.last_setting_index, cyc
+        assert_allclose(a._utility_dev.cpu().numpy(), b.last_utility, rtol=RTOL)
+        unshifted += not a.last_sweep["shifted"]
+        y = float(omodels.lorentzian(xb, true, cons)) + sigma * sim.standard_normal()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            a.pdf_update((xa, y, sigma))
+            b.pdf_update((xb, y, sigma))
+        assert a.just_resampled == b.just_resampled, cyc
+        resamples += a.just_resampled
+        assert_allclose(a.mean(), b.mean(), rtol=RTOL)
+        assert_allclose(a.std(), b.std(), rtol=1e-8)
+    assert resamples >= 3 and unshifted >= 5
+    assert_allclose(a.particle_weights, b.particle_weights, rtol=RTOL, atol=1e-13 * b.particle_weights.max())
+    assert a.rng.bit_generator.state == b.rng.bit_generator.state      # the streams stayed in step
