@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group even with one rank (exercises the N > 1 code path)")
     args = ap.parse_args()
 
     import torch
@@ -124,8 +126,13 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     shard = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         # RCCL prints a version banner on stdout when the communicator comes up; keep
         # stdout for the one JSON line by pointing fd 1 at stderr until it is up
         sys.stdout.flush()
@@ -138,6 +145,7 @@ def main():
             torch.cuda.synchronize()
         finally:
             sys.stdout.flush()
+            ctypes.CDLL(None).fflush(None)       # RCCL printf()s into libc's buffer: flush it to stderr too
             os.dup2(saved, 1)
             os.close(saved)
         from optbayesexpt_amd import SettingsShard
@@ -163,7 +171,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     # state for the benchmark: a few real updates (non-uniform weights), SURVEY §8(d)
@@ -181,7 +189,7 @@ def main():
         resamples += r
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -273,7 +281,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(cfg, settings, prior, cons, true, sigma)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

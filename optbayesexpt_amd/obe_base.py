@@ -94,6 +94,7 @@ class OptBayesExpt(ParticlePDF):
 
         self.model_function = measurement_model
         self._device_model = measurement_model if isinstance(measurement_model, DeviceModel) else None
+        self._mlib = self._lib          # model-dependent entry points; an expression model brings its own
         self.setting_values = setting_values
         #: (S, N_s) all setting combinations, meshgrid indexing='ij' (obe_base.py:174-176)
         self.allsettings = np.array([s.flatten() for s in
@@ -379,7 +380,7 @@ class OptBayesExpt(ParticlePDF):
 
     def _utility_fusable(self):
         return (self._device_model is not None
-                and self.utility.__func__ is OptBayesExpt.utility_variance
+                and getattr(self.utility, "__func__", None) is OptBayesExpt.utility_variance
                 and not _overridden(self, "yvar_from_parameter_draws", OptBayesExpt)
                 and not _overridden(self, "eval_over_all_settings", OptBayesExpt))
 
