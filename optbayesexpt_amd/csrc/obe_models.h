@@ -109,15 +109,29 @@ struct Lorentz {
         for (int j = 0; j < SPT; ++j) v[j][0] = pk[K + 1];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            double q[SPT], r[SPT];
+            double q[SPT];
 #pragma unroll
             for (int j = 0; j < SPT; ++j) {
                 const double t = xs[j][0] - pk[k];
                 q[j] = fma(t, t, 1.0);
             }
-            batch_rcp<SPT>(q, r);
+            if constexpr (SPT == 1) {
+                v[0][0] = fma(pk[K], fast_rcp(q[0]), v[0][0]);
+            } else {
+                // Batch inversion stopped one level early: invert the SPT/2 pair products, fold
+                // the amplitude into each pair inverse, and let the final multiply by the sibling
+                // be the FMA that accumulates the peak:  a/q0 = (a / (q0 q1)) * q1.
+                double pp[SPT / 2], ip[SPT / 2];
 #pragma unroll
-            for (int j = 0; j < SPT; ++j) v[j][0] = fma(pk[K], r[j], v[j][0]);
+                for (int h = 0; h < SPT / 2; ++h) pp[h] = q[2 * h] * q[2 * h + 1];
+                batch_rcp<SPT / 2>(pp, ip);
+#pragma unroll
+                for (int h = 0; h < SPT / 2; ++h) {
+                    const double g = pk[K] * ip[h];
+                    v[2 * h][0] = fma(g, q[2 * h + 1], v[2 * h][0]);
+                    v[2 * h + 1][0] = fma(g, q[2 * h], v[2 * h + 1][0]);
+                }
+            }
         }
     }
 };
