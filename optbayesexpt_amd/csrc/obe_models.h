@@ -134,6 +134,43 @@ struct Lorentz {
             }
         }
     }
+    // Two particles at once: their 2*SPT/2 pair products share ONE reciprocal.
+    static constexpr bool kHasPairEval = true;
+    template <int SPT>
+    __device__ __forceinline__ static void sweep_eval_pair(const double (&xs)[SPT][NXS], const double* pa,
+                                                           const double* pb, double (&va)[SPT][NC],
+                                                           double (&vb)[SPT][NC]) {
+        static_assert(SPT >= 2 && SPT <= 8, "pair evaluation batches SPT pair products");
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) {
+            va[j][0] = pa[K + 1];
+            vb[j][0] = pb[K + 1];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double qa[SPT], qb[SPT], pp[SPT], ip[SPT];
+#pragma unroll
+            for (int j = 0; j < SPT; ++j) {
+                const double ta = xs[j][0] - pa[k], tb = xs[j][0] - pb[k];
+                qa[j] = fma(ta, ta, 1.0);
+                qb[j] = fma(tb, tb, 1.0);
+            }
+#pragma unroll
+            for (int h = 0; h < SPT / 2; ++h) {
+                pp[h] = qa[2 * h] * qa[2 * h + 1];
+                pp[SPT / 2 + h] = qb[2 * h] * qb[2 * h + 1];
+            }
+            batch_rcp<SPT>(pp, ip);
+#pragma unroll
+            for (int h = 0; h < SPT / 2; ++h) {
+                const double ga = pa[K] * ip[h], gb = pb[K] * ip[SPT / 2 + h];
+                va[2 * h][0] = fma(ga, qa[2 * h + 1], va[2 * h][0]);
+                va[2 * h + 1][0] = fma(ga, qa[2 * h], va[2 * h + 1][0]);
+                vb[2 * h][0] = fma(gb, qb[2 * h + 1], vb[2 * h][0]);
+                vb[2 * h + 1][0] = fma(gb, qb[2 * h], vb[2 * h + 1][0]);
+            }
+        }
+    }
 };
 
 // y = p0 + p1 * x        tests/test_optbayesexpt.py:11-14
@@ -278,6 +315,11 @@ struct Coil {
         }
     }
 };
+
+template <class M, class = void>
+struct has_pair_eval { static constexpr bool value = false; };
+template <class M>
+struct has_pair_eval<M, std::enable_if_t<M::kHasPairEval>> { static constexpr bool value = true; };
 
 #ifdef OBE_PLUGIN_MODEL_HEADER
 // ---- plugin build -------------------------------------------------------------------

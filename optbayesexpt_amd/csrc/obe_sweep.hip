@@ -163,14 +163,7 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(SweepArgs a) {
             tile[i * NPKW + NPK] = sw;
         }
         __syncthreads();
-#pragma unroll 2
-        for (int i = 0; i < n; ++i) {
-            double pk[NPK];
-#pragma unroll
-            for (int k = 0; k < NPK; ++k) pk[k] = tile[i * NPKW + k];   // same address in every lane: LDS broadcast
-            const double sw = tile[i * NPKW + NPK];
-            double v[SPT][NC];
-            M::template sweep_eval<SPT>(xs, pk, sw, a.m, v);             // sqrt(w) * y'
+        auto accumulate = [&](const double (&v)[SPT][NC], double sw) {
 #pragma unroll
             for (int j = 0; j < SPT; ++j) {
 #pragma unroll
@@ -180,6 +173,32 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(SweepArgs a) {
                     s2[j][c] = fma(u, u, s2[j][c]);                      // sum w (y' - c_s)^2
                 }
             }
+        };
+        int i = 0;
+        if constexpr (has_pair_eval<M>::value && SPT >= 2) {
+            for (; i + 1 < n; i += 2) {          // two particles share one reciprocal
+                double pa[NPK], pb[NPK];
+#pragma unroll
+                for (int k = 0; k < NPK; ++k) {
+                    pa[k] = tile[i * NPKW + k];                          // same address in every lane:
+                    pb[k] = tile[(i + 1) * NPKW + k];                    // LDS broadcast
+                }
+                const double swa = tile[i * NPKW + NPK], swb = tile[(i + 1) * NPKW + NPK];
+                double va[SPT][NC], vb[SPT][NC];
+                M::template sweep_eval_pair<SPT>(xs, pa, pb, va, vb);
+                accumulate(va, swa);
+                accumulate(vb, swb);
+            }
+        }
+#pragma unroll 2
+        for (; i < n; ++i) {
+            double pk[NPK];
+#pragma unroll
+            for (int k = 0; k < NPK; ++k) pk[k] = tile[i * NPKW + k];   // same address in every lane: LDS broadcast
+            const double sw = tile[i * NPKW + NPK];
+            double v[SPT][NC];
+            M::template sweep_eval<SPT>(xs, pk, sw, a.m, v);             // sqrt(w) * y'
+            accumulate(v, sw);
         }
     }
 
