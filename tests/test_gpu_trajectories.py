@@ -40,6 +40,23 @@ def test_trajectory_matches_reference(hip, name):
     assert stats["resamples"] == int(np.sum(fx["resampled"])) >= 5
 
 
+@pytest.mark.parametrize("name", ["lorentz3_opt", "multilorentz7_noise", "coil_2ch_noise"])
+def test_trajectory_with_device_rng_forced(hip, name, monkeypatch):
+    """The golden clouds are small enough that resample() would call self.rng on the host;
+    force the device continuation of the numpy stream so that it is exercised on every
+    reference trajectory shape (3, 4 and 10 parameters)."""
+    import optbayesexpt_amd as obe
+    from optbayesexpt_amd import _devrng
+    monkeypatch.setattr(_devrng, "MIN_DEVICE_DRAWS", 64)
+    fx = _replay.load_traj(name)
+    o = _replay.construct(fx, obe.OptBayesExpt, obe.OptBayesExptNoiseParameter,
+                          device_models()[fx["meta"]["model"]])
+    _replay.replay(fx, o, _replay.HIP_RTOL[name], get_draw_idx=lambda x: x.last_draw_indices,
+                   floor_units=_replay.NUDGE_FLOOR_UNITS[name])
+    ref = np.random.default_rng(fx["meta"]["seed"])
+    assert o.rng.bit_generator.state["state"]["inc"] == ref.bit_generator.state["state"]["inc"]
+
+
 @pytest.mark.parametrize("name", ["lorentz3_opt", "line_noiseparam"])
 def test_trajectory_strict_cdf(hip, name):
     """Same replay with the serial-order CDF (tuning_parameters['strict_cdf'])."""
