@@ -88,6 +88,9 @@ class ParticlePDF:
         n, d = self.n_particles, self.n_dims
         n_settings, n_channels = self._scratch_dims()
         nbytes = self._lib.workspace_bytes(n, n_settings, n_channels, d)
+        n_local = getattr(self, "_s_end", n_settings) - getattr(self, "_s_begin", 0)
+        if 0 < n_local < n_settings:       # a settings shard plans its sweep for its own slice
+            nbytes = max(nbytes, self._lib.workspace_bytes(n, n_local, n_channels, d))
         self._ws = torch.empty(nbytes // 8 + 1, dtype=torch.float64, device=self._device)
         self._ws_bytes = self._ws.numel() * 8
         self._moments_dev = torch.zeros(self._lib.moments_len(d), dtype=torch.float64, device=self._device)
