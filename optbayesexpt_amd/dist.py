@@ -83,8 +83,9 @@ class SettingsShard:
         w = self.world_size
         if w == 1:
             return record.cpu().reshape(1, 4)
-        gathered = torch.empty(4 * w, dtype=torch.float64, device=record.device)
-        dist.all_gather_into_tensor(gathered, record.contiguous(), group=self.group)
+        dev = self._comm_device(record.device)        # nccl: stay on the GPU; gloo: host tensors
+        gathered = torch.empty(4 * w, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(gathered, record.contiguous().to(dev), group=self.group)
         return gathered.cpu().reshape(w, 4)
 
     @staticmethod

@@ -1,0 +1,74 @@
+"""Two processes sharing the one GPU of the test box, torch.distributed backend gloo: the
+whole sharded measurement cycle (settings slices, record all-gather, lock-step adaptive
+shift, replicated update and seeded resample, sharded good_setting) with real multi-process
+semantics.  RCCL needs one GPU per rank, so N > 1 over RCCL itself is left to the 8-GPU
+scaling run; the collective calls are the same."""
+import os
+import socket
+import warnings
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _cycle_log(obe_mod, shard, n_cycles=8):
+    import bench
+    settings, prior, cons, true, sigma = bench.make_workload("c2")
+    sv = (np.ascontiguousarray(settings[0][::4]),)           # 1024 settings x 262144 particles
+    o = obe_mod.OptBayesExpt(obe_mod.models.lorentzian(), sv, prior.copy(), cons, scale=False,
+                             utility_method="variance_full", default_noise_std=sigma, settings_shard=shard)
+    o.rng = np.random.default_rng(21)
+    sim = np.random.default_rng(22)
+    log = []
+    for cyc in range(n_cycles):
+        x = o.opt_setting() if cyc % 3 else o.good_setting(pickiness=19)
+        y = float(o.model_function(x, true, cons)) + sigma * sim.standard_normal()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            o.pdf_update((x, y, sigma))
+        log.append((int(o.last_setting_index), bool(o.just_resampled), bool(o.last_sweep["shifted"]),
+                    o.mean().tolist()))
+    util = o.utility()
+    return log, util
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import optbayesexpt_amd as obe_mod
+        log, util = _cycle_log(obe_mod, obe_mod.SettingsShard())
+        ret[rank] = (log, util)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_share_one_gpu(hip):
+    import optbayesexpt_amd as obe_mod
+    ref_log, ref_util = _cycle_log(obe_mod, None)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    for rank in (0, 1):
+        log, util = ret[rank]
+        assert [l[:2] for l in log] == [l[:2] for l in ref_log]            # settings and resamples
+        for a, b in zip(log, ref_log):
+            np.testing.assert_allclose(a[3], b[3], rtol=1e-11)
+        np.testing.assert_allclose(util, ref_util, rtol=1e-12)
+    assert [l[2] for l in ret[0][0]] == [l[2] for l in ret[1][0]]           # lock-step shift decisions
+    assert sum(l[1] for l in ref_log) >= 1
