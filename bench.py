@@ -124,6 +124,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # test hooks (flow check on a 1-GPU box): OBE_BENCH_BACKEND=gloo OBE_BENCH_ONE_DEVICE=1 lets
+    # several ranks share cuda:0; the numbers of such a run mean nothing
+    backend = os.environ.get("OBE_BENCH_BACKEND", "nccl")
+    if os.environ.get("OBE_BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     shard = None
     use_dist = world > 1 or args.force_dist
@@ -139,8 +144,11 @@ def main():
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            warm = torch.zeros(4, dtype=torch.float64, device="cuda")
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend)
+            warm = torch.zeros(4, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(warm)
             torch.cuda.synchronize()
         finally:
@@ -190,7 +198,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
