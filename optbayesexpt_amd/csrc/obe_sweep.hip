@@ -31,6 +31,12 @@ namespace obe {
 
 constexpr int kSweepLdsDoubles = 4096;   // 32 KiB tile per workgroup -> 4-5 workgroups per CU
 constexpr int kMaxChunks = 1024;
+constexpr int kFinMaxBlocks = 65536;     // finalize workgroups (64 settings each) the argmax partials hold
+constexpr int kFinSettings = kWave;      // settings per finalize workgroup
+
+static int64_t argmax_slots(int64_t n_settings) {
+    return std::max<int64_t>(kMaxBlocks, (n_settings + kFinSettings - 1) / kFinSettings);
+}
 
 struct SweepPlan {
     int spt;           // settings per thread
@@ -65,7 +71,7 @@ static int64_t sweep_ws_doubles(int64_t ns, int64_t nd, int nc) {
     const SweepPlan p = plan_sweep(ns, nd);
     return 2 * (int64_t)p.nchunks * nc * ns      // partial S1, S2
            + (int64_t)nc * ns                      // per-setting shift
-           + 3 * (int64_t)kMaxBlocks + 16;         // argmax / kappa partials + scalars
+           + 3 * argmax_slots(ns) + 16;            // argmax / kappa partials + scalars
 }
 
 struct SweepArgs {
@@ -255,7 +261,13 @@ __device__ __forceinline__ void block_argmax(Best b, double* bv, int64_t* bi) {
     }
 }
 
-// folds the chunk partials -> yvar, utility; per-block first-max
+// folds the chunk partials -> yvar, utility; per-block first-max.
+// A workgroup owns 64 consecutive settings; its 4 wavefronts each sum a quarter of the
+// chunks (coalesced 512-byte rows, independent loads in flight), the quarters are combined
+// in a fixed order through LDS.  (One thread per setting walking all chunks serially was
+// latency-bound: 100+ us at 512 chunks.)
+constexpr int kFinGroups = kBlock / kWave;          // chunk groups = wavefronts
+
 __global__ __launch_bounds__(kBlock) void sweep_finalize(const double* __restrict__ part1,
                                                          const double* __restrict__ part2, int nchunks, int nc,
                                                          int64_t ns, const double* __restrict__ moments,
@@ -265,17 +277,35 @@ __global__ __launch_bounds__(kBlock) void sweep_finalize(const double* __restric
                                                          double* __restrict__ utility, double* __restrict__ bv,
                                                          int64_t* __restrict__ bi, double* __restrict__ bk) {
     __shared__ double red[kBlock];
+    __shared__ double acc1[OBE_MAX_CHANNELS][kFinGroups][kFinSettings];
+    __shared__ double acc2[OBE_MAX_CHANNELS][kFinGroups][kFinSettings];
     const double W = full_mode ? moments[0] : 1.0;
-    Best best{-INFINITY, INT64_MAX};
-    double kappa = 0.0;     // worst (mean of y')^2 / var: the cancellation an UNSHIFTED sweep would suffer
-    for (int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x; s < ns; s += (int64_t)gridDim.x * kBlock) {
-        double var[OBE_MAX_CHANNELS];
-        for (int c = 0; c < nc; ++c) {
-            double a1 = 0.0, a2 = 0.0;
-            for (int k = 0; k < nchunks; ++k) {
+    const int lane = threadIdx.x & (kWave - 1), grp = threadIdx.x / kWave;
+    const int64_t s = (int64_t)blockIdx.x * kFinSettings + lane;
+    for (int c = 0; c < nc; ++c) {
+        double a1 = 0.0, a2 = 0.0;
+        if (s < ns) {
+#pragma unroll 4
+            for (int k = grp; k < nchunks; k += kFinGroups) {
                 const int64_t o = ((int64_t)k * nc + c) * ns + s;
                 a1 += part1[o];
                 a2 += part2[o];
+            }
+        }
+        acc1[c][grp][lane] = a1;
+        acc2[c][grp][lane] = a2;
+    }
+    __syncthreads();
+    Best best{-INFINITY, INT64_MAX};
+    double kappa = 0.0;     // worst (mean of y')^2 / var: the cancellation an UNSHIFTED sweep would suffer
+    if (grp == 0 && s < ns) {
+        double var[OBE_MAX_CHANNELS];
+        for (int c = 0; c < nc; ++c) {
+            double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+            for (int g = 0; g < kFinGroups; ++g) {
+                a1 += acc1[c][g][lane];
+                a2 += acc2[c][g][lane];
             }
             const double mu = a1 / W;
             double v = (a2 - a1 * mu) / W;
@@ -288,8 +318,7 @@ __global__ __launch_bounds__(kBlock) void sweep_finalize(const double* __restric
         }
         const double u = utility_of(var, nc, s, ua);
         utility[s] = u;
-        Best cand{u, s};
-        if (better(cand, best)) best = cand;
+        best = Best{u, s};
     }
     block_argmax(best, bv, bi);
     red[threadIdx.x] = kappa;
@@ -388,16 +417,17 @@ struct SweepWs {
     double* cs;
 };
 
-static int carve_sweep_ws(void* d_ws, int64_t ws_bytes, int64_t part_doubles, int64_t cs_doubles, SweepWs& w) {
-    const int64_t need = (2 * part_doubles + cs_doubles + 3 * (int64_t)kMaxBlocks + 16) * sizeof(double);
+static int carve_sweep_ws(void* d_ws, int64_t ws_bytes, int64_t part_doubles, int64_t cs_doubles, SweepWs& w,
+                          int64_t slots = kMaxBlocks) {
+    const int64_t need = (2 * part_doubles + cs_doubles + 3 * slots + 16) * sizeof(double);
     if (!d_ws || ws_bytes < need) return bad_arg("sweep workspace too small");
     double* base = static_cast<double*>(d_ws);
     w.out_v = base;                                     // [0] best value, [1] worst cancellation factor
     w.out_i = reinterpret_cast<int64_t*>(base + 8);     // [8]
     w.bv = base + 16;
-    w.bi = reinterpret_cast<int64_t*>(base + 16 + kMaxBlocks);
-    w.bk = base + 16 + 2 * kMaxBlocks;
-    w.cs = base + 16 + 3 * kMaxBlocks;
+    w.bi = reinterpret_cast<int64_t*>(base + 16 + slots);
+    w.bk = base + 16 + 2 * slots;
+    w.cs = base + 16 + 3 * slots;
     w.part1 = w.cs + cs_doubles;
     w.part2 = w.part1 + part_doubles;
     return 0;
@@ -456,7 +486,7 @@ static int prepare_sweep(const obe_model* m, obe_model& mm, const double* d_sett
     if (nd <= 0) return bad_arg("sweep: n_draws must be positive");
     plan = plan_sweep(ns, nd);
     const int64_t part = (int64_t)plan.nchunks * mm.n_channels * ns;
-    if (int rc = carve_sweep_ws(d_ws, ws_bytes, part, (int64_t)mm.n_channels * ns, w)) return rc;
+    if (int rc = carve_sweep_ws(d_ws, ws_bytes, part, (int64_t)mm.n_channels * ns, w, argmax_slots(ns))) return rc;
     a.cs_out = w.cs;
     a.m = mm;
     a.settings = d_settings;
@@ -513,7 +543,8 @@ int obe_sweep_utility(const obe_model* m, const double* d_settings, int64_t ld_s
     int rc = dispatch_model(mm, [&](auto M) -> int { return launch_sweep<decltype(M)>(plan, a, shifted != 0, st); });
     if (rc) return rc;
     UtilArgs ua{d_noise_var, noise_ld, d_cost, cost_scalar};
-    const int nb = stream_blocks(n_settings, kBlock);
+    const int nb = static_cast<int>((n_settings + kFinSettings - 1) / kFinSettings);
+    if (nb > kFinMaxBlocks) return bad_arg("obe_sweep_utility: more than 4 194 304 settings per call");
     sweep_finalize<<<nb, kBlock, 0, st>>>(w.part1, w.part2, plan.nchunks, mm.n_channels, n_settings, d_moments,
                                           d_draw_idx == nullptr, ua, w.cs, d_yvar, d_utility, w.bv, w.bi, w.bk);
     OBE_CHECK_LAUNCH("sweep_finalize");

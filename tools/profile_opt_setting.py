@@ -12,8 +12,10 @@ class _Solo(SettingsShard):
         g[self.rank] = record.cpu()
         return g
 
-settings, prior, cons, true, sigma = bench.make_workload("c3")
-obe = bench.build_obe("c3", _Solo(rank=0, world_size=8), settings, prior.copy(), cons)
+cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
+world = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+settings, prior, cons, true, sigma = bench.make_workload(cfg)
+obe = bench.build_obe(cfg, _Solo(rank=0, world_size=world) if world > 1 else None, settings, prior.copy(), cons)
 obe.rng = np.random.default_rng(1)
 for _ in range(3):
     x = obe.opt_setting(); obe.pdf_update((x, 49000.0, sigma))
@@ -38,5 +40,5 @@ from optbayesexpt_amd.particlepdf import _ptr
 lib = _lib.load(); ms = ctypes.c_float()
 p, w = obe._pw_tensors(); mom = obe._moments_on_device()
 n_local = obe._s_end - obe._s_begin
-lib.call("obe_sweep_kernel_time", obe._model_struct, ctypes.c_void_p(obe._settings_dev.data_ptr()), 65536, n_local, _ptr(p), p.shape[1], p.shape[1], _ptr(w), _ptr(mom), 0, _ptr(obe._ws), obe._ws_bytes, 10, ctypes.byref(ms), obe._stream())
+lib.call("obe_sweep_kernel_time", obe._model_struct, ctypes.c_void_p(obe._settings_dev.data_ptr()), obe._n_settings, n_local, _ptr(p), p.shape[1], p.shape[1], _ptr(w), _ptr(mom), 0, _ptr(obe._ws), obe._ws_bytes, 10, ctypes.byref(ms), obe._stream())
 print("K1 kernel alone (unshifted) us:", 1e3 * ms.value)
