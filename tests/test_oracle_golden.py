@@ -198,3 +198,29 @@ def test_likelihood_two_channel_choke():
                                     np.ones((4, n)), (), choke=0.6, n_channels=2)
     got = obe.likelihood(u["lk_ym"], ((1.0,), (0.3, -0.2), (1.5, 0.7)))
     assert_allclose(got, u["lk_out"], rtol=1e-15)
+
+
+def test_c_restatement_agrees_with_numpy_oracle_and_reference():
+    """oracle/csweep.c (plain C, OpenMP) against the NumPy oracle and, at uniform weights,
+    against the real reference's full-sweep golden vector."""
+    from oracle import csweep
+    f = _replay.load("full_sweep_uniform.npz")
+    g = np.random.default_rng(8)
+    for tag, k, fn in (("lor", 1, models.lorentzian), ("ml7", 7, models.multi_lorentzian(7))):
+        prior, x = f[f"fs_{tag}_prior"], f["fs_lor_x"]
+        n = prior.shape[1]
+        uni = np.full(n, 1.0 / n)
+        assert_allclose(csweep.lorentz_yvar(x, prior, uni, 0.1, k), f[f"fs_{tag}_yvar"][0], rtol=1e-11)
+        w = g.exponential(1.0, n)
+        w /= w.sum()
+        ref = oracle.yvar_full_sweep(fn, oracle.flatten_settings((x,)), prior, w, (0.1,))[0]
+        assert_allclose(csweep.lorentz_yvar(x, prior, w, 0.1, k), ref, rtol=1e-11)
+    prior = f["fs_lor_prior"]
+    w = g.exponential(1.0, prior.shape[1])
+    w /= w.sum()
+    lik = oracle.gauss_likelihood(models.lorentzian((3.1,), prior, (0.1,)), 49200.0, 400.0)
+    got, s2 = csweep.lorentz_update(3.1, 49200.0, 400.0, prior, w, 0.1)
+    want = oracle.normalized_product(w, lik)
+    assert_allclose(got, want, rtol=1e-12)
+    assert_allclose(s2, np.sum(want * want), rtol=1e-12)
+    assert csweep.threads() >= 1
