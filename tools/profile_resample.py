@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from optbayesexpt_amd import _devrng
-settings, prior, cons, true, sigma = bench.make_workload("c3")
+settings, prior, cons, true, sigma = bench.make_workload(sys.argv[1] if len(sys.argv) > 1 else "c3")
 import optbayesexpt_amd as obe
 pdf = obe.ParticlePDF(prior.copy(), scale=False)
 g = np.random.default_rng(3)
