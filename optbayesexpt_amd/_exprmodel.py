@@ -28,9 +28,8 @@ _CONSTS = {"pi": float(np.pi), "e": float(np.e)}
 
 
 class _ToC(ast.NodeVisitor):
-    def __init__(self, names, fast_division=False):
+    def __init__(self, names):
         self.names = names
-        self.fast_division = fast_division
 
     def visit_Expression(self, node):
         return self.visit(node.body)
@@ -64,8 +63,6 @@ class _ToC(ast.NodeVisitor):
         if isinstance(node.op, ast.Mult):
             return f"({a} * {b})"
         if isinstance(node.op, ast.Div):
-            if self.fast_division:
-                return f"({a} * guarded_rcp({b}))"      # sweep form: ~10 issue slots instead of ~28
             return f"({a} / {b})"
         if isinstance(node.op, ast.Pow):
             if isinstance(node.right, ast.Constant) and node.right.value == 2:
@@ -87,6 +84,254 @@ class _ToC(ast.NodeVisitor):
         raise ValueError(f"unsupported syntax: {type(node).__name__}")
 
 
+# ---------------------------------------------------------------------------
+# Sweep form.  The K1 kernel evaluates the model ns x n times, so the generated sweep code
+# is a small compiler pass over the expression rather than a transliteration:
+#   * every node has a level: C (constants only), S (settings), P (parameters, sqrt(w)), SP;
+#   * maximal S-level subtrees are computed once per setting (prep_setting -> xs slots),
+#     maximal C/P-level subtrees once per particle (pack -> pk slots, staged through LDS);
+#   * products are distributed / re-associated when that moves work out of the SP level
+#     ((x - x0)/d -> x/d - x0/d;  sw*(b + a*r) -> (sw*a)*r + sw*b);
+#   * divisions by SP-level denominators are batched over the SPT settings a lane owns
+#     (batch_rcp_guarded: one v_rcp_f64 per batch); a*b + c is emitted as fma.
+# Only the sweep uses this form (utilities agree with the exact form to ~1e-13 relative);
+# the Bayes update and eval_over_* use the exact one-operation-per-node `formula`.
+_LC, _LS, _LP, _LSP = 0, 1, 2, 3
+
+
+class _Node:
+    __slots__ = ("op", "args", "val", "level", "key")
+
+    def __init__(self, op, args=(), val=None, level=None):
+        self.op, self.args, self.val = op, tuple(args), val
+        if level is None:
+            level = 0
+            for a in self.args:
+                level |= a.level
+        self.level = level
+        self.key = (op, val, tuple(a.key for a in self.args))
+
+
+def _num(v):
+    return _Node("num", val=float(v), level=_LC)
+
+
+def _mul(a, b):
+    """a*b, pushing a non-SP factor into an SP-level sum / product / quotient when that
+    takes at least one multiplication out of the SP level."""
+    for x, f in ((a, b), (b, a)):
+        if f.op == "num" and f.val == 1.0:
+            return x
+        if x.level != _LSP or f.level == _LSP:
+            continue
+        if x.op in ("add", "sub") and any((t.level | f.level) != _LSP for t in x.args):
+            return _Node(x.op, (_mul(x.args[0], f), _mul(x.args[1], f)))
+        if x.op == "neg":
+            return _Node("neg", (_mul(x.args[0], f),))
+        if x.op == "mul":
+            p, q = x.args
+            if (p.level | f.level) != _LSP:
+                return _mul(_mul(p, f), q)
+            if (q.level | f.level) != _LSP:
+                return _mul(p, _mul(q, f))
+        if x.op == "div" and (x.args[0].level | f.level) != _LSP:
+            return _div(_mul(x.args[0], f), x.args[1])
+    return _Node("mul", (a, b))
+
+
+def _div(a, b):
+    if (a.level | b.level) != _LSP or b.level == _LSP:
+        return _Node("div", (a, b))
+    return _mul(a, _Node("div", (_num(1.0), b)))      # reciprocal hoisted to b's level
+
+
+class _SweepBuilder(ast.NodeVisitor):
+    def __init__(self, settings, parameters, constants):
+        self.sets = {n: k for k, n in enumerate(settings)}
+        self.pars = {n: k for k, n in enumerate(parameters)}
+        self.cons = {n: k for k, n in enumerate(constants)}
+
+    def visit_Expression(self, node):
+        return self.visit(node.body)
+
+    def visit_Constant(self, node):
+        if isinstance(node.value, bool) or not isinstance(node.value, (int, float)):
+            raise ValueError(f"unsupported constant {node.value!r}")
+        return _num(node.value)
+
+    def visit_Name(self, node):
+        if node.id in self.sets:
+            return _Node("set", val=self.sets[node.id], level=_LS)
+        if node.id in self.pars:
+            return _Node("par", val=self.pars[node.id], level=_LP)
+        if node.id in self.cons:
+            return _Node("con", val=self.cons[node.id], level=_LC)
+        if node.id in _CONSTS:
+            return _num(_CONSTS[node.id])
+        raise ValueError(f"unknown name {node.id!r}")
+
+    def visit_UnaryOp(self, node):
+        v = self.visit(node.operand)
+        if isinstance(node.op, ast.USub):
+            return _Node("neg", (v,))
+        if isinstance(node.op, ast.UAdd):
+            return v
+        raise ValueError("unsupported unary operator")
+
+    def visit_BinOp(self, node):
+        a, b = self.visit(node.left), self.visit(node.right)
+        if isinstance(node.op, ast.Add):
+            return _Node("add", (a, b))
+        if isinstance(node.op, ast.Sub):
+            return _Node("sub", (a, b))
+        if isinstance(node.op, ast.Mult):
+            return _mul(a, b)
+        if isinstance(node.op, ast.Div):
+            return _div(a, b)
+        if isinstance(node.op, ast.Pow):
+            if b.op == "num" and b.val == 2.0:
+                return _Node("sq", (a,))
+            if b.op == "num" and b.val == 0.5:
+                return _Node("call", (a,), val="sqrt")
+            return _Node("call", (a, b), val="pow")
+        raise ValueError("unsupported binary operator")
+
+    def visit_Call(self, node):
+        if not isinstance(node.func, ast.Name) or node.func.id not in _FUNCS or node.keywords:
+            raise ValueError("unsupported function call")
+        cname, _, arity = _FUNCS[node.func.id]
+        if len(node.args) != arity:
+            raise ValueError(f"{node.func.id} takes {arity} argument(s)")
+        return _Node("call", [self.visit(a) for a in node.args], val=cname)
+
+    def generic_visit(self, node):
+        raise ValueError(f"unsupported syntax: {type(node).__name__}")
+
+
+class _SweepEmitter:
+    """C code for prep_setting (xs slots), pack (pk slots) and the phased sweep_eval body."""
+
+    def __init__(self):
+        self.xs_slots, self.pk_slots = {}, {}     # node key -> slot index
+        self.prep, self.pack = [], []             # C statements filling the slots
+        self.phases, self.memo = [], {}
+        self.count = 0
+
+    # exact (one operation per node) form of a hoisted subtree, inside prep_setting / pack
+    def exact(self, n):
+        a = [self.exact(c) for c in n.args]
+        if n.op == "num":
+            return repr(n.val)
+        if n.op == "set":
+            return f"x[{n.val}]"
+        if n.op == "par":
+            return f"th({n.val})"
+        if n.op == "con":
+            return f"m.consts[{n.val}]"
+        if n.op == "sw":
+            return "sw"
+        if n.op == "neg":
+            return f"(-{a[0]})"
+        if n.op == "sq":
+            return f"sq({a[0]})"
+        if n.op == "call":
+            return f"{n.val}({', '.join(a)})"
+        return f"({a[0]} {dict(add='+', sub='-', mul='*', div='/')[n.op]} {a[1]})"
+
+    def slot(self, n):
+        if n.level == _LS:
+            k = self.xs_slots.setdefault(n.key, len(self.xs_slots))
+            if k == len(self.prep):
+                self.prep.append(f"        xs[{k}] = {self.exact(n)};")
+            return f"xs[j][{k}]"
+        k = self.pk_slots.setdefault(n.key, len(self.pk_slots))
+        if k == len(self.pack):
+            self.pack.append(f"        pk[{k}] = {self.exact(n)};")
+        return f"pk[{k}]"
+
+    def temp(self, code):
+        k = self.count
+        self.count += 1
+        self.phases.append(f"        double t{k}[SPT];\n"
+                           f"        _Pragma(\"unroll\") for (int j = 0; j < SPT; ++j) t{k}[j] = {code};")
+        return f"t{k}[j]"
+
+    def factors(self, n):
+        """(a, b) when the SP-level node is a product a*b that a parent sum can fuse."""
+        if n.level != _LSP:
+            return None
+        if n.op == "mul":
+            return self.emit(n.args[0]), self.emit(n.args[1])
+        if n.op == "sq":
+            a = self.emit(n.args[0])
+            if n.args[0].level == _LSP and not a.startswith(("t", "r")):
+                a = self.memo[n.args[0].key] = self.temp(a)
+            return a, a
+        if n.op == "div":
+            r = self.reciprocal(n.args[1])
+            if n.args[0].op == "num" and n.args[0].val == 1.0:
+                return None
+            return self.emit(n.args[0]), r
+        return None
+
+    def reciprocal(self, den):
+        key = ("rcp", den.key)
+        if key not in self.memo:
+            k = self.count
+            self.count += 1
+            self.phases.append(
+                f"        double den{k}[SPT], r{k}[SPT];\n"
+                f"        _Pragma(\"unroll\") for (int j = 0; j < SPT; ++j) den{k}[j] = {self.emit(den)};\n"
+                f"        batch_rcp_guarded<SPT>(den{k}, r{k});")
+            self.memo[key] = f"r{k}[j]"
+        return self.memo[key]
+
+    def emit(self, n):
+        if n.op == "num":
+            return repr(n.val)
+        if n.level != _LSP:
+            return self.slot(n)
+        if n.key in self.memo:
+            return self.memo[n.key]
+        a, b = (n.args + (None, None))[:2]
+        if n.op in ("add", "sub"):
+            fa, fb = self.factors(a), self.factors(b)
+            if fb is not None:
+                code = f"fma({'-' if n.op == 'sub' else ''}{fb[0]}, {fb[1]}, {self.emit(a)})"
+            elif fa is not None:
+                code = f"fma({fa[0]}, {fa[1]}, {'-' if n.op == 'sub' else ''}{self.emit(b)})"
+            else:
+                code = f"({self.emit(a)} {'+' if n.op == 'add' else '-'} {self.emit(b)})"
+        elif n.op in ("mul", "sq"):
+            f = self.factors(n)
+            code = f"({f[0]} * {f[1]})"
+        elif n.op == "div":
+            f = self.factors(n)
+            code = self.reciprocal(b) if f is None else f"({f[0]} * {f[1]})"
+        elif n.op == "neg":
+            code = f"(-{self.emit(a)})"
+        elif n.op == "call":
+            code = f"{n.val}({', '.join(self.emit(c) for c in n.args)})"
+        else:
+            raise AssertionError(n.op)
+        self.memo[n.key] = code
+        return code
+
+
+def _sweep_code(trees, settings, parameters, constants):
+    """(prep_setting body, NXS, pack body, NPK, sweep_eval body) of the generated model."""
+    build = _SweepBuilder(settings, parameters, constants)
+    sw = _Node("sw", level=_LP)
+    em = _SweepEmitter()
+    out = []
+    for c, t in enumerate(trees):
+        root = _mul(build.visit(t), sw)                        # the kernel wants sqrt(w) * y
+        out.append(f"        _Pragma(\"unroll\") for (int j = 0; j < SPT; ++j) v[j][{c}] = {em.emit(root)};")
+    nl = "\n"
+    return (nl.join(em.prep), max(1, len(em.xs_slots)), nl.join(em.pack), max(1, len(em.pk_slots)),
+            nl.join(em.phases + out))
+
+
 def _check_names(names):
     seen = set()
     for n in names:
@@ -105,13 +350,12 @@ def translate(expressions, settings, parameters, constants):
     names = set(settings + parameters + constants)
     trees = [ast.parse(e.strip(), mode="eval") for e in expressions]
     c_exprs = [_ToC(names).visit(t) for t in trees]
-    c_fast = [_ToC(names, fast_division=True).visit(t) for t in trees]
+    prep_body, nxs, pack_body, npk, sweep_body = _sweep_code(trees, settings, parameters, constants)
     ns, nc, npar, ncon = len(settings), len(expressions), len(parameters), len(constants)
     decl = [f"        const double u_{n} = x_[{i}];" for i, n in enumerate(settings)]
     decl += [f"        const double u_{n} = th_[{i}];" for i, n in enumerate(parameters)]
     decl += [f"        const double u_{n} = c_[{i}];" for i, n in enumerate(constants)]
     body = [f"        y_[{c}] = {e};" for c, e in enumerate(c_exprs)]
-    body_fast = [f"        y_[{c}] = {e};" for c, e in enumerate(c_fast)]
     nl = "\n"
     header = f"""// generated by optbayesexpt_amd.models.from_expression — do not edit
 // settings {settings}, parameters {parameters}, constants {constants}
@@ -119,7 +363,7 @@ def translate(expressions, settings, parameters, constants):
 #pragma once
 namespace obe {{
 struct PluginModel {{
-    static constexpr int NS = {ns}, NC = {nc}, NREAD = {npar}, NCONST = {ncon}, NXS = {ns}, NPK = {npar};
+    static constexpr int NS = {ns}, NC = {nc}, NREAD = {npar}, NCONST = {ncon}, NXS = {nxs}, NPK = {npk};
     __device__ __forceinline__ static double sq(double v) {{ return v * v; }}
     __device__ __forceinline__ static void formula(const double* x_, const double* th_, const double* c_,
                                                    double* y_) {{
@@ -127,46 +371,27 @@ struct PluginModel {{
         (void)x_; (void)th_; (void)c_;
 {nl.join(body)}
     }}
-    // 1/b for the flop-bound sweep: v_rcp_f64 + one cubic correction (~1 ulp); falls back to the
-    // raw reciprocal for b = 0 / inf / NaN so that a/0 = inf and a/inf = 0 as in IEEE division
-    __device__ __forceinline__ static double guarded_rcp(double b) {{
-        const double r0 = __builtin_amdgcn_rcp(b);
-        const double e = fma(-b, r0, 1.0);
-        const double r = fma(r0, fma(e, e, e), r0);
-        return r == r ? r : r0;
-    }}
-    // the same formula with divisions as multiplications by guarded_rcp (sweep only; the
-    // Bayes update and eval_over_* use the exact IEEE form above)
-    __device__ __forceinline__ static void formula_fast(const double* x_, const double* th_, const double* c_,
-                                                        double* y_) {{
-{nl.join(decl)}
-        (void)x_; (void)th_; (void)c_;
-{nl.join(body_fast)}
-    }}
     __device__ static void eval(const double* x, const ParamRef& th, const obe_model& m, double* y) {{
         double t[NREAD];
 #pragma unroll
         for (int i = 0; i < NREAD; ++i) t[i] = th(i);
         formula(x, t, m.consts, y);
     }}
-    __device__ static void prep_setting(const double* x, const obe_model&, double* xs) {{
-#pragma unroll
-        for (int k = 0; k < NS; ++k) xs[k] = x[k];
+    // sweep form (see _exprmodel.py): per-setting terms -> xs, per-particle terms (times
+    // sqrt(w) where it folds in) -> pk, the rest batched over the SPT settings of a lane
+    __device__ static void prep_setting(const double* x, const obe_model& m, double* xs) {{
+        (void)x; (void)m; (void)xs;
+{prep_body}
     }}
-    __device__ static void pack(const ParamRef& th, const double*, const obe_model&, double, double* pk) {{
-#pragma unroll
-        for (int i = 0; i < NREAD; ++i) pk[i] = th(i);
+    __device__ static void pack(const ParamRef& th, const double*, const obe_model& m, double sw, double* pk) {{
+        (void)th; (void)m; (void)sw; (void)pk;
+{pack_body}
     }}
     template <int SPT>
-    __device__ __forceinline__ static void sweep_eval(const double (&xs)[SPT][NXS], const double* pk, double sw,
-                                                      const obe_model& m, double (&v)[SPT][NC]) {{
-#pragma unroll
-        for (int j = 0; j < SPT; ++j) {{
-            double y[NC];
-            formula_fast(xs[j], pk, m.consts, y);
-#pragma unroll
-            for (int c = 0; c < NC; ++c) v[j][c] = sw * y[c];
-        }}
+    __device__ __forceinline__ static void sweep_eval(const double (&xs)[SPT][NXS], const double* pk, double,
+                                                      const obe_model&, double (&v)[SPT][NC]) {{
+        (void)xs; (void)pk;
+{sweep_body}
     }}
 }};
 }}  // namespace obe

@@ -34,15 +34,18 @@ __device__ __forceinline__ double fast_rcp(double q) {
 
 // Batch inversion: r[j] = 1/q[j] for N values from one reciprocal of their product
 // (3(N-1) multiplies + 1 rcp instead of N rcp + 4N Newton FMAs).  q >= 1 on every
-// caller, so the product cannot underflow; it overflows only beyond q ~ 1e77.
+// direct caller, so the product cannot underflow; it overflows only beyond q ~ 1e77.
+// Returns the reciprocal of the whole product (batch_rcp_guarded's range check).
 template <int N>
-__device__ __forceinline__ void batch_rcp(const double (&q)[N], double (&r)[N]) {
+__device__ __forceinline__ double batch_rcp(const double (&q)[N], double (&r)[N]) {
     if constexpr (N == 1) {
         r[0] = fast_rcp(q[0]);
+        return r[0];
     } else if constexpr (N == 2) {
         const double inv = fast_rcp(q[0] * q[1]);
         r[0] = inv * q[1];
         r[1] = inv * q[0];
+        return inv;
     } else if constexpr (N == 4) {
         const double p01 = q[0] * q[1], p23 = q[2] * q[3];
         const double inv = fast_rcp(p01 * p23);
@@ -51,6 +54,7 @@ __device__ __forceinline__ void batch_rcp(const double (&q)[N], double (&r)[N]) 
         r[1] = i01 * q[0];
         r[2] = i23 * q[3];
         r[3] = i23 * q[2];
+        return inv;
     } else {
         static_assert(N == 8, "batch_rcp: N must be 1, 2, 4 or 8");
         const double p01 = q[0] * q[1], p23 = q[2] * q[3], p45 = q[4] * q[5], p67 = q[6] * q[7];
@@ -66,6 +70,48 @@ __device__ __forceinline__ void batch_rcp(const double (&q)[N], double (&r)[N]) 
         r[5] = i45 * q[4];
         r[6] = i67 * q[7];
         r[7] = i67 * q[6];
+        return inv;
+    }
+}
+
+// 1/b with IEEE behaviour at the edges (b = 0 -> inf, b = inf -> 0, NaN -> NaN): the raw
+// v_rcp_f64 result is returned whenever the correction step produced a NaN.
+__device__ __forceinline__ double guarded_rcp(double b) {
+    const double r0 = __builtin_amdgcn_rcp(b);
+    const double e = fma(-b, r0, 1.0);
+    const double r = fma(r0, fma(e, e, e), r0);
+    return r == r ? r : r0;
+}
+
+// Batch inversion for denominators that are not known to be >= 1 (generated expression
+// models).  The batch runs over the N/2 pair products; it is accepted when their magnitudes
+// sum to < 1e30 (no overflow, inf or NaN) and the reciprocal of the whole product is
+// < 1e200 in magnitude: then every partial product inside batch_rcp lies in
+// (1e-290, 1e120) — no zero, no subnormal that would lose bits.  Otherwise every element
+// gets its own guarded reciprocal (IEEE results for 0, inf and NaN).
+template <int N>
+__device__ __forceinline__ void batch_rcp_guarded(const double (&q)[N], double (&r)[N]) {
+    if constexpr (N == 1) {
+        r[0] = guarded_rcp(q[0]);
+    } else {
+        double pp[N / 2], ip[N / 2];
+        double mag = 0.0;
+#pragma unroll
+        for (int h = 0; h < N / 2; ++h) {
+            pp[h] = q[2 * h] * q[2 * h + 1];
+            mag += fabs(pp[h]);
+        }
+        const double inv = batch_rcp<N / 2>(pp, ip);
+        if (mag < 1e30 && fabs(inv) < 1e200) {
+#pragma unroll
+            for (int h = 0; h < N / 2; ++h) {
+                r[2 * h] = ip[h] * q[2 * h + 1];
+                r[2 * h + 1] = ip[h] * q[2 * h];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < N; ++j) r[j] = guarded_rcp(q[j]);
+        }
     }
 }
 

@@ -552,7 +552,9 @@ def test_device_limits_4_settings_16_parameters_4_channels(obe):
     g = np.random.default_rng(404)
     n = 3000
     prior = np.vstack([g.normal(1.0, 0.3, (12, n)), g.uniform(0.5, 2.0, (4, n))])
-    sv = (np.linspace(0, 1, 3), np.linspace(-1, 1, 4), np.linspace(0, 3, 5), np.linspace(0.1, 2, 2))
+    # s0 > 0 and an asymmetric s1 grid: with s0 = 0 the formulas are even in s1, and settings
+    # +-1/3 would tie to the last bit (the winner then depends on rounding, not on the method)
+    sv = (np.linspace(0.2, 1, 3), np.linspace(-1, 1.4, 4), np.linspace(0, 3, 5), np.linspace(0.1, 2, 2))
     kw = dict(scale=False, noise_parameter_index=(12, 13, 14, 15))
     true = np.r_[np.ones(12), np.ones(4)]
     for method in ("variance_approx", "variance_full"):

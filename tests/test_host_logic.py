@@ -137,7 +137,12 @@ def test_expression_translator():
     pars = (g.uniform(2, 4, 1), g.uniform(-2000, -400, 1), g.normal(5e4, 1e3, 1))
     assert_array_equal(form((x,), pars, (0.1,)), omodels.lorentzian((x,), pars, (0.1,)))
     assert "struct PluginModel" in header and "NS = 1, NC = 1, NREAD = 3, NCONST = 1" in header
-    assert "sq(" in header and "guarded_rcp" in header and len(digest) == 16
+    assert "sq(" in header and len(digest) == 16
+    # the sweep form: x/d hoisted per setting, x0/d and sqrt(w)*a, sqrt(w)*b per particle, the
+    # division batched over the settings of a lane, the sums as FMAs
+    assert "NXS = 1, NPK = 3" in header and "xs[0] = (x[0] * (1.0 / m.consts[0]));" in header
+    assert "pk[1] = (th(1) * sw);" in header and "batch_rcp_guarded<SPT>" in header
+    assert "v[j][0] = fma(pk[1], r0[j], pk[2]);" in header
     assert _exprmodel.translate("b + a / (((x - x0) / d)**2 + 1)", ("x",), ("x0", "a", "b"), ("d",))[2] == digest
     rabi = ("baseline*(1 - exp(-t/T1)*contrast/2*(1 - cos(pi*2*hypot(df - fc, B1)*t))/(((df - fc)/B1)**2 + 1))")
     _, form2, _ = _exprmodel.translate(rabi, ("t", "df"), ("B1", "fc"), ("baseline", "contrast", "T1"))
