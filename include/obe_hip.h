@@ -146,6 +146,18 @@ int obe_moments(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t
  * inside that gap).  h_total (nullable) receives sum(w) (sync). */
 int obe_weight_cdf(const double* d_weights, int64_t n_particles, int32_t strict_order,
                    double* d_cdf, double* h_total, void* d_ws, int64_t ws_bytes, void* stream);
+/* ---- sweeper composition (demos/sweeper/obe_sweeper.py:122-149) ----
+ * obe_cumsum: out = np.cumsum(x) (strict_order as above; no normalisation).
+ * obe_interval_utility: utility[i] = (cum[stop_i] - cum[start_i]) / cost_i for the
+ * n_pairs (start, stop) index rows of d_pairs (int64, row-major (n_pairs, 2)) — the
+ * `(ends[:, 1] - ends[:, 0]) / cost` of sweep_utility(); cost_i = d_cost[i], or
+ * stop_i - start_i + cost_of_new_sweep (sweep_cost_estimate(), obe_sweeper.py:106-120)
+ * when d_cost == NULL.  Follow with obe_argmax. */
+int obe_cumsum(const double* d_x, int64_t n, int32_t strict_order, double* d_out,
+               void* d_ws, int64_t ws_bytes, void* stream);
+int obe_interval_utility(const double* d_cum, int64_t n_settings, const int64_t* d_pairs,
+                         int64_t n_pairs, const double* d_cost, double cost_of_new_sweep,
+                         double* d_utility, void* stream);
 /* idx[j] = #{i : cdf[i] <= u[j]}  (searchsorted side='right'), int64. */
 int obe_cdf_search(const double* d_cdf, int64_t n, const double* d_uniforms, int64_t n_draws,
                    int64_t* d_idx_out, void* stream);

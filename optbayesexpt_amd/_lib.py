@@ -70,6 +70,8 @@ _SIGNATURES = {
                                        _P, c_int64, _P, _P]),
     "obe_mask_nonpositive": (c_int, [_P, c_int64, c_int64, _P, c_int32, _P, _P, _P, c_int64, _P]),
     "obe_noise_var_from_moments": (c_int, [_P, c_int32, _P, c_int32, _P, _P]),
+    "obe_cumsum": (c_int, [_P, c_int64, c_int32, _P, _P, c_int64, _P]),
+    "obe_interval_utility": (c_int, [_P, c_int64, _P, c_int64, _P, c_double, _P, _P]),
     "obe_power_normalize": (c_int, [_P, c_int64, c_double, _P, _P, c_int64, _P]),
     "obe_sweep_utility": (c_int, [ctypes.POINTER(ObeModelStruct), _P, c_int64, c_int64, _P, c_int64, c_int64,
                                   _P, _P, c_int64, _P, c_int32, _P, c_int64, _P, c_double, _P, _P, _P, _P, _P,

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kBlock) void scan_offsets(double* __restrict__ bloc
 __global__ __launch_bounds__(kBlock) void scan_write_cdf(const double* __restrict__ w, int64_t n,
                                                          const double* __restrict__ block_off,
                                                          const double* __restrict__ scalars,
-                                                         double* __restrict__ cdf) {
+                                                         double* __restrict__ cdf, int normalize) {
     __shared__ double lds[kBlock / kWave];
     double v[kScanItems];
     const int64_t base = (int64_t)blockIdx.x * kScanTile;
@@ -87,7 +87,10 @@ __global__ __launch_bounds__(kBlock) void scan_write_cdf(const double* __restric
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
         const int64_t i = i0 + k;
-        if (i < n) cdf[i] = (i == n - 1) ? 1.0 : (off + v[k]) / total;   // cdf[-1]/cdf[-1] == 1
+        if (i < n) {
+            if (normalize) cdf[i] = (i == n - 1) ? 1.0 : (off + v[k]) / total;   // cdf[-1]/cdf[-1] == 1
+            else cdf[i] = off + v[k];
+        }
     }
 }
 
@@ -101,7 +104,7 @@ __device__ __forceinline__ double readlane_f64(double x, int lane) {
 // wavefront: a coalesced 64-wide load, then 64 dependent adds fed by v_readlane.
 __global__ __launch_bounds__(kWave) void cdf_strict_kernel(const double* __restrict__ w, int64_t n,
                                                            double* __restrict__ cdf,
-                                                           double* __restrict__ scalars) {
+                                                           double* __restrict__ scalars, int normalize) {
     const int lane = threadIdx.x;
     double run = 0.0;
     for (int64_t base = 0; base < n; base += kWave) {
@@ -116,6 +119,7 @@ __global__ __launch_bounds__(kWave) void cdf_strict_kernel(const double* __restr
         if (i < n) cdf[i] = mine;
     }
     if (lane == 0) scalars[0] = run;
+    if (!normalize) return;
     __threadfence_block();
     for (int64_t base = 0; base < n; base += kWave) {
         const int64_t i = base + lane;
@@ -207,30 +211,71 @@ using namespace obe;
 
 extern "C" {
 
-int obe_weight_cdf(const double* d_weights, int64_t n_particles, int32_t strict_order, double* d_cdf,
-                   double* h_total, void* d_ws, int64_t ws_bytes, void* stream) {
-    if (!d_weights || !d_cdf || n_particles <= 0) return bad_arg("obe_weight_cdf: bad pointer/size");
-    const int64_t nb = (n_particles + kScanTile - 1) / kScanTile;
+static int scan_common(const char* who, const double* d_x, int64_t n, int32_t strict_order, int normalize,
+                       double* d_out, double* h_total, void* d_ws, int64_t ws_bytes, void* stream) {
+    if (!d_x || !d_out || n <= 0) return bad_arg(who);
+    const int64_t nb = (n + kScanTile - 1) / kScanTile;
     const int64_t need = (nb + 8) * (int64_t)sizeof(double);
-    if (!d_ws || ws_bytes < need) return bad_arg("obe_weight_cdf: workspace too small");
+    if (!d_ws || ws_bytes < need) return bad_arg("scan: workspace too small");
     double* scalars = static_cast<double*>(d_ws);
     double* block_sums = scalars + 8;
     hipStream_t st = as_stream(stream);
     if (strict_order) {
-        cdf_strict_kernel<<<1, kWave, 0, st>>>(d_weights, n_particles, d_cdf, scalars);
+        cdf_strict_kernel<<<1, kWave, 0, st>>>(d_x, n, d_out, scalars, normalize);
         OBE_CHECK_LAUNCH("cdf_strict_kernel");
     } else {
-        scan_block_sums<<<(unsigned)nb, kBlock, 0, st>>>(d_weights, n_particles, block_sums);
+        scan_block_sums<<<(unsigned)nb, kBlock, 0, st>>>(d_x, n, block_sums);
         OBE_CHECK_LAUNCH("scan_block_sums");
         scan_offsets<<<1, kBlock, 0, st>>>(block_sums, nb, scalars);
         OBE_CHECK_LAUNCH("scan_offsets");
-        scan_write_cdf<<<(unsigned)nb, kBlock, 0, st>>>(d_weights, n_particles, block_sums, scalars, d_cdf);
+        scan_write_cdf<<<(unsigned)nb, kBlock, 0, st>>>(d_x, n, block_sums, scalars, d_out, normalize);
         OBE_CHECK_LAUNCH("scan_write_cdf");
     }
     if (h_total) {
         OBE_HIP_TRY(hipMemcpyAsync(h_total, scalars, sizeof(double), hipMemcpyDeviceToHost, st));
         OBE_HIP_TRY(hipStreamSynchronize(st));
     }
+    return 0;
+}
+
+int obe_weight_cdf(const double* d_weights, int64_t n_particles, int32_t strict_order, double* d_cdf,
+                   double* h_total, void* d_ws, int64_t ws_bytes, void* stream) {
+    return scan_common("obe_weight_cdf: bad pointer/size", d_weights, n_particles, strict_order, 1, d_cdf, h_total,
+                       d_ws, ws_bytes, stream);
+}
+
+int obe_cumsum(const double* d_x, int64_t n, int32_t strict_order, double* d_out, void* d_ws, int64_t ws_bytes,
+               void* stream) {
+    return scan_common("obe_cumsum: bad pointer/size", d_x, n, strict_order, 0, d_out, nullptr, d_ws, ws_bytes,
+                       stream);
+}
+
+// Sweeper composition: utility of the sweep start_i..stop_i = difference of the running
+// point-utility integral at its two ends over the sweep's cost.
+__global__ __launch_bounds__(kBlock) void interval_utility_kernel(const double* __restrict__ cum, int64_t n,
+                                                                  const int64_t* __restrict__ pairs, int64_t np,
+                                                                  const double* __restrict__ cost,
+                                                                  double cost_of_new_sweep,
+                                                                  double* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < np; i += (int64_t)gridDim.x * kBlock) {
+        const longlong2 se = reinterpret_cast<const longlong2*>(pairs)[i];      // one 16 B load
+        int64_t a = se.x, b = se.y;
+        const double c = cost ? cost[i] : (double)(b - a) + cost_of_new_sweep;   // obe_sweeper.py:119-120
+        a = a < 0 ? a + n : a;                                                  // NumPy index wrap
+        b = b < 0 ? b + n : b;
+        a = a < 0 ? 0 : (a >= n ? n - 1 : a);
+        b = b < 0 ? 0 : (b >= n ? n - 1 : b);
+        out[i] = (cum[b] - cum[a]) / c;
+    }
+}
+
+int obe_interval_utility(const double* d_cum, int64_t n_settings, const int64_t* d_pairs, int64_t n_pairs,
+                         const double* d_cost, double cost_of_new_sweep, double* d_utility, void* stream) {
+    if (!d_cum || !d_pairs || !d_utility || n_settings <= 0 || n_pairs <= 0)
+        return bad_arg("obe_interval_utility: bad pointer/size");
+    interval_utility_kernel<<<stream_blocks(n_pairs, kBlock), kBlock, 0, as_stream(stream)>>>(
+        d_cum, n_settings, d_pairs, n_pairs, d_cost, cost_of_new_sweep, d_utility);
+    OBE_CHECK_LAUNCH("interval_utility_kernel");
     return 0;
 }
 

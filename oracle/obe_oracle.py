@@ -22,6 +22,7 @@ __all__ = [
     "nudge_factor", "gauss_likelihood", "yvar_from_draws", "yvar_full_sweep",
     "utility_from_yvar", "mean_noise_variance", "flatten_settings",
     "OracleParticlePDF", "OracleOptBayesExpt", "OracleOptBayesExptNoiseParameter",
+    "OracleOptBayesExptSweeper",
 ]
 
 DEFAULT_N_DRAWS = 30          # obe_base.py:19
@@ -438,3 +439,65 @@ class OracleOptBayesExptNoiseParameter(OracleOptBayesExpt):
     def yvar_noise_model(self):
         return mean_noise_variance(self.parameters, self.noise_parameter_index,
                                    self.particle_weights)
+
+
+class OracleOptBayesExptSweeper(OracleOptBayesExptNoiseParameter):
+    """demos/sweeper/obe_sweeper.py:9-229 — settings are (start, stop) index pairs on the
+    first setting axis; a measurement is a whole sweep.  ``sweep_rng`` stands for that
+    module's own module-level generator (used by good_setting / random_setting)."""
+
+    def __init__(self, measurement_model, setting_values, parameter_samples, constants,
+                 noise_parameter_index, **kwargs):
+        OracleOptBayesExptNoiseParameter.__init__(self, measurement_model, setting_values, parameter_samples,
+                                                  constants, noise_parameter_index, **kwargs)
+        self.sweep_settings = setting_values[0]
+        self.start_stop_subsample = 3
+        self.start_stop_indices = self._generate_start_stop_indices()
+        self.start_stop_choice_indices = np.arange(len(self.start_stop_indices), dtype=int)
+        self.start_stop_values = self.sweep_settings[self.start_stop_indices]
+        self.cost_of_new_sweep = 5.
+        self.sweep_rng = np.random.default_rng()
+
+    def _generate_start_stop_indices(self):
+        """obe_sweeper.py:207-229: every (start, stop) with stop > start on the sub-sampled
+        index grid 0, k, 2k, ... plus the last index; start-major order."""
+        n = len(self.sweep_settings)
+        grid = list(range(0, n, self.start_stop_subsample))
+        if grid[-1] != n - 1:
+            grid.append(n - 1)
+        grid = np.array(grid)
+        i, j = np.triu_indices(len(grid), 1)
+        return np.stack([grid[i], grid[j]], axis=1)
+
+    def pdf_update(self, measurement_record):
+        """obe_sweeper.py:86-100: one NoiseParameter update per point of the sweep."""
+        (xs,), ys = measurement_record
+        for x, y in zip(xs, ys):
+            OracleOptBayesExptNoiseParameter.pdf_update(self, ((x,), y))
+
+    def sweep_cost_estimate(self):
+        """obe_sweeper.py:106-120."""
+        return self.start_stop_indices[:, 1] - self.start_stop_indices[:, 0] + self.cost_of_new_sweep
+
+    def sweep_utility(self):
+        """obe_sweeper.py:122-149: running sum of the point utility, differenced at the ends."""
+        cost = self.sweep_cost_estimate()
+        proto = np.cumsum(self.utility())
+        ends = proto[self.start_stop_indices]
+        return (ends[:, 1] - ends[:, 0]) / cost
+
+    def opt_setting(self):
+        """obe_sweeper.py:151-167 — returns the (start, stop) index pair."""
+        self.last_utility = self.sweep_utility()
+        index = int(np.argmax(self.last_utility))
+        self.last_setting_index = index
+        return self.start_stop_indices[index]
+
+    def good_setting(self):
+        """obe_sweeper.py:169-193."""
+        self.last_utility = self.sweep_utility()
+        p = self.last_utility ** self.pickiness
+        p = p / np.sum(p)
+        index = int(choice_indices(p, np.array([self.sweep_rng.random()]))[0])
+        self.last_setting_index = index
+        return self.start_stop_indices[index]

@@ -153,3 +153,51 @@ def replay(fx, obe, rtol, get_draw_idx=None, get_utility=None, check_moments=Tru
               f"sum w^2, cycle {cyc}")
         stats["cycles"] += 1
     return stats
+
+
+SWEEPER_TRAJECTORIES = ["sweeper_opt", "sweeper_good"]
+
+
+def replay_sweeper(fx, obe, rtol, set_sweep_rng, get_draw_idx=None, get_utility=None):
+    """Drive a sweeper object through the recorded sweeps: per cycle the sweep
+    utility over all (start, stop) pairs, the chosen pair, one pdf_update per point of the
+    simulated sweep, then the posterior statistics.  ``set_sweep_rng(generator)`` installs
+    the generator that stands for the reference demo module's own ``rng``."""
+    meta = fx["meta"]
+    xvals = fx["setval_0"]
+    obe.rng = np.random.default_rng(meta["seed"])
+    set_sweep_rng(np.random.default_rng(meta["seed"] + 3))
+    assert_array_equal(np.asarray(obe.start_stop_indices), fx["pairs"])
+    assert_array_equal(np.asarray(obe.sweep_cost_estimate(), dtype=np.float64), fx["sweep_cost"])
+    optimal = meta["ctor"]["selection_method"] == "optimal"
+    pos, points = 0, 0
+    for cyc in range(meta["n_cycles"]):
+        pair = obe.get_setting()
+        if optimal and get_utility is not None:
+            close(get_utility(obe), fx["sweep_utility"][cyc], rtol, f"sweep utility, cycle {cyc}")
+        if get_draw_idx is not None:
+            assert_array_equal(np.asarray(get_draw_idx(obe)), fx["draw_idx"][cyc], err_msg=f"draw indices, cycle {cyc}")
+        assert int(obe.last_setting_index) == int(fx["chosen_index"][cyc]), f"chosen pair index, cycle {cyc}"
+        assert_array_equal(np.asarray(pair), fx["pair"][cyc])
+        start, stop = int(pair[0]), int(pair[1])
+        sweep_x = xvals[start:stop]
+        y = fx["y_concat"][pos:pos + len(sweep_x)]
+        pos += len(sweep_x)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            obe.pdf_update(((sweep_x,), y))
+        points += len(sweep_x)
+        mtol = rtol * (np.abs(fx["mean"][cyc]) + fx["std"][cyc])
+        merr = np.abs(np.asarray(obe.mean()) - fx["mean"][cyc])
+        assert np.all(merr <= mtol), f"mean, cycle {cyc}: err {merr} tol {mtol}"
+        sd = fx["std"][cyc]
+        tol = rtol * sd + 64 * 2.3e-16 * fx["mean"][cyc] ** 2 / np.maximum(sd, 1e-300)
+        err = np.abs(np.asarray(obe.std()) - sd)
+        assert np.all(err <= tol), f"std, cycle {cyc}: err {err} tol {tol}"
+        close(obe.covariance(), fx["cov"][cyc], rtol, f"covariance, cycle {cyc}")
+        close(np.sum(np.asarray(obe.particle_weights) ** 2), fx["sum_w2"][cyc], rtol, f"sum w^2, cycle {cyc}")
+        if cyc == 0:
+            close(obe.particle_weights, fx["w_snaps"][0], rtol, "weights, cycle 0")
+    close(obe.particle_weights, fx["w_snaps"][-1], rtol, "weights, last cycle")
+    assert pos == len(fx["y_concat"])
+    return dict(cycles=meta["n_cycles"], points=points)

@@ -350,8 +350,85 @@ def full_sweep_cases():
     print("full_sweep_uniform: written")
 
 
+def sweeper_cases():
+    """the sweeper composition.  The reference's OptBayesExptSweeper lives in
+    demos/sweeper/obe_sweeper.py (a subclass of OptBayesExptNoiseParameter); it is loaded
+    from there, driven through seeded sweep cycles in both selection modes, and per cycle
+    the sweep utility, the chosen (start, stop) pair, the simulated sweep and the posterior
+    statistics are stored."""
+    import importlib.util
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    spec = importlib.util.spec_from_file_location("ref_obe_sweeper", "/root/reference/demos/sweeper/obe_sweeper.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g = np.random.default_rng(90210)
+    xvals = np.linspace(1.5, 4.5, 100)                     # demos/sweeper/sweeper.py:69
+    cons = (0.1,)
+    true_pars = (3.1, 1200.0, 300.0, 800.0)
+    for name, selection, n_cycles, seed in (("sweeper_opt", "optimal", 10, 911), ("sweeper_good", "good", 10, 912)):
+        n = 4096
+        prior = np.array([g.uniform(2, 4, n), g.uniform(400, 2000, n), g.normal(500, 1000, n),
+                          g.exponential(500, n)])      # sweeper.py:74-83
+        ctor = dict(scale=False, utility_method="variance_approx", selection_method=selection, pickiness=20,
+                    noise_parameter_index=3)
+        obe = mod.OptBayesExptSweeper(models.lorentzian, (xvals,), prior.copy(), cons, **ctor)
+        rng = RecordingRNG(seed)
+        obe.rng = rng
+        mod.rng = RecordingRNG(seed + 3)                   # that module's own generator (good_setting)
+        sim = np.random.default_rng(seed + 1)
+        out = dict(chosen_index=[], pair=[], sweep_utility=[], draw_idx=[], n_resamples=[], mean=[], std=[],
+                   cov=[], sum_w2=[])
+        ys, w_snaps = [], []
+        for cyc in range(n_cycles):
+            rng.choices.clear()
+            if selection == "optimal":
+                util = obe.sweep_utility()                 # what opt_setting() maximises (obe_sweeper.py:163)
+                index = int(np.argmax(util))
+                obe.last_setting_index = index
+                pair = obe.start_stop_indices[index]
+            else:
+                pair = obe.get_setting()
+                index = int(obe.last_setting_index)
+                util = np.full(len(obe.start_stop_indices), np.nan)
+            draw_idx = rng.choices[0].copy()
+            start, stop = int(pair[0]), int(pair[1])
+            sweep_x = xvals[start:stop]                    # sweeper.py:129
+            y = models.lorentzian((sweep_x,), true_pars, cons) + true_pars[3] * sim.standard_normal(len(sweep_x))
+            n_res = 0
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", RuntimeWarning)
+                # count the resamples inside the sweep: one full-size choice() each
+                rng.choices.clear()
+                obe.pdf_update(((sweep_x,), y))
+                n_res = sum(1 for c in rng.choices if len(c) == n)
+            out["chosen_index"].append(index)
+            out["pair"].append([start, stop])
+            out["sweep_utility"].append(util)
+            out["draw_idx"].append(draw_idx)
+            out["n_resamples"].append(n_res)
+            out["mean"].append(obe.mean())
+            out["std"].append(obe.std())
+            out["cov"].append(obe.covariance())
+            out["sum_w2"].append(np.sum(obe.particle_weights ** 2))
+            ys.append(y)
+            if cyc in (0, n_cycles - 1):
+                w_snaps.append(np.array(obe.particle_weights))
+        meta = dict(name=name, model="lorentzian", cls="sweeper", ctor=ctor, seed=seed, n_cycles=n_cycles,
+                    true_pars=list(true_pars), numpy=np.__version__, reference=ref.__version__)
+        arrays = {k: np.array(v) for k, v in out.items()}
+        arrays.update(prior=prior, cons=np.array(cons), setval_0=xvals, y_concat=np.concatenate(ys),
+                      w_snaps=np.array(w_snaps), pairs=np.array(obe.start_stop_indices),
+                      sweep_cost=np.asarray(obe.sweep_cost_estimate(), dtype=np.float64),
+                      meta=np.array(json.dumps(meta)))
+        path = os.path.join(HERE, f"traj_{name}.npz")
+        np.savez_compressed(path, **arrays)
+        print(f"{name}: {n_cycles} sweeps, {len(arrays['y_concat'])} points, "
+              f"{int(np.sum(out['n_resamples']))} resamples, {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 if __name__ == "__main__":
-    trajectories()
-    yspace_utilities()
-    unit_cases()
-    full_sweep_cases()
+    which = sys.argv[1:] or ["trajectories", "yspace", "units", "full_sweep", "sweeper"]
+    steps = dict(trajectories=trajectories, yspace=yspace_utilities, units=unit_cases,
+                 full_sweep=full_sweep_cases, sweeper=sweeper_cases)
+    for w in which:
+        steps[w]()

@@ -48,6 +48,20 @@ def test_yspace_utility_trajectory_matches_reference(name):
     assert stats["resamples"] == int(np.sum(fx["resampled"])) >= 5
 
 
+@pytest.mark.parametrize("name", _replay.SWEEPER_TRAJECTORIES)
+def test_sweeper_trajectory_matches_reference(name):
+    """(start, stop) sweep selection and per-point updates of the reference's
+    demos/sweeper/obe_sweeper.py, optimal and good selection."""
+    fx = _replay.load_traj(name)
+    ctor = dict(fx["meta"]["ctor"])
+    obe = oracle.OracleOptBayesExptSweeper(models.lorentzian, (fx["setval_0"],), fx["prior"].copy(),
+                                           tuple(fx["cons"]), **ctor)
+    stats = _replay.replay_sweeper(fx, obe, ORACLE_RTOL, lambda g: setattr(obe, "sweep_rng", g),
+                                   get_draw_idx=lambda o: o.last_draw_indices,
+                                   get_utility=lambda o: o.last_utility)
+    assert stats["points"] == len(fx["y_concat"]) > 100 and int(np.sum(fx["n_resamples"])) >= 10
+
+
 def test_reference_conditioning_10_parameters(monkeypatch):
     """Why the HIP tolerance on the 10-parameter trajectory is 1e-6 and not 1e-10: the
     reference algorithm, run on the CPU with its weighted covariance summed in reverse
