@@ -94,6 +94,21 @@ int obe_bayes_update_model(const obe_model* m,
                            int32_t n_lik_channels, double choke,
                            void* d_ws, int64_t ws_bytes, double* h_out, void* stream);
 
+/* A whole sweep of measurements (demos/sweeper/obe_sweeper.py:86-100: one pdf_update per point,
+ * each followed by the resample test of particlepdf.py:236-258) enqueued back to back, no
+ * host round trip between the points.  h_settings (n_points, OBE_MAX_SETDIMS) and h_y_meas
+ * (n_points, OBE_MAX_CHANNELS) row-major; sigma / noise rows / choke as obe_bayes_update_model.
+ * With auto_resample != 0 the test runs on the device after every point: as soon as
+ * n_eff < 0.1 N or n_eff / N < resample_threshold the remaining points are skipped (their
+ * kernels return at once).  h_out[0] = sum t and h_out[1] = sum w'^2 of the last point applied,
+ * h_out[2] = 1 if a resample is due, h_out[3] = points applied (>= 1); the caller resamples and
+ * submits the rest.  Sync. */
+int obe_bayes_update_sweep(const obe_model* m, const double* d_particles, int64_t ld_p,
+                           int64_t n_particles, double* d_weights, const double* h_settings,
+                           const double* h_y_meas, const double* h_sigma,
+                           const int32_t* h_noise_rows, int32_t n_lik_channels, double choke,
+                           int64_t n_points, int32_t auto_resample, double resample_threshold,
+                           void* d_ws, int64_t ws_bytes, double* h_out, void* stream);
 /* Same update from precomputed model outputs d_y (C, N_p) row-major, ld_y between
  * channels  (pdf_update(..., y_model_data), obe_base.py:384-385). */
 int obe_bayes_update_y(const double* d_y, int64_t ld_y, int32_t n_channels,

@@ -53,6 +53,8 @@ _SIGNATURES = {
     "obe_workspace_bytes": (c_int64, [c_int64, c_int64, c_int32, c_int32]),
     "obe_bayes_update_model": (c_int, [ctypes.POINTER(ObeModelStruct), _P, c_int64, c_int64, _P, _P, _P, _P, _P,
                                        c_int32, c_double, _P, c_int64, _P, _P]),
+    "obe_bayes_update_sweep": (c_int, [ctypes.POINTER(ObeModelStruct), _P, c_int64, c_int64, _P, _P, _P, _P, _P,
+                                       c_int32, c_double, c_int64, c_int32, c_double, _P, c_int64, _P, _P]),
     "obe_bayes_update_y": (c_int, [_P, c_int64, c_int32, _P, c_int64, c_int64, _P, _P, _P, _P, c_int32,
                                    c_double, _P, c_int64, _P, _P]),
     "obe_bayes_update_lik": (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P]),
@@ -99,7 +101,8 @@ _SIGNATURES = {
 
 
 # entry points whose code depends on the model: a plugin library serves these
-MODEL_ENTRY_POINTS = ("obe_model_validate", "obe_bayes_update_model", "obe_eval_over_particles",
+MODEL_ENTRY_POINTS = ("obe_model_validate", "obe_bayes_update_model", "obe_bayes_update_sweep",
+                      "obe_eval_over_particles",
                       "obe_eval_over_settings", "obe_sweep_utility", "obe_sweep_kernel_time", "obe_eval_draws")
 
 

@@ -49,8 +49,9 @@ struct SettingArg {
 template <class M>
 __global__ __launch_bounds__(kBlock) void update_model_kernel(
     obe_model m, SettingArg st, LikArgs la, const double* __restrict__ particles, int64_t ld,
-    int64_t n, double* __restrict__ weights, double* __restrict__ partials) {
+    int64_t n, double* __restrict__ weights, double* __restrict__ partials, const double* __restrict__ stop) {
     __shared__ double red[kBlock / kWave];
+    if (stop && stop[0] != 0.0) return;      // sweep batch: an earlier point asked for a resample
     double acc = 0.0;
     for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (int64_t)gridDim.x * kBlock) {
         double y[M::NC];
@@ -100,8 +101,10 @@ __global__ __launch_bounds__(kBlock) void update_lik_kernel(const double* __rest
 __global__ __launch_bounds__(kBlock) void normalize_kernel(const double* __restrict__ partials_in,
                                                            int n_partials, int64_t n,
                                                            double* __restrict__ weights,
-                                                           double* __restrict__ partials_out) {
+                                                           double* __restrict__ partials_out,
+                                                           const double* __restrict__ stop) {
     __shared__ double red[kBlock / kWave];
+    if (stop && stop[0] != 0.0) return;
     const double total = block_sum_array(partials_in, n_partials, red);
     double acc = 0.0;
     for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (int64_t)gridDim.x * kBlock) {
@@ -124,6 +127,33 @@ __global__ __launch_bounds__(kBlock) void fold2_kernel(const double* __restrict_
         scalars[0] = a;
         scalars[1] = b;
     }
+}
+
+// pass C of a sweep batch (obe_bayes_update_sweep): as fold2_kernel, plus the resample test
+// of particlepdf.py:236-258 on the device.  scalars[2] = stop flag, scalars[3] = points applied.
+__global__ __launch_bounds__(kBlock) void fold2_stop_kernel(const double* __restrict__ pa,
+                                                            const double* __restrict__ pb, int n_partials,
+                                                            double* __restrict__ scalars, double n_particles,
+                                                            int auto_resample, double resample_threshold) {
+    __shared__ double red[kBlock / kWave];
+    if (scalars[2] != 0.0) return;
+    const double a = block_sum_array(pa, n_partials, red);
+    __syncthreads();
+    const double b = block_sum_array(pb, n_partials, red);
+    if (threadIdx.x == 0) {
+        scalars[0] = a;
+        scalars[1] = b;
+        scalars[3] = scalars[3] + 1.0;
+        if (auto_resample) {
+            const double n_eff = 1.0 / b;
+            if (n_eff < 0.1 * n_particles || n_eff / n_particles < resample_threshold) scalars[2] = 1.0;
+        }
+    }
+}
+
+__global__ void sweep_state_reset_kernel(double* __restrict__ scalars) {
+    scalars[2] = 0.0;
+    scalars[3] = 0.0;
 }
 
 __global__ __launch_bounds__(kBlock) void weight_sums_kernel(const double* __restrict__ weights, int64_t n,
@@ -297,7 +327,7 @@ static int update_blocks(int64_t n) {
 }
 
 static int finish_update(const UpdateWs& w, int nb, int64_t n, double* d_weights, double* h_out, hipStream_t st) {
-    normalize_kernel<<<nb, kBlock, 0, st>>>(w.pa, nb, n, d_weights, w.pb);
+    normalize_kernel<<<nb, kBlock, 0, st>>>(w.pa, nb, n, d_weights, w.pb, nullptr);
     OBE_CHECK_LAUNCH("normalize_kernel");
     fold2_kernel<<<1, kBlock, 0, st>>>(w.pa, w.pb, nb, w.scalars);
     OBE_CHECK_LAUNCH("fold2_kernel");
@@ -332,12 +362,56 @@ int obe_bayes_update_model(const obe_model* m, const double* d_particles, int64_
     const int nb = update_blocks(n_particles);
     int rc = dispatch_model(mm, [&](auto M) -> int {
         using Model = decltype(M);
-        update_model_kernel<Model><<<nb, kBlock, 0, st>>>(mm, sa, la, d_particles, ld_p, n_particles, d_weights, w.pa);
+        update_model_kernel<Model><<<nb, kBlock, 0, st>>>(mm, sa, la, d_particles, ld_p, n_particles, d_weights, w.pa,
+                                                          nullptr);
         OBE_CHECK_LAUNCH("update_model_kernel");
         return 0;
     });
     if (rc) return rc;
     return finish_update(w, nb, n_particles, d_weights, h_out, st);
+}
+
+int obe_bayes_update_sweep(const obe_model* m, const double* d_particles, int64_t ld_p, int64_t n_particles,
+                           double* d_weights, const double* h_settings, const double* h_y_meas,
+                           const double* h_sigma, const int32_t* h_noise_rows, int32_t n_lik_channels,
+                           double choke, int64_t n_points, int32_t auto_resample, double resample_threshold,
+                           void* d_ws, int64_t ws_bytes, double* h_out, void* stream) {
+    if (!m || !d_particles || !d_weights || n_particles <= 0 || n_points <= 0 || !h_y_meas || !h_out)
+        return bad_arg("obe_bayes_update_sweep: bad pointer/size");
+    obe_model mm = *m;
+    if (int rc = obe_model_validate(&mm)) return rc;
+    if (n_lik_channels > mm.n_channels) return bad_arg("n_lik_channels exceeds model channels");
+    UpdateWs w;
+    if (int rc = carve_update_ws(d_ws, ws_bytes, w)) return rc;
+    hipStream_t st = as_stream(stream);
+    const int nb = update_blocks(n_particles);
+    sweep_state_reset_kernel<<<1, 1, 0, st>>>(w.scalars);
+    OBE_CHECK_LAUNCH("sweep_state_reset_kernel");
+    const double* stop = w.scalars + 2;
+    for (int64_t k = 0; k < n_points; ++k) {
+        LikArgs la;
+        if (int rc = fill_lik_args(la, h_y_meas + k * OBE_MAX_CHANNELS, h_sigma, h_noise_rows, n_lik_channels, choke,
+                                   mm.n_params))
+            return rc;
+        SettingArg sa{};
+        for (int j = 0; j < mm.n_setdims; ++j) sa.x[j] = h_settings ? h_settings[k * OBE_MAX_SETDIMS + j] : 0.0;
+        int rc = dispatch_model(mm, [&](auto M) -> int {
+            using Model = decltype(M);
+            update_model_kernel<Model><<<nb, kBlock, 0, st>>>(mm, sa, la, d_particles, ld_p, n_particles, d_weights,
+                                                              w.pa, stop);
+            OBE_CHECK_LAUNCH("update_model_kernel");
+            return 0;
+        });
+        if (rc) return rc;
+        normalize_kernel<<<nb, kBlock, 0, st>>>(w.pa, nb, n_particles, d_weights, w.pb, stop);
+        OBE_CHECK_LAUNCH("normalize_kernel");
+        fold2_stop_kernel<<<1, kBlock, 0, st>>>(w.pa, w.pb, nb, w.scalars, (double)n_particles, auto_resample,
+                                                resample_threshold);
+        OBE_CHECK_LAUNCH("fold2_stop_kernel");
+    }
+    OBE_HIP_TRY(hipMemcpyAsync(h_out, w.scalars, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+    OBE_HIP_TRY(hipStreamSynchronize(st));
+    return 0;
 }
 
 int obe_bayes_update_y(const double* d_y, int64_t ld_y, int32_t n_channels, const double* d_particles,

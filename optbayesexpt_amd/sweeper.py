@@ -20,9 +20,9 @@ import numpy as np
 import torch
 
 from . import _lib
-from .obe_base import _overridden
+from .obe_base import OptBayesExpt, _LazyState, _overridden
 from .obe_noiseparam import OptBayesExptNoiseParameter
-from .particlepdf import _ptr
+from .particlepdf import ParticlePDF, _ptr
 
 #: module-level generator for good_setting / random_setting, like the reference module's
 #: own ``rng`` (obe_sweeper.py:3-6)
@@ -52,12 +52,71 @@ class OptBayesExptSweeper(OptBayesExptNoiseParameter):
     # ------------------------------------------------------------------ inference
     def pdf_update(self, measurement_record):
         """One Bayesian update per point of the sweep (obe_sweeper.py:86-100); the record is
-        ``((x_values,), y_values)``."""
+        ``((x_values,), y_values)``.
+
+        With a device model and none of the per-point hooks overridden the points are enqueued
+        in batches (``obe_bayes_update_sweep``): the resample test between the points runs on
+        the device, and the host synchronises once per batch instead of once per point.  A point
+        that calls for a resample ends its batch; the resample (and the constraint hook) run
+        on the host path exactly as in the one-by-one loop, then the rest of the sweep follows."""
         (setting_values,), result_values = measurement_record
-        out = None
-        for setting, result in zip(setting_values, result_values):
-            out = OptBayesExptNoiseParameter.pdf_update(self, ((setting,), result))
-        return out
+        points = list(zip(setting_values, result_values))
+        if not points:
+            return None
+        batch = self._sweep_batch_inputs(points)
+        if batch is None:
+            out = None
+            for setting, result in points:
+                out = OptBayesExptNoiseParameter.pdf_update(self, ((setting,), result))
+            return out
+        xs, ys, n_lik = batch
+        par, w = self._parameters.tensor(), self._weights.tensor()
+        if par.shape[1] != w.shape[0]:
+            raise ValueError("parameters and particle_weights have different lengths")
+        pos, chunk, out = 0, self.SWEEP_BATCH_MIN, self._host_out
+        self.last_sweep_batches = []            # (points submitted, points applied) per device batch
+        while pos < len(points):
+            k = min(chunk, len(points) - pos)
+            par, w = self._parameters.tensor(), self._weights.tensor()
+            self._mlib.call("obe_bayes_update_sweep", self._model_struct, _ptr(par), par.shape[1], self.n_particles,
+                            _ptr(w), _lib.host_ptr(xs[pos:]), _lib.host_ptr(ys[pos:]), None,
+                            _lib.host_ptr(self._noise_rows), n_lik, self._choke_value(), k,
+                            1 if self.tuning_parameters["auto_resample"] else 0,
+                            float(self.tuning_parameters["resample_threshold"]),
+                            _ptr(self._ws), self._ws_bytes, _lib.host_ptr(out), self._stream())
+            applied = int(out[3])
+            self.last_sweep_batches.append((k, applied))
+            self._after_weight_update(out[1])       # the same test on the host: resamples if it is due
+            self._parameters = self._particles
+            if self.just_resampled:
+                self.enforce_parameter_constraints()
+            pos += applied
+            chunk = min(self.SWEEP_BATCH_MAX, 2 * chunk) if applied == k else self.SWEEP_BATCH_MIN
+        return _LazyState(self)
+
+    #: points per device batch: doubled after every batch that ran to its end, reset by a resample
+    SWEEP_BATCH_MIN, SWEEP_BATCH_MAX = 8, 64
+
+    def _sweep_batch_inputs(self, points):
+        """(settings (M, OBE_MAX_SETDIMS), y (M, OBE_MAX_CHANNELS), n_lik) for the batched
+        update, or None when the sweep has to go point by point (host-callable model, or a
+        subclass overriding one of the hooks that the per-point path calls)."""
+        if self._device_model is None or len(points) < 2 \
+                or _overridden(self, "eval_over_all_parameters", OptBayesExpt) or self._likelihood_overridden() \
+                or _overridden(self, "bayesian_update", ParticlePDF) or _overridden(self, "resample_test", ParticlePDF) \
+                or _overridden(self, "_likelihood_inputs", OptBayesExptNoiseParameter):
+            return None
+        xs = np.zeros((len(points), _lib.OBE_MAX_SETDIMS))
+        ys = np.zeros((len(points), _lib.OBE_MAX_CHANNELS))
+        n_lik = None
+        for i, (setting, result) in enumerate(points):
+            xs[i] = self._setting_array((setting,))
+            n, ys[i], _ = self._record_channels(result, None)
+            if n_lik is None:
+                n_lik = n
+            elif n != n_lik:
+                return None
+        return xs, ys, n_lik
 
     # -------------------------------------------------------------------- utility
     def cost_estimate(self):

@@ -115,8 +115,13 @@ def test_reference_style_host_subclass_runs_unchanged(hip):
             warnings.simplefilter("ignore", RuntimeWarning)
             h.pdf_update(((xs,), ys))
             d.pdf_update(((xs,), ys))
+        # h updated point by point (K2 + host resample test each), d in device batches with the
+        # test on the device: same bits, through the resamples inside the sweeps
         assert_array_equal(h.particle_weights, d.particle_weights)
         assert_array_equal(h.mean(), d.mean())
+        assert_array_equal(h.particles, d.particles)
+        assert sum(a for _, a in d.last_sweep_batches) == len(xs)
+        assert len(d.last_sweep_batches) < len(xs) or len(xs) < 3
 
 
 def test_sweeper_overridden_cost_and_other_selection_methods(hip):
