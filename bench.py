@@ -34,6 +34,10 @@ sys.path.insert(0, ROOT)
 FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X datasheet FP64 vector = 256 CU x 128 flop/clk x 2.4 GHz
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 FLOP_PER_EVAL = {"lorentzian": 10, "lorentzian7": 46}
+# FP64 VALU issue slots per evaluation in the kernel's pair loop, counted in the gfx950 ISA
+# (tools/count_isa.py; v_rcp_f64 = 4 slots): (unshifted, shifted)
+ISSUE_SLOTS_PER_EVAL = {"lorentzian": (7.75, 8.75), "lorentzian7": (42.25, 43.25)}
+VALU_ISSUE_PEAK = 256 * 4 * 16 * 2.4e9                   # lane-instructions/s: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz
 
 CONFIGS = {
     # name: (n_settings, n_particles, model, description)
@@ -259,6 +263,11 @@ def main():
                 "flop_per_eval": FLOP_PER_EVAL[model], "evals_per_launch": n_local * n_p,
                 "launch_ms": ms.value, "variant": "shifted" if shifted else "unshifted",
                 "kappa": obe.last_sweep["kappa"], "traffic": traffic,
+                "valu_issue": (lambda slots: {
+                    "slots_per_eval": slots, "achieved": slots * n_local * n_p / k1_s, "peak": VALU_ISSUE_PEAK,
+                    "unit": "FP64 lane-instructions/s", "frac": slots * n_local * n_p / k1_s / VALU_ISSUE_PEAK,
+                    "note": "the flop roofline prices every slot as an FMA; the kernel's mix is ~half mul/add"})(
+                        ISSUE_SLOTS_PER_EVAL[model][1 if shifted else 0]),
                 "hbm_algorithmic": {"bytes": k1_bytes, "achieved": k1_bytes / k1_s / 1e9, "peak": HBM_PEAK_GBS,
                                     "unit": "GB/s", "frac": k1_bytes / k1_s / 1e9 / HBM_PEAK_GBS,
                                     "note": "compute-bound kernel: ~1e4 flop per compulsory byte"}}
