@@ -74,6 +74,41 @@ __device__ __forceinline__ double batch_rcp(const double (&q)[N], double (&r)[N]
     }
 }
 
+// Batch inversion of two groups that share one reciprocal, each result scaled by its group's
+// factor: r[j] = s_lo / q[j] (j < N/2), s_hi / q[j] (j >= N/2).  The factors enter at the
+// top of the back-substitution (two multiplies) instead of once per element afterwards.
+template <int N>
+__device__ __forceinline__ void batch_rcp_scaled2(const double (&q)[N], double s_lo, double s_hi, double (&r)[N]) {
+    if constexpr (N == 2) {
+        const double inv = fast_rcp(q[0] * q[1]);
+        r[0] = inv * (q[1] * s_lo);
+        r[1] = inv * (q[0] * s_hi);
+    } else if constexpr (N == 4) {
+        const double p01 = q[0] * q[1], p23 = q[2] * q[3];
+        const double inv = fast_rcp(p01 * p23);
+        const double i01 = inv * (p23 * s_lo), i23 = inv * (p01 * s_hi);
+        r[0] = i01 * q[1];
+        r[1] = i01 * q[0];
+        r[2] = i23 * q[3];
+        r[3] = i23 * q[2];
+    } else {
+        static_assert(N == 8, "batch_rcp_scaled2: N must be 2, 4 or 8");
+        const double p01 = q[0] * q[1], p23 = q[2] * q[3], p45 = q[4] * q[5], p67 = q[6] * q[7];
+        const double p03 = p01 * p23, p47 = p45 * p67;
+        const double inv = fast_rcp(p03 * p47);
+        const double i03 = inv * (p47 * s_lo), i47 = inv * (p03 * s_hi);
+        const double i01 = i03 * p23, i23 = i03 * p01, i45 = i47 * p67, i67 = i47 * p45;
+        r[0] = i01 * q[1];
+        r[1] = i01 * q[0];
+        r[2] = i23 * q[3];
+        r[3] = i23 * q[2];
+        r[4] = i45 * q[5];
+        r[5] = i45 * q[4];
+        r[6] = i67 * q[7];
+        r[7] = i67 * q[6];
+    }
+}
+
 // 1/b with IEEE behaviour at the edges (b = 0 -> inf, b = inf -> 0, NaN -> NaN): the raw
 // v_rcp_f64 result is returned whenever the correction step produced a NaN.
 __device__ __forceinline__ double guarded_rcp(double b) {
@@ -180,7 +215,8 @@ struct Lorentz {
             }
         }
     }
-    // Two particles at once: their 2*SPT/2 pair products share ONE reciprocal.
+    // Two particles at once: their 2*SPT/2 pair products share ONE reciprocal, and each
+    // particle's amplitude enters the inversion tree at its root (2 multiplies per 16 evaluations).
     static constexpr bool kHasPairEval = true;
     template <int SPT>
     __device__ __forceinline__ static void sweep_eval_pair(const double (&xs)[SPT][NXS], const double* pa,
@@ -206,10 +242,10 @@ struct Lorentz {
                 pp[h] = qa[2 * h] * qa[2 * h + 1];
                 pp[SPT / 2 + h] = qb[2 * h] * qb[2 * h + 1];
             }
-            batch_rcp<SPT>(pp, ip);
+            batch_rcp_scaled2<SPT>(pp, pa[K], pb[K], ip);      // ip = amplitude / pair product
 #pragma unroll
             for (int h = 0; h < SPT / 2; ++h) {
-                const double ga = pa[K] * ip[h], gb = pb[K] * ip[SPT / 2 + h];
+                const double ga = ip[h], gb = ip[SPT / 2 + h];
                 va[2 * h][0] = fma(ga, qa[2 * h + 1], va[2 * h][0]);
                 va[2 * h + 1][0] = fma(ga, qa[2 * h], va[2 * h + 1][0]);
                 vb[2 * h][0] = fma(gb, qb[2 * h + 1], vb[2 * h][0]);
