@@ -215,8 +215,10 @@ int obe_power_normalize(const double* d_u, int64_t n, double exponent, double* d
  *                        ddof=0 variance (np.var over utility_y_space, obe_base.py:488)
  * d_moments: output of obe_moments for the same particles/weights (mean parameters are
  * used as the variance shift, sum w as the normaliser).
- * shifted != 0: moments are accumulated about a per-setting shift (always safe).
- * shifted == 0: one instruction fewer per evaluation, accurate only while the predicted
+ * `shifted` is a bit set: OBE_SWEEP_SHIFTED (1) and, for expression (plugin) models,
+ * OBE_SWEEP_SAFE (2).
+ * OBE_SWEEP_SHIFTED set: moments are accumulated about a per-setting shift (always accurate).
+ * OBE_SWEEP_SHIFTED clear: one instruction fewer per evaluation, accurate only while the predicted
  * mean does not dominate the spread; *h_kappa (nullable) returns the worst
  * (mean of y)^2 / var over settings and channels — the factor by which an unshifted sweep
  * amplifies rounding — so the caller can choose the mode for the next sweep, or repeat
@@ -232,6 +234,13 @@ int obe_power_normalize(const double* d_u, int64_t n, double exponent, double* d
  * {best value (f64), best local index (i64 bits), kappa (f64), 0} — what a sharded caller
  * all-gathers across ranks (RCCL) without copying it to the host first. */
 #define OBE_WS_RESULT_OFFSET 2
+/* bits of the `shifted` argument of obe_sweep_utility / obe_sweep_kernel_time.  A plugin
+ * model's fast sweep form batches its divisions without a branch and poisons (NaN) a batch
+ * whose denominators leave the range in which that is exact; a NaN variance comes back as
+ * *h_kappa = NaN, and the caller repeats the sweep with OBE_SWEEP_SAFE (one IEEE
+ * reciprocal per element, implies the shift).  Built-in models ignore OBE_SWEEP_SAFE. */
+#define OBE_SWEEP_SHIFTED 1
+#define OBE_SWEEP_SAFE 2
 int obe_sweep_utility(const obe_model* m,
                       const double* d_settings, int64_t ld_s, int64_t n_settings,
                       const double* d_particles, int64_t ld_p, int64_t n_particles,

@@ -211,9 +211,16 @@ class _SweepBuilder(ast.NodeVisitor):
 class _SweepEmitter:
     """C code for prep_setting (xs slots), pack (pk slots) and the phased sweep_eval body."""
 
-    def __init__(self):
-        self.xs_slots, self.pk_slots = {}, {}     # node key -> slot index
-        self.prep, self.pack = [], []             # C statements filling the slots
+    def __init__(self, safe=False, share=None):
+        """``safe``: one guarded IEEE reciprocal per element instead of the branch-free batched
+        inversions (the sweep_eval_safe twin); ``share``: the emitter of the fast form, whose
+        xs / pk slot tables this one extends so that both forms read the same prepared data."""
+        self.safe = safe
+        if share is None:
+            self.xs_slots, self.pk_slots = {}, {}     # node key -> slot index
+            self.prep, self.pack = [], []             # C statements filling the slots
+        else:
+            self.xs_slots, self.pk_slots, self.prep, self.pack = share.xs_slots, share.pk_slots, share.prep, share.pack
         self.phases, self.memo = [], {}
         self.count = 0
 
@@ -268,11 +275,30 @@ class _SweepEmitter:
                 a = self.memo[n.args[0].key] = self.temp(a)
             return a, a
         if n.op == "div":
-            r = self.reciprocal(n.args[1])
-            if n.args[0].op == "num" and n.args[0].val == 1.0:
+            num, den = n.args
+            if num.op == "num" and num.val == 1.0:
+                self.reciprocal(den)
                 return None
-            return self.emit(n.args[0]), r
+            if num.level != _LSP:                 # setting-independent numerator: into the tree's root
+                return self.quotient_factors(num, den)
+            return self.emit(num), self.reciprocal(den)
         return None
+
+    def quotient_factors(self, num, den):
+        """num / den for a setting-independent numerator, as the two factors of the final
+        multiply: (pair inverse with the numerator folded into the tree's root, sibling)."""
+        if self.safe:
+            return self.emit(num), self.reciprocal(den)
+        key = ("quot", num.key, den.key)
+        if key not in self.memo:
+            k = self.count
+            self.count += 1
+            self.phases.append(
+                f"        double den{k}[SPT], ip{k}[(SPT + 1) / 2];\n"
+                f"        _Pragma(\"unroll\") for (int j = 0; j < SPT; ++j) den{k}[j] = {self.emit(den)};\n"
+                f"        batch_div_poisoned<SPT>(den{k}, {self.emit(num)}, ip{k});")
+            self.memo[key] = (f"ip{k}[j / 2]", f"sibling_of<SPT>(den{k}, j)")
+        return self.memo[key]
 
     def reciprocal(self, den):
         key = ("rcp", den.key)
@@ -281,8 +307,9 @@ class _SweepEmitter:
             self.count += 1
             self.phases.append(
                 f"        double den{k}[SPT], r{k}[SPT];\n"
-                f"        _Pragma(\"unroll\") for (int j = 0; j < SPT; ++j) den{k}[j] = {self.emit(den)};\n"
-                f"        batch_rcp_guarded<SPT>(den{k}, r{k});")
+                f"        _Pragma(\"unroll\") for (int j = 0; j < SPT; ++j) den{k}[j] = {self.emit(den)};\n" +
+                (f"        _Pragma(\"unroll\") for (int j = 0; j < SPT; ++j) r{k}[j] = guarded_rcp(den{k}[j]);"
+                   if self.safe else f"        batch_rcp_poisoned<SPT>(den{k}, r{k});"))
             self.memo[key] = f"r{k}[j]"
         return self.memo[key]
 
@@ -319,17 +346,21 @@ class _SweepEmitter:
 
 
 def _sweep_code(trees, settings, parameters, constants):
-    """(prep_setting body, NXS, pack body, NPK, sweep_eval body) of the generated model."""
+    """(prep_setting body, NXS, pack body, NPK, sweep_eval body, sweep_eval_safe body) of the
+    generated model."""
     build = _SweepBuilder(settings, parameters, constants)
     sw = _Node("sw", level=_LP)
-    em = _SweepEmitter()
-    out = []
-    for c, t in enumerate(trees):
-        root = _mul(build.visit(t), sw)                        # the kernel wants sqrt(w) * y
-        out.append(f"        _Pragma(\"unroll\") for (int j = 0; j < SPT; ++j) v[j][{c}] = {em.emit(root)};")
+    roots = [_mul(build.visit(t), sw) for t in trees]         # the kernel wants sqrt(w) * y
+    fast = _SweepEmitter()
+    safe = _SweepEmitter(safe=True, share=fast)
+    bodies = []
+    for em in (fast, safe):
+        out = [f"        _Pragma(\"unroll\") for (int j = 0; j < SPT; ++j) v[j][{c}] = {em.emit(root)};"
+               for c, root in enumerate(roots)]
+        bodies.append("\n".join(em.phases + out))
     nl = "\n"
-    return (nl.join(em.prep), max(1, len(em.xs_slots)), nl.join(em.pack), max(1, len(em.pk_slots)),
-            nl.join(em.phases + out))
+    return (nl.join(fast.prep), max(1, len(fast.xs_slots)), nl.join(fast.pack), max(1, len(fast.pk_slots)),
+            bodies[0], bodies[1])
 
 
 def _check_names(names):
@@ -350,7 +381,7 @@ def translate(expressions, settings, parameters, constants):
     names = set(settings + parameters + constants)
     trees = [ast.parse(e.strip(), mode="eval") for e in expressions]
     c_exprs = [_ToC(names).visit(t) for t in trees]
-    prep_body, nxs, pack_body, npk, sweep_body = _sweep_code(trees, settings, parameters, constants)
+    prep_body, nxs, pack_body, npk, sweep_body, safe_body = _sweep_code(trees, settings, parameters, constants)
     ns, nc, npar, ncon = len(settings), len(expressions), len(parameters), len(constants)
     decl = [f"        const double u_{n} = x_[{i}];" for i, n in enumerate(settings)]
     decl += [f"        const double u_{n} = th_[{i}];" for i, n in enumerate(parameters)]
@@ -392,6 +423,15 @@ struct PluginModel {{
                                                       const obe_model&, double (&v)[SPT][NC]) {{
         (void)xs; (void)pk;
 {sweep_body}
+    }}
+    // the same with one guarded IEEE reciprocal per element: used for the repeat after a sweep
+    // in which a batch above left its exact range (NaN-poisoned; include/obe_hip.h OBE_SWEEP_SAFE)
+    static constexpr bool kHasSafeEval = true;
+    template <int SPT>
+    __device__ __forceinline__ static void sweep_eval_safe(const double (&xs)[SPT][NXS], const double* pk, double,
+                                                           const obe_model&, double (&v)[SPT][NC]) {{
+        (void)xs; (void)pk;
+{safe_body}
     }}
 }};
 }}  // namespace obe

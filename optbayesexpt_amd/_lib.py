@@ -20,6 +20,7 @@ OBE_MAX_CHANNELS = 4
 OBE_MAX_SETDIMS = 4
 OBE_MAX_DIMS = 16
 OBE_WS_RESULT_OFFSET = 2      # doubles; include/obe_hip.h
+OBE_SWEEP_SHIFTED, OBE_SWEEP_SAFE = 1, 2      # bits of obe_sweep_utility's `shifted` argument
 
 c_void_p, c_int, c_int32, c_int64, c_double = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int32,
                                                ctypes.c_int64, ctypes.c_double)

@@ -118,36 +118,59 @@ __device__ __forceinline__ double guarded_rcp(double b) {
     return r == r ? r : r0;
 }
 
-// Batch inversion for denominators that are not known to be >= 1 (generated expression
-// models).  The batch runs over the N/2 pair products; it is accepted when their magnitudes
-// sum to < 1e30 (no overflow, inf or NaN) and the reciprocal of the whole product is
-// < 1e200 in magnitude: then every partial product inside batch_rcp lies in
-// (1e-290, 1e120) — no zero, no subnormal that would lose bits.  Otherwise every element
-// gets its own guarded reciprocal (IEEE results for 0, inf and NaN).
+// Batch inversions for generated expression models, whose denominators are not known to be
+// >= 1.  Straight-line code: the batch runs over the N/2 pair products and is accepted when
+// their magnitudes sum to < 1e30 (no overflow, inf or NaN) and the reciprocal of the whole
+// product is < 1e200 in magnitude — then every partial product inside the tree lies in
+// (1e-290, 1e120): no zero, no subnormal that would lose bits.  Otherwise the root inverse is
+// replaced by NaN, which poisons every result of the batch and, through the moments, the
+// variance of the setting: the sweep reports kappa = NaN and the host repeats it with the
+// model's sweep_eval_safe() (one guarded IEEE reciprocal per element), so a branch never
+// sits in the hot loop.
+__device__ __forceinline__ double poison_unless(bool ok, double v) { return ok ? v : __builtin_nan(""); }
+
+// pair inverses ip[h] = s / (q[2h] q[2h+1]); the caller multiplies by the sibling (sibling_of)
 template <int N>
-__device__ __forceinline__ void batch_rcp_guarded(const double (&q)[N], double (&r)[N]) {
+__device__ __forceinline__ void batch_div_poisoned(const double (&q)[N], double s, double (&ip)[(N + 1) / 2]) {
     if constexpr (N == 1) {
-        r[0] = guarded_rcp(q[0]);
+        ip[0] = s * guarded_rcp(q[0]);
+    } else if constexpr (N == 2) {
+        const double pp = q[0] * q[1];
+        const double inv = fast_rcp(pp);
+        ip[0] = poison_unless(fabs(pp) < 1e30 && fabs(inv) < 1e200, inv) * s;
+    } else if constexpr (N == 4) {
+        const double p0 = q[0] * q[1], p1 = q[2] * q[3];
+        const double inv = fast_rcp(p0 * p1);
+        const double is = poison_unless(fabs(p0) + fabs(p1) < 1e30 && fabs(inv) < 1e200, inv) * s;
+        ip[0] = is * p1;
+        ip[1] = is * p0;
     } else {
-        double pp[N / 2], ip[N / 2];
-        double mag = 0.0;
-#pragma unroll
-        for (int h = 0; h < N / 2; ++h) {
-            pp[h] = q[2 * h] * q[2 * h + 1];
-            mag += fabs(pp[h]);
-        }
-        const double inv = batch_rcp<N / 2>(pp, ip);
-        if (mag < 1e30 && fabs(inv) < 1e200) {
-#pragma unroll
-            for (int h = 0; h < N / 2; ++h) {
-                r[2 * h] = ip[h] * q[2 * h + 1];
-                r[2 * h + 1] = ip[h] * q[2 * h];
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < N; ++j) r[j] = guarded_rcp(q[j]);
-        }
+        static_assert(N == 8, "batch_div_poisoned: N must be 1, 2, 4 or 8");
+        const double p0 = q[0] * q[1], p1 = q[2] * q[3], p2 = q[4] * q[5], p3 = q[6] * q[7];
+        const double p01 = p0 * p1, p23 = p2 * p3;
+        const double inv = fast_rcp(p01 * p23);
+        const double mag = (fabs(p0) + fabs(p1)) + (fabs(p2) + fabs(p3));
+        const double is = poison_unless(mag < 1e30 && fabs(inv) < 1e200, inv) * s;
+        const double i01 = is * p23, i23 = is * p01;
+        ip[0] = i01 * p1;
+        ip[1] = i01 * p0;
+        ip[2] = i23 * p3;
+        ip[3] = i23 * p2;
     }
+}
+template <int N>
+__device__ __forceinline__ double sibling_of(const double (&q)[N], int j) {
+    if constexpr (N == 1) return 1.0;
+    else return q[j ^ 1];
+}
+
+// r[j] = 1 / q[j]
+template <int N>
+__device__ __forceinline__ void batch_rcp_poisoned(const double (&q)[N], double (&r)[N]) {
+    double ip[(N + 1) / 2];
+    batch_div_poisoned<N>(q, 1.0, ip);
+#pragma unroll
+    for (int j = 0; j < N; ++j) r[j] = ip[j / 2] * sibling_of<N>(q, j);
 }
 
 // ---------------------------------------------------------------------------
@@ -402,6 +425,11 @@ template <class M, class = void>
 struct has_pair_eval { static constexpr bool value = false; };
 template <class M>
 struct has_pair_eval<M, std::enable_if_t<M::kHasPairEval>> { static constexpr bool value = true; };
+// models whose sweep_eval() may poison out-of-range batches bring a branchy, always-IEEE twin
+template <class M, class = void>
+struct has_safe_eval { static constexpr bool value = false; };
+template <class M>
+struct has_safe_eval<M, std::enable_if_t<M::kHasSafeEval>> { static constexpr bool value = true; };
 
 #ifdef OBE_PLUGIN_MODEL_HEADER
 // ---- plugin build -------------------------------------------------------------------

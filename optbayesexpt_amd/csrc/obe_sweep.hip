@@ -94,7 +94,9 @@ struct SweepArgs {
     double* cs_out;            // (C, ns): the shift each setting used (0 when unshifted)
 };
 
-template <class M, int SPT, bool SHIFT>
+// SAFE (models with kHasSafeEval only): evaluate with the model's sweep_eval_safe() — the repeat
+// after a sweep whose fast, branch-free batch inversions poisoned a variance (kappa = NaN).
+template <class M, int SPT, bool SHIFT, bool SAFE = false>
 __global__ __launch_bounds__(kBlock) void sweep_kernel(SweepArgs a) {
     constexpr int NC = M::NC, NXS = M::NXS, NPK = M::NPK;
     constexpr int NPKW = (NPK + 1 + 1) & ~1;   // packed particle + sqrt(weight), padded to 16 B
@@ -126,7 +128,8 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(SweepArgs a) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) s1[j][c] = s2[j][c] = 0.0;
         }
-        M::template sweep_eval<SPT>(xs, pkbar, 1.0, a.m, cs);
+        if constexpr (SAFE) M::template sweep_eval_safe<SPT>(xs, pkbar, 1.0, a.m, cs);
+        else M::template sweep_eval<SPT>(xs, pkbar, 1.0, a.m, cs);
         if (!SHIFT) {
 #pragma unroll
             for (int j = 0; j < SPT; ++j)
@@ -201,14 +204,15 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(SweepArgs a) {
                 accumulate(vb, swb);
             }
         }
-#pragma unroll 2
+#pragma unroll 4
         for (; i < n; ++i) {
             double pk[NPK];
 #pragma unroll
             for (int k = 0; k < NPK; ++k) pk[k] = tile[i * NPKW + k];   // same address in every lane: LDS broadcast
             const double sw = tile[i * NPKW + NPK];
             double v[SPT][NC];
-            M::template sweep_eval<SPT>(xs, pk, sw, a.m, v);             // sqrt(w) * y'
+            if constexpr (SAFE) M::template sweep_eval_safe<SPT>(xs, pk, sw, a.m, v);
+            else M::template sweep_eval<SPT>(xs, pk, sw, a.m, v);        // sqrt(w) * y'
             accumulate(v, sw);
         }
     }
@@ -273,6 +277,11 @@ __device__ __forceinline__ void block_argmax(Best b, double* bv, int64_t* bi) {
 // latency-bound: 100+ us at 512 chunks.)
 constexpr int kFinGroups = kBlock / kWave;          // chunk groups = wavefronts
 
+// worst cancellation factor so far; a NaN (some variance is NaN) is sticky
+__device__ __forceinline__ double kappa_worst(double a, double b) {
+    return a != a ? a : (b != b ? b : (a > b ? a : b));
+}
+
 __global__ __launch_bounds__(kBlock) void sweep_finalize(const double* __restrict__ part1,
                                                          const double* __restrict__ part2, int nchunks, int nc,
                                                          int64_t ns, const double* __restrict__ moments,
@@ -314,12 +323,12 @@ __global__ __launch_bounds__(kBlock) void sweep_finalize(const double* __restric
             }
             const double mu = a1 / W;
             double v = (a2 - a1 * mu) / W;
-            v = v > 0.0 ? v : 0.0;
+            v = v > 0.0 ? v : (v != v ? v : 0.0);          // rounding may leave -0 / tiny negatives; NaN stays NaN (np.var)
             var[c] = v;
             yvar[(int64_t)c * ns + s] = v;
             const double m = cs[(int64_t)c * ns + s] + mu;
-            const double k = v > 0.0 ? (m * m) / v : (m == 0.0 ? 0.0 : INFINITY);
-            if (!(k <= kappa)) kappa = k;                  // NaN counts as "too large"
+            const double k = v != v ? v : (v > 0.0 ? (m * m) / v : (m == 0.0 ? 0.0 : INFINITY));
+            kappa = kappa_worst(kappa, k);                 // a NaN variance is reported as kappa = NaN
         }
         const double u = utility_of(var, nc, s, ua);
         utility[s] = u;
@@ -329,7 +338,7 @@ __global__ __launch_bounds__(kBlock) void sweep_finalize(const double* __restric
     red[threadIdx.x] = kappa;
     __syncthreads();
     for (int o = kBlock / 2; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o && !(red[threadIdx.x + o] <= red[threadIdx.x])) red[threadIdx.x] = red[threadIdx.x + o];
+        if ((int)threadIdx.x < o) red[threadIdx.x] = kappa_worst(red[threadIdx.x], red[threadIdx.x + o]);
         __syncthreads();
     }
     if (threadIdx.x == 0) bk[blockIdx.x] = red[0];
@@ -372,14 +381,13 @@ __global__ __launch_bounds__(kBlock) void argmax_fold(const double* __restrict__
     }
     block_argmax(best, out_v, out_i);   // gridDim.x == 1 -> writes element 0
     __shared__ double kred[kBlock];
-    double kmax = 0.0;                  // worst cancellation factor; NaN counts as "too large"
+    double kmax = 0.0;                  // worst cancellation factor; NaN is sticky
     if (bk)
-        for (int b = threadIdx.x; b < nb; b += kBlock)
-            if (!(bk[b] <= kmax)) kmax = bk[b];
+        for (int b = threadIdx.x; b < nb; b += kBlock) kmax = kappa_worst(kmax, bk[b]);
     kred[threadIdx.x] = kmax;
     __syncthreads();
     for (int o = kBlock / 2; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o && !(kred[threadIdx.x + o] <= kred[threadIdx.x])) kred[threadIdx.x] = kred[threadIdx.x + o];
+        if ((int)threadIdx.x < o) kred[threadIdx.x] = kappa_worst(kred[threadIdx.x], kred[threadIdx.x + o]);
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -450,8 +458,18 @@ static int read_best(const SweepWs& w, double* h_best, int64_t* h_best_idx, hipS
     return 0;
 }
 
+template <class M, bool SHIFT, bool SAFE>
+static void launch_sweep_spt(int spt, unsigned grid, size_t lds, const SweepArgs& a, hipStream_t st) {
+    switch (spt) {
+        case 8: sweep_kernel<M, 8, SHIFT, SAFE><<<grid, kBlock, lds, st>>>(a); break;
+        case 4: sweep_kernel<M, 4, SHIFT, SAFE><<<grid, kBlock, lds, st>>>(a); break;
+        case 2: sweep_kernel<M, 2, SHIFT, SAFE><<<grid, kBlock, lds, st>>>(a); break;
+        default: sweep_kernel<M, 1, SHIFT, SAFE><<<grid, kBlock, lds, st>>>(a); break;
+    }
+}
+
 template <class M>
-static int launch_sweep(const SweepPlan& p, SweepArgs& a, bool shifted, hipStream_t st) {
+static int launch_sweep(const SweepPlan& p, SweepArgs& a, int flags, hipStream_t st) {
     constexpr int NPKW = (M::NPK + 2) & ~1;
     int tile = kSweepLdsDoubles / NPKW;
     tile = tile / 64 * 64;
@@ -460,20 +478,17 @@ static int launch_sweep(const SweepPlan& p, SweepArgs& a, bool shifted, hipStrea
     a.tiles_x = p.tiles_x;
     a.nchunks = p.nchunks;
     const unsigned grid = (unsigned)p.tiles_x * (unsigned)((p.nchunks + 7) / 8 * 8);
-    if (shifted) {
-        switch (p.spt) {
-            case 8: sweep_kernel<M, 8, true><<<grid, kBlock, lds, st>>>(a); break;
-            case 4: sweep_kernel<M, 4, true><<<grid, kBlock, lds, st>>>(a); break;
-            case 2: sweep_kernel<M, 2, true><<<grid, kBlock, lds, st>>>(a); break;
-            default: sweep_kernel<M, 1, true><<<grid, kBlock, lds, st>>>(a); break;
+    const bool shifted = flags & OBE_SWEEP_SHIFTED;
+    bool safe = false;
+    if constexpr (has_safe_eval<M>::value) safe = flags & OBE_SWEEP_SAFE;
+    if (safe) {
+        if constexpr (has_safe_eval<M>::value) {        // always shifted: the careful variant
+            launch_sweep_spt<M, true, true>(p.spt, grid, lds, a, st);
         }
+    } else if (shifted) {
+        launch_sweep_spt<M, true, false>(p.spt, grid, lds, a, st);
     } else {
-        switch (p.spt) {
-            case 8: sweep_kernel<M, 8, false><<<grid, kBlock, lds, st>>>(a); break;
-            case 4: sweep_kernel<M, 4, false><<<grid, kBlock, lds, st>>>(a); break;
-            case 2: sweep_kernel<M, 2, false><<<grid, kBlock, lds, st>>>(a); break;
-            default: sweep_kernel<M, 1, false><<<grid, kBlock, lds, st>>>(a); break;
-        }
+        launch_sweep_spt<M, false, false>(p.spt, grid, lds, a, st);
     }
     OBE_CHECK_LAUNCH("sweep_kernel");
     return 0;
@@ -545,7 +560,7 @@ int obe_sweep_utility(const obe_model* m, const double* d_settings, int64_t ld_s
                                d_draw_idx, n_draws, d_moments, d_ws, ws_bytes, plan, a, w))
         return rc;
     hipStream_t st = as_stream(stream);
-    int rc = dispatch_model(mm, [&](auto M) -> int { return launch_sweep<decltype(M)>(plan, a, shifted != 0, st); });
+    int rc = dispatch_model(mm, [&](auto M) -> int { return launch_sweep<decltype(M)>(plan, a, shifted, st); });
     if (rc) return rc;
     UtilArgs ua{d_noise_var, noise_ld, d_cost, cost_scalar};
     const int nb = static_cast<int>((n_settings + kFinSettings - 1) / kFinSettings);
@@ -574,7 +589,7 @@ int obe_sweep_kernel_time(const obe_model* m, const double* d_settings, int64_t 
     hipEvent_t e0, e1;
     OBE_HIP_TRY(hipEventCreate(&e0));
     OBE_HIP_TRY(hipEventCreate(&e1));
-    const bool sh = shifted != 0;
+    const int sh = shifted;
     int rc = dispatch_model(mm, [&](auto M) -> int { return launch_sweep<decltype(M)>(plan, a, sh, st); });   // warm
     if (!rc) {
         (void)hipEventRecord(e0, st);

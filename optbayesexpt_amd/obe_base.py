@@ -406,12 +406,13 @@ class OptBayesExpt(ParticlePDF):
         sharded = self._shard is not None     # every sweep of a sharded object gathers: ranks stay in lockstep
         result = {}
 
-        def launch(shifted):
+        def launch(shifted, safe=False):
             # sharded: no host read here — the 32-byte result record is all-gathered from
             # device memory and read back once, together with the other ranks' records
             self._mlib.call("obe_sweep_utility", self._model_struct, s_ptr, self._n_settings, n_local,
                            _ptr(p), p.shape[1], self.n_particles, _ptr(w),
-                           None if idx is None else _ptr(idx), n_draws, _ptr(mom), 1 if shifted else 0,
+                           None if idx is None else _ptr(idx), n_draws, _ptr(mom),
+                           (_lib.OBE_SWEEP_SHIFTED if shifted else 0) | (_lib.OBE_SWEEP_SAFE if safe else 0),
                            _ptr(noise), noise_ld, None if cost_t is None else _ptr(cost_t), cost_s,
                            _ptr(self._yvar_dev), _ptr(self._utility_dev),
                            None if sharded else _lib.host_ptr(best),
@@ -443,7 +444,13 @@ class OptBayesExpt(ParticlePDF):
                 self._sweep_unshifted = False
                 shifted = True
                 launch(True)
-        self.last_sweep = dict(shifted=shifted, kappa=float(kappa[0]))
+        safe = False
+        if np.isnan(kappa[0]) and self._device_model.plugin_path:
+            # an expression model's branch-free batched divisions left their exact range somewhere
+            # (or the model really produces NaN): repeat with one IEEE reciprocal per element
+            safe = shifted = True
+            launch(True, safe=True)
+        self.last_sweep = dict(shifted=shifted, kappa=float(kappa[0]), safe=safe)
         if want_best:
             return result["best"]
         return None

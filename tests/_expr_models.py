@@ -18,6 +18,8 @@ def expression_models():
         settings=("s0", "s1", "s2", "s3"), parameters=pn, name="limits_4x16x4")
     return {
         "limits": big,
+        # a model with a true pole (tests the NaN semantics of the sweep)
+        "pole": models.from_expression("a / (x - x0)", settings=("x",), parameters=("x0", "a")),
         # demos/find_peak/sequentialLorentzian.py:53-75 as a formula
         "lorentzian": models.from_expression("b + a / (((x - x0) / d)**2 + 1)", settings=("x",),
                                              parameters=("x0", "a", "b"), constants=("d",)),

@@ -544,6 +544,53 @@ def test_expression_model_full_sweep_matches_oracle(obe):
                        np.atleast_2d(omodels.lorentzian(sv, (3.0, -1000.0, 50000.0), (0.1,))))
 
 
+def test_expression_model_out_of_range_batch_is_repeated_safely(obe):
+    """The fast sweep form of an expression model batches its divisions without a branch and
+    poisons a batch whose denominators leave the exactly-invertible range; the sweep then comes
+    back with kappa = NaN and is repeated with one IEEE reciprocal per element.  Denominators
+    of ~1e50 (pair products 1e100) must give the oracle's numbers; a true pole gives NaN at that
+    setting exactly as NumPy does."""
+    import _expr_models
+    g = np.random.default_rng(15)
+    n = 1536
+    prior = np.array([g.uniform(2, 4, n), g.uniform(-2000, -400, n), g.normal(50000, 1000, n)])
+    w = g.exponential(1.0, n)
+    w /= w.sum()
+    model = _expr_models.expression_models()["lorentzian"]
+    # the batch size follows the settings count (8 per lane from 4096 settings, 4 from 1024, 2 from 512)
+    for ns in (4100, 1030, 520):
+        sv = (np.linspace(1.5, 4.5, ns),)
+        for d, expect_safe in ((0.1, False), (1e-25, True)):
+            o = obe.OptBayesExpt(model, sv, prior.copy(), (d,), utility_method="variance_full", auto_resample=False,
+                                 default_noise_std=500.0)
+            o.particle_weights = w
+            ref = oracle.yvar_full_sweep(omodels.lorentzian, oracle.flatten_settings(sv), prior, w, (d,))
+            got = o.yvar_from_parameter_draws()
+            assert o.last_sweep["safe"] is expect_safe, (ns, d, o.last_sweep)
+            assert_allclose(got, ref, rtol=1e-9, atol=1e-9 * ref.max())
+    # reference semantics (30 draws) through the same path
+    sv = (np.linspace(1.5, 4.5, 4100),)
+    o = obe.OptBayesExpt(model, sv, prior.copy(), (1e-25,), default_noise_std=500.0)
+    b = oracle.OracleOptBayesExpt(omodels.lorentzian, sv, prior.copy(), (1e-25,), default_noise_std=500.0)
+    o.rng, b.rng = np.random.default_rng(2), np.random.default_rng(2)
+    o.opt_setting(), b.opt_setting()
+    assert o.last_sweep["safe"] and o.last_setting_index == b.last_setting_index
+    assert_allclose(o._utility_dev.cpu().numpy(), b.last_utility, rtol=1e-9, atol=1e-9 * b.last_utility.max())
+    # a pole: y = a / (x - x0) with one particle sitting exactly on a setting
+    pole = _expr_models.expression_models()["pole"]
+    x = np.linspace(1.0, 2.0, 4100)
+    pr = np.array([g.uniform(3.0, 4.0, 500), g.uniform(1.0, 2.0, 500)])
+    pr[0, 17] = x[5]
+    o = obe.OptBayesExpt(pole, (x,), pr, (), utility_method="variance_full", auto_resample=False)
+    with np.errstate(all="ignore"):
+        ref = oracle.yvar_full_sweep(lambda s, p, c: p[1] / (s[0] - p[0]), oracle.flatten_settings((x,)), pr,
+                                     np.full(500, 1 / 500), ())
+    got = o.yvar_from_parameter_draws()
+    assert o.last_sweep["safe"] and np.isnan(got[0, 5]) and np.isnan(ref[0, 5])
+    keep = np.arange(len(x)) != 5
+    assert_allclose(got[0, keep], ref[0, keep], rtol=1e-9)
+
+
 def test_device_limits_4_settings_16_parameters_4_channels(obe):
     """OBE_MAX_SETDIMS / OBE_MAX_DIMS / OBE_MAX_CHANNELS exercised together through an
     expression model with a noise parameter per channel: cycles against the oracle."""

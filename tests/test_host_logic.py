@@ -141,8 +141,10 @@ def test_expression_translator():
     # the sweep form: x/d hoisted per setting, x0/d and sqrt(w)*a, sqrt(w)*b per particle, the
     # division batched over the settings of a lane, the sums as FMAs
     assert "NXS = 1, NPK = 3" in header and "xs[0] = (x[0] * (1.0 / m.consts[0]));" in header
-    assert "pk[1] = (th(1) * sw);" in header and "batch_rcp_guarded<SPT>" in header
-    assert "v[j][0] = fma(pk[1], r0[j], pk[2]);" in header
+    assert "pk[1] = (th(1) * sw);" in header and "batch_div_poisoned<SPT>(den0, pk[1], ip0);" in header
+    assert "v[j][0] = fma(ip0[j / 2], sibling_of<SPT>(den0, j), pk[2]);" in header
+    # and its always-IEEE twin for the repeat after a poisoned sweep
+    assert "sweep_eval_safe" in header and "r0[j] = guarded_rcp(den0[j]);" in header
     assert _exprmodel.translate("b + a / (((x - x0) / d)**2 + 1)", ("x",), ("x0", "a", "b"), ("d",))[2] == digest
     rabi = ("baseline*(1 - exp(-t/T1)*contrast/2*(1 - cos(pi*2*hypot(df - fc, B1)*t))/(((df - fc)/B1)**2 + 1))")
     _, form2, _ = _exprmodel.translate(rabi, ("t", "df"), ("B1", "fc"), ("baseline", "contrast", "T1"))
