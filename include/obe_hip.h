@@ -173,6 +173,17 @@ int obe_cumsum(const double* d_x, int64_t n, int32_t strict_order, double* d_out
 int obe_interval_utility(const double* d_cum, int64_t n_settings, const int64_t* d_pairs,
                          int64_t n_pairs, const double* d_cost, double cost_of_new_sweep,
                          double* d_utility, void* stream);
+/* The index part of randdraw() for a small draw (n_draws <= 64; the reference's N_DRAWS = 30,
+ * good_setting's single draw): the uniforms travel as kernel arguments, the CDF is rebuilt
+ * unless cdf_is_fresh (d_cdf still holds the CDF of d_weights), and for clouds of up to
+ * 65 536 particles scan and search are one launch.  Same CDF bits and indices as
+ * obe_weight_cdf + obe_cdf_search.  Never synchronises: when the CDF is rebuilt and
+ * h_total_pinned != NULL (pinned host memory), sum(w) is copied there asynchronously and is
+ * valid after the caller's next synchronisation of the stream. */
+int obe_draw_indices(const double* d_weights, int64_t n_particles, int32_t strict_order,
+                     int32_t cdf_is_fresh, double* d_cdf, const double* h_uniforms,
+                     int32_t n_draws, int64_t* d_idx, double* h_total_pinned,
+                     void* d_ws, int64_t ws_bytes, void* stream);
 /* idx[j] = #{i : cdf[i] <= u[j]}  (searchsorted side='right'), int64. */
 int obe_cdf_search(const double* d_cdf, int64_t n, const double* d_uniforms, int64_t n_draws,
                    int64_t* d_idx_out, void* stream);

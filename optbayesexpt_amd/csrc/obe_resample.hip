@@ -127,6 +127,77 @@ __global__ __launch_bounds__(kWave) void cdf_strict_kernel(const double* __restr
     }
 }
 
+// The uniforms of a small draw (randdraw's 30 parameter sets, good_setting's single one) travel
+// as kernel arguments: no host-to-device copy.
+constexpr int kMaxArgDraws = 64;
+struct UniformArg {
+    double u[kMaxArgDraws];
+};
+
+__device__ __forceinline__ int64_t search_right(const double* cdf, int64_t n, double x) {
+    int64_t lo = 0, hi = n;                 // first i with cdf[i] > x
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (cdf[mid] <= x) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(kWave) void cdf_search_arg_kernel(const double* __restrict__ cdf, int64_t n, UniformArg ua,
+                                                               int nd, int64_t* __restrict__ idx) {
+    if ((int)threadIdx.x < nd) idx[threadIdx.x] = search_right(cdf, n, ua.u[threadIdx.x]);
+}
+
+// CDF + search in one launch for clouds of up to kSmallCloud particles: one workgroup walks the
+// 2048-weight tiles with the same tile_scan / tile-offset arithmetic as the three-kernel path
+// (identical CDF bits), then up to 64 threads run the searches.  total_out[0] = sum(w).
+constexpr int64_t kSmallCloud = 65536;
+constexpr int kSmallTiles = static_cast<int>(kSmallCloud / kScanTile);
+
+__global__ __launch_bounds__(kBlock) void draw_small_kernel(const double* __restrict__ w, int64_t n,
+                                                            double* __restrict__ cdf, UniformArg ua, int nd,
+                                                            int64_t* __restrict__ idx, double* __restrict__ total_out) {
+    __shared__ double lds[kBlock / kWave];
+    __shared__ double toff[kSmallTiles + 1];
+    const int nb = static_cast<int>((n + kScanTile - 1) / kScanTile);
+    double v[kScanItems];
+    for (int b = 0; b < nb; ++b) {
+        load_tile(w, n, (int64_t)b * kScanTile, v);
+        const double total = tile_scan(v, lds);
+        if (threadIdx.x == 0) toff[b] = total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {                 // exclusive scan of the tile totals, in tile order (scan_offsets)
+        double run = 0.0;
+        for (int b = 0; b < nb; ++b) {
+            const double t = toff[b];
+            toff[b] = run;
+            run = run + t;
+        }
+        toff[nb] = run;
+        total_out[0] = run;
+    }
+    __syncthreads();
+    const double total = toff[nb];
+    for (int b = 0; b < nb; ++b) {
+        const int64_t base = (int64_t)b * kScanTile;
+        load_tile(w, n, base, v);
+        tile_scan(v, lds);
+        const double off = toff[b];
+        const int64_t i0 = base + (int64_t)threadIdx.x * kScanItems;
+#pragma unroll
+        for (int k = 0; k < kScanItems; ++k) {
+            const int64_t i = i0 + k;
+            if (i < n) cdf[i] = (i == n - 1) ? 1.0 : (off + v[k]) / total;
+        }
+        __syncthreads();
+    }
+    __threadfence_block();
+    __syncthreads();
+    if ((int)threadIdx.x < nd) idx[threadIdx.x] = search_right(cdf, n, ua.u[threadIdx.x]);
+}
+
 // idx = first i with cdf[i] > u   (searchsorted side='right')
 __global__ __launch_bounds__(kBlock) void cdf_search_kernel(const double* __restrict__ cdf, int64_t n,
                                                             const double* __restrict__ u, int64_t nd,
@@ -276,6 +347,35 @@ int obe_interval_utility(const double* d_cum, int64_t n_settings, const int64_t*
     interval_utility_kernel<<<stream_blocks(n_pairs, kBlock), kBlock, 0, as_stream(stream)>>>(
         d_cum, n_settings, d_pairs, n_pairs, d_cost, cost_of_new_sweep, d_utility);
     OBE_CHECK_LAUNCH("interval_utility_kernel");
+    return 0;
+}
+
+int obe_draw_indices(const double* d_weights, int64_t n_particles, int32_t strict_order, int32_t cdf_is_fresh,
+                     double* d_cdf, const double* h_uniforms, int32_t n_draws, int64_t* d_idx,
+                     double* h_total_pinned, void* d_ws, int64_t ws_bytes, void* stream) {
+    if (!d_weights || !d_cdf || !h_uniforms || !d_idx || n_particles <= 0 || n_draws <= 0 || n_draws > kMaxArgDraws)
+        return bad_arg("obe_draw_indices: bad pointer/size (at most 64 draws)");
+    if (!d_ws || ws_bytes < 8 * (int64_t)sizeof(double)) return bad_arg("obe_draw_indices: workspace too small");
+    hipStream_t st = as_stream(stream);
+    UniformArg ua{};
+    for (int i = 0; i < n_draws; ++i) ua.u[i] = h_uniforms[i];
+    double* scalars = static_cast<double*>(d_ws);
+    if (cdf_is_fresh) {
+        cdf_search_arg_kernel<<<1, kWave, 0, st>>>(d_cdf, n_particles, ua, n_draws, d_idx);
+        OBE_CHECK_LAUNCH("cdf_search_arg_kernel");
+        return 0;
+    }
+    if (!strict_order && n_particles <= kSmallCloud) {
+        draw_small_kernel<<<1, kBlock, 0, st>>>(d_weights, n_particles, d_cdf, ua, n_draws, d_idx, scalars);
+        OBE_CHECK_LAUNCH("draw_small_kernel");
+    } else {
+        if (int rc = scan_common("obe_draw_indices: bad pointer/size", d_weights, n_particles, strict_order, 1, d_cdf,
+                                 nullptr, d_ws, ws_bytes, stream))
+            return rc;
+        cdf_search_arg_kernel<<<1, kWave, 0, st>>>(d_cdf, n_particles, ua, n_draws, d_idx);
+        OBE_CHECK_LAUNCH("cdf_search_arg_kernel");
+    }
+    if (h_total_pinned) OBE_HIP_TRY(hipMemcpyAsync(h_total_pinned, scalars, sizeof(double), hipMemcpyDeviceToHost, st));
     return 0;
 }
 

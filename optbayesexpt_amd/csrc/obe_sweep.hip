@@ -38,6 +38,9 @@ static int64_t argmax_slots(int64_t n_settings) {
     return std::max<int64_t>(kMaxBlocks, (n_settings + kFinSettings - 1) / kFinSettings);
 }
 
+// one-workgroup path for reference-semantics sweeps (sweep_small_kernel)
+constexpr int64_t kSmallSweepDraws = 256, kSmallSweepEvals = 131072;
+
 struct SweepPlan {
     int spt;           // settings per thread
     int tiles_x;       // setting tiles
@@ -403,6 +406,97 @@ __global__ __launch_bounds__(kBlock) void argmax_fold(const double* __restrict__
     }
 }
 
+// Reference-semantics sweeps are tiny (201 settings x 30 draws in the demos): one workgroup
+// does what sweep_kernel + sweep_finalize + argmax_fold do in three launches — the draws are
+// packed into LDS once, each thread walks its settings, and the block folds utility, first
+// maximum and kappa.  Same formulas and summation order as the SPT = 1, one-chunk path of the
+// big kernels, hence the same bits.
+template <class M, bool SAFE>
+__global__ __launch_bounds__(kBlock) void sweep_small_kernel(SweepArgs a, UtilArgs ua, double* __restrict__ yvar,
+                                                             double* __restrict__ utility,
+                                                             double* __restrict__ out_v,
+                                                             int64_t* __restrict__ out_i) {
+    constexpr int NC = M::NC, NXS = M::NXS, NPK = M::NPK;
+    constexpr int NPKW = (NPK + 1 + 1) & ~1;
+    extern __shared__ __attribute__((aligned(16))) double tile[];
+    __shared__ double kred[kBlock];
+    const double* __restrict__ thbar = a.moments + 2;
+    const int nd = static_cast<int>(a.nd);
+    for (int i = threadIdx.x; i < nd; i += kBlock) {
+        int64_t src = a.draw_idx[i];
+        src = src < 0 ? 0 : (src >= a.n_particles ? a.n_particles - 1 : src);
+        const double sw = sqrt(a.uniform_w);
+        double pk[NPK];
+        M::pack(ParamRef{a.particles + src, a.ld_p}, thbar, a.m, sw, pk);
+#pragma unroll
+        for (int k = 0; k < NPK; ++k) tile[i * NPKW + k] = pk[k];
+        tile[i * NPKW + NPK] = sw;
+    }
+    __syncthreads();
+    double pkbar[NPK];
+    M::pack(ParamRef{thbar, 1}, thbar, a.m, 1.0, pkbar);
+    auto eval = [&](const double (&xs)[1][NXS], const double* pk, double sw, double (&v)[1][NC]) {
+        if constexpr (SAFE) M::template sweep_eval_safe<1>(xs, pk, sw, a.m, v);
+        else M::template sweep_eval<1>(xs, pk, sw, a.m, v);
+    };
+    const double W = 1.0;      // draws mode: uniform weights 1/nd
+    Best best{-INFINITY, INT64_MAX};
+    double kappa = 0.0;
+    for (int64_t s = threadIdx.x; s < a.ns; s += kBlock) {
+        double x[M::NS], xs[1][NXS], cs[1][NC], s1[NC], s2[NC];
+#pragma unroll
+        for (int k = 0; k < M::NS; ++k) x[k] = a.settings[(int64_t)k * a.ld_s + s];
+        M::prep_setting(x, a.m, xs[0]);
+        eval(xs, pkbar, 1.0, cs);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) s1[c] = s2[c] = 0.0;
+        for (int i = 0; i < nd; ++i) {
+            double pk[NPK], v[1][NC];
+#pragma unroll
+            for (int k = 0; k < NPK; ++k) pk[k] = tile[i * NPKW + k];
+            const double sw = tile[i * NPKW + NPK];
+            eval(xs, pk, sw, v);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const double u = fma(-cs[0][c], sw, v[0][c]);
+                s1[c] = fma(sw, u, s1[c]);
+                s2[c] = fma(u, u, s2[c]);
+            }
+        }
+        double var[OBE_MAX_CHANNELS];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const double mu = s1[c] / W;
+            double v = (s2[c] - s1[c] * mu) / W;
+            v = v > 0.0 ? v : (v != v ? v : 0.0);
+            var[c] = v;
+            yvar[(int64_t)c * a.ns + s] = v;
+            const double m = cs[0][c] + mu;
+            const double k = v != v ? v : (v > 0.0 ? (m * m) / v : (m == 0.0 ? 0.0 : INFINITY));
+            kappa = kappa_worst(kappa, k);
+        }
+        const double u = utility_of(var, NC, s, ua);
+        utility[s] = u;
+        const Best cand{u, s};
+        if (better(cand, best)) best = cand;
+    }
+    block_argmax(best, out_v, out_i);       // one block: element 0
+    kred[threadIdx.x] = kappa;
+    __syncthreads();
+    for (int o = kBlock / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) kred[threadIdx.x] = kappa_worst(kred[threadIdx.x], kred[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {                 // the result record, as argmax_fold leaves it
+        const double k = kred[0];
+        out_v[1] = k;
+        out_v[2] = out_v[0];
+        reinterpret_cast<int64_t*>(out_v)[3] = out_i[0];
+        out_v[4] = k;
+        out_v[5] = 0.0;
+    }
+}
+
 // np.var(utility_y_space, axis=0): two-pass over the (small) draw axis
 __global__ __launch_bounds__(kBlock) void yspace_var_kernel(const double* __restrict__ ysp, int64_t nd,
                                                             int64_t row /* C*Ns */, double* __restrict__ yvar) {
@@ -560,9 +654,29 @@ int obe_sweep_utility(const obe_model* m, const double* d_settings, int64_t ld_s
                                d_draw_idx, n_draws, d_moments, d_ws, ws_bytes, plan, a, w))
         return rc;
     hipStream_t st = as_stream(stream);
+    UtilArgs ua{d_noise_var, noise_ld, d_cost, cost_scalar};
+    static const bool no_small = getenv("OBE_SWEEP_NO_SMALL") != nullptr;      // test / tuning aid
+    if (d_draw_idx && !no_small && n_draws <= kSmallSweepDraws && n_settings * n_draws <= kSmallSweepEvals) {
+        int rc = dispatch_model(mm, [&](auto M) -> int {
+            using Model = decltype(M);
+            constexpr int NPKW = (Model::NPK + 2) & ~1;
+            const size_t lds = (size_t)n_draws * NPKW * sizeof(double);
+            bool safe = false;
+            if constexpr (has_safe_eval<Model>::value) safe = shifted & OBE_SWEEP_SAFE;
+            if (safe) {
+                if constexpr (has_safe_eval<Model>::value)
+                    sweep_small_kernel<Model, true><<<1, kBlock, lds, st>>>(a, ua, d_yvar, d_utility, w.out_v, w.out_i);
+            } else {
+                sweep_small_kernel<Model, false><<<1, kBlock, lds, st>>>(a, ua, d_yvar, d_utility, w.out_v, w.out_i);
+            }
+            OBE_CHECK_LAUNCH("sweep_small_kernel");
+            return 0;
+        });
+        if (rc) return rc;
+        return read_best(w, h_best, h_best_idx, st, h_kappa);
+    }
     int rc = dispatch_model(mm, [&](auto M) -> int { return launch_sweep<decltype(M)>(plan, a, shifted, st); });
     if (rc) return rc;
-    UtilArgs ua{d_noise_var, noise_ld, d_cost, cost_scalar};
     const int nb = static_cast<int>((n_settings + kFinSettings - 1) / kFinSettings);
     if (nb > kFinMaxBlocks) return bad_arg("obe_sweep_utility: more than 4 194 304 settings per call");
     sweep_finalize<<<nb, kBlock, 0, st>>>(w.part1, w.part2, plan.nchunks, mm.n_channels, n_settings, d_moments,

@@ -391,7 +391,8 @@ class OptBayesExpt(ParticlePDF):
         idx = None
         n_draws = 0
         if not full:
-            idx = self._draw_indices(self.N_DRAWS)       # consumes N_DRAWS uniforms (randdraw)
+            # consumes N_DRAWS uniforms (randdraw); its check of sum(w) waits for the sweep's own sync
+            idx = self._draw_indices(self.N_DRAWS, defer_validation=True)
             n_draws = self.N_DRAWS
         mom = self._moments_on_device()
         p, w = self._pw_tensors()
@@ -437,6 +438,7 @@ class OptBayesExpt(ParticlePDF):
         mode = self.tuning_parameters.get("sweep_shift", "auto")
         shifted = (not full) or mode == "always" or (mode == "auto" and not self._sweep_unshifted)
         launch(shifted)
+        self._check_pending_total()
         if full and mode == "auto":
             if shifted:
                 self._sweep_unshifted = bool(kappa[0] < self.KAPPA_ENTER)

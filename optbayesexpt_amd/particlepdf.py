@@ -99,6 +99,8 @@ class ParticlePDF:
         self._mom_dev_key = None       # same, for the device copy
         self._cdf_dev = torch.empty(n, dtype=torch.float64, device=self._device)
         self._cdf_key = None           # (weights version, strict)
+        self._total_pinned = torch.zeros(8, dtype=torch.float64).pin_memory()   # async sum(w) of a small draw
+        self._pending_total = None     # (generator state before the draw,) while that sum is unchecked
         self._sumsq_key = None         # weights version for which _sumsq is valid
         self._sumsq = None
         self.last_draw_indices_device = None
@@ -245,12 +247,7 @@ class ParticlePDF:
             self._lib.call("obe_weight_cdf", _ptr(w), self.n_particles, 1 if strict else 0,
                            _ptr(self._cdf_dev), _lib.host_ptr(self._host_out), _ptr(self._ws),
                            self._ws_bytes, self._stream())
-            total = self._host_out[0]
-            # numpy's validation of p in Generator.choice (ValueError in the reference)
-            if total != total:
-                raise ValueError("probabilities contain NaN")
-            if abs(total - 1.0) > SQRT_EPS:
-                raise ValueError("probabilities do not sum to 1")
+            self._validate_total(self._host_out[0])
             self._cdf_key = key
         return self._cdf_dev
 
@@ -264,22 +261,73 @@ class ParticlePDF:
             return None
         return _devrng.DeviceStream(self._lib, self._device, self._stream(), self.rng, n_uniform, n_normal)
 
-    def _draw_indices(self, n_draws, stream=None):
+    @staticmethod
+    def _validate_total(total):
+        # numpy's validation of p in Generator.choice (ValueError in the reference)
+        if total != total:
+            raise ValueError("probabilities contain NaN")
+        if abs(total - 1.0) > SQRT_EPS:
+            raise ValueError("probabilities do not sum to 1")
+
+    def _check_pending_total(self):
+        """After a stream synchronisation: the deferred validation of the weights a small draw
+        used.  On failure the generator is put back where it was before the draw — numpy
+        validates p before it consumes any uniforms."""
+        if self._pending_total is None:
+            return
+        (state,), self._pending_total = self._pending_total, None
+        try:
+            self._validate_total(float(self._total_pinned[0]))
+        except ValueError:
+            if state is not None:
+                self.rng.bit_generator.state = state
+            self._cdf_key = None
+            raise
+
+    def _draw_indices(self, n_draws, stream=None, defer_validation=False):
         """Device int64 indices of ``n_draws`` weighted draws: the uniforms
-        Generator.choice would take from self.rng, CDF search on the device."""
+        Generator.choice would take from self.rng, CDF search on the device.
+
+        ``defer_validation``: the caller synchronises the stream soon anyway and then calls
+        ``_check_pending_total()`` — the draw itself then never waits for the device."""
         if self._weights.shape[0] != self.n_particles:
             raise ValueError("a and p must have same size")
-        cdf = self._cdf()
         own = stream is None
         if own:
             stream = self._device_stream(n_draws, 0)
+        idx = torch.empty(n_draws, dtype=torch.int64, device=self._device)
+        if stream is None and n_draws <= 64:
+            # small draw: uniforms as kernel arguments, CDF + search in one call, no synchronisation
+            strict = bool(self.tuning_parameters.get("strict_cdf", False))
+            key = (self._weights.version, strict)
+            fresh = self._cdf_key == key
+            w = self._weights.tensor()
+            if self._cdf_dev.numel() != self.n_particles:
+                self._cdf_dev = torch.empty(self.n_particles, dtype=torch.float64, device=self._device)
+                fresh = False
+            state = None
+            if not fresh and hasattr(self.rng, "bit_generator"):
+                state = self.rng.bit_generator.state
+            u = np.atleast_1d(self.rng.random(n_draws))
+            self._lib.call("obe_draw_indices", _ptr(w), self.n_particles, 1 if strict else 0, 1 if fresh else 0,
+                           _ptr(self._cdf_dev), _lib.host_ptr(u), n_draws, _ptr(idx),
+                           None if fresh else _P(self._total_pinned.data_ptr()), _ptr(self._ws), self._ws_bytes,
+                           self._stream())
+            if not fresh:
+                self._cdf_key = key
+                self._pending_total = (state,)
+                if not defer_validation:
+                    torch.cuda.current_stream(self._device).synchronize()
+                    self._check_pending_total()
+            self.last_draw_indices_device = idx
+            return idx
+        cdf = self._cdf()
         if stream is not None:
             u_dev = stream.uniforms()
             if own:
                 stream.finish_uniform_only()
         else:
             u_dev = torch.from_numpy(np.atleast_1d(self.rng.random(n_draws))).to(self._device)
-        idx = torch.empty(n_draws, dtype=torch.int64, device=self._device)
         self._lib.call("obe_cdf_search", _ptr(cdf), self.n_particles, _ptr(u_dev), n_draws, _ptr(idx),
                        self._stream())
         self.last_draw_indices_device = idx

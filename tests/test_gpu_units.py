@@ -568,8 +568,9 @@ def test_expression_model_out_of_range_batch_is_repeated_safely(obe):
             got = o.yvar_from_parameter_draws()
             assert o.last_sweep["safe"] is expect_safe, (ns, d, o.last_sweep)
             assert_allclose(got, ref, rtol=1e-9, atol=1e-9 * ref.max())
-    # reference semantics (30 draws) through the same path
-    sv = (np.linspace(1.5, 4.5, 4100),)
+    # reference semantics (30 draws) through the same path (8200 settings: beyond the one-workgroup
+    # sweep, which evaluates element by element and never needs the repeat)
+    sv = (np.linspace(1.5, 4.5, 8200),)
     o = obe.OptBayesExpt(model, sv, prior.copy(), (1e-25,), default_noise_std=500.0)
     b = oracle.OracleOptBayesExpt(omodels.lorentzian, sv, prior.copy(), (1e-25,), default_noise_std=500.0)
     o.rng, b.rng = np.random.default_rng(2), np.random.default_rng(2)
