@@ -609,11 +609,11 @@ class OptBayesExpt(ParticlePDF):
         cdf = torch.empty(n, dtype=torch.float64, device=self._device)
         self._lib.call("obe_power_normalize", _ptr(u), n, float(pickiness), _ptr(prob), _ptr(self._ws),
                        self._ws_bytes, self._stream())
-        self._lib.call("obe_weight_cdf", _ptr(prob), n, 0, _ptr(cdf), None, _ptr(self._ws), self._ws_bytes,
-                       self._stream())
-        uni = torch.from_numpy(np.atleast_1d(self.rng.random())).to(self._device)
+        uni = np.atleast_1d(self.rng.random())
         idx = torch.empty(1, dtype=torch.int64, device=self._device)
-        self._lib.call("obe_cdf_search", _ptr(cdf), n, _ptr(uni), 1, _ptr(idx), self._stream())
+        # CDF of the selection probabilities + the search for one uniform (passed by value)
+        self._lib.call("obe_draw_indices", _ptr(prob), n, 0, 0, _ptr(cdf), _lib.host_ptr(uni), 1, _ptr(idx), None,
+                       _ptr(self._ws), self._ws_bytes, self._stream())
         goodindex = int(idx.cpu()[0])
         self.last_setting_index = goodindex
         return tuple(self.allsettings[:, goodindex])

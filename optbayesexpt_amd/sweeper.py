@@ -206,10 +206,10 @@ class OptBayesExptSweeper(OptBayesExptNoiseParameter):
         cdf = torch.empty(n, dtype=torch.float64, device=self._device)
         self._lib.call("obe_power_normalize", _ptr(u), n, float(self.pickiness), _ptr(prob), _ptr(ws), wsb,
                        self._stream())
-        self._lib.call("obe_weight_cdf", _ptr(prob), n, 0, _ptr(cdf), None, _ptr(ws), wsb, self._stream())
-        uni = torch.from_numpy(np.atleast_1d(rng.random())).to(self._device)
+        uni = np.atleast_1d(rng.random())
         idx = torch.empty(1, dtype=torch.int64, device=self._device)
-        self._lib.call("obe_cdf_search", _ptr(cdf), n, _ptr(uni), 1, _ptr(idx), self._stream())
+        self._lib.call("obe_draw_indices", _ptr(prob), n, 0, 0, _ptr(cdf), _lib.host_ptr(uni), 1, _ptr(idx), None,
+                       _ptr(ws), wsb, self._stream())
         index = int(idx.cpu()[0])
         self.last_setting_index = index
         return self.start_stop_indices[index]
