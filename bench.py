@@ -25,6 +25,7 @@ import json
 import os
 import sys
 import time
+import warnings
 
 import numpy as np
 
@@ -79,7 +80,7 @@ def build_obe(cfg, shard, settings, prior, cons):
                                           settings_shard=shard)
 
 
-def cpu_baseline(cfg, settings, prior, cons, true, sigma, target_s=6.0):
+def cpu_baseline(cfg, settings, prior, cons, true, sigma, target_s=10.0):
     """The oracle (NumPy, one core) on a bounded sample of the same workload: the full
     particle cloud against a sub-grid of evenly spaced settings for the sweep, plus the
     full update.  A short probe sizes the sub-grid for ~``target_s`` seconds of CPU work.
@@ -90,6 +91,24 @@ def cpu_baseline(cfg, settings, prior, cons, true, sigma, target_s=6.0):
     fn = om.lorentzian if CONFIGS[cfg][2] == "lorentzian" else om.multi_lorentzian(7)
     ns, n_p = CONFIGS[cfg][0], CONFIGS[cfg][1]
     w = np.full(n_p, 1.0 / n_p)
+    if cfg == "c1":
+        # reference semantics: the oracle class itself through whole opt_setting + pdf_update
+        # cycles (N_DRAWS = 30 weighted draws, resamples included), like the timed GPU loop
+        o = oracle.OracleOptBayesExpt(fn, settings, prior.copy(), cons, scale=False, default_noise_std=sigma)
+        o.rng = np.random.default_rng(1)
+        sim = np.random.default_rng(2)
+        n_cycles, t0 = 0, time.perf_counter()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            while time.perf_counter() - t0 < min(target_s, 3.0):
+                x = o.opt_setting()
+                o.pdf_update((x, float(fn(x, true, cons)) + sigma * sim.standard_normal(), sigma))
+                n_cycles += 1
+        dt = time.perf_counter() - t0
+        return {"value": n_cycles * (ns * o.N_DRAWS + n_p) / dt, "unit": "model-evals/s", "cores": 1, "kind": "port",
+                "sample": f"{n_cycles} opt_setting + pdf_update cycles of the oracle class ({ns} settings x "
+                          f"{o.N_DRAWS} draws + {n_p}-particle update each), {dt:.1f} s, {1e3 * dt / n_cycles:.3f} ms per cycle",
+                "host_cpus": os.cpu_count()}
 
     def cycle(n_sub):
         sub = (np.ascontiguousarray(settings[0][:: max(1, ns // n_sub)][:n_sub]),)
@@ -321,6 +340,7 @@ def main():
            "roofline": roofline, "roofline_update": roofline_update}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, settings, prior, cons, true, sigma)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and obe.utility_method == "variance_full":
         try:
             out["cpu_baseline_allcores"] = cpu_baseline_allcores(cfg, settings, prior, cons, true, sigma)
         except Exception as exc:          # no gcc/OpenMP on the box: the 1-core figure stands alone

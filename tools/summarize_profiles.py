@@ -84,3 +84,27 @@ allcfg = json.load(open(tpath)) if os.path.exists(tpath) else {}
 allcfg[cfg] = {"sweep_kernel_hbm_bytes_per_launch": summary.get("sweep_kernel_hbm_bytes_per_launch"),
                "source": os.path.basename(path)}
 json.dump(allcfg, open(tpath, "w"), indent=1)
+
+# 3. SQ issue counters of the sweep kernel (tools/profile_sq.sh), if collected
+sq_db = os.path.join(ROOT, "gpurun_out", "prof_sq", "sq")
+dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(sq_db) for f in fs if f.endswith(".db")] if os.path.isdir(sq_db) else []
+if dbs:
+    c = sqlite3.connect(dbs[0])
+    q = ("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
+         "where kernel_name like '%sweep_kernel%' group by kernel_name, counter_name")
+    out = {}
+    for name, counter, n, avg in c.execute(q):
+        out.setdefault(short(name), {"dispatches": n})[counter] = avg
+    for k, v in out.items():
+        if "GRBM_GUI_ACTIVE" in v and "SQ_ACTIVE_INST_VALU" in v:
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_* counters are in quad-cycles summed over
+            # all 1024 SIMDs (MI355X_MICROARCH.md: PMC units)
+            cycles = v["GRBM_GUI_ACTIVE"] / 8.0
+            v["derived"] = {"shader_cycles_per_launch": cycles,
+                            "valu_busy_fraction": v["SQ_ACTIVE_INST_VALU"] / (cycles / 4.0 * 1024),
+                            "mean_waves_per_simd": v["SQ_WAVE_CYCLES"] / (cycles / 4.0 * 1024),
+                            "note": "effective clock = shader_cycles_per_launch / launch duration of the same run"}
+    json.dump({"config": cfg, "source": "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU "
+               "SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE (own pass)",
+               "kernels": out}, open(os.path.join(DST, f"{tag}_sq_issue_{cfg}.json"), "w"), indent=1)
+    print(json.dumps(out, indent=1)[:3000])
