@@ -1,0 +1,35 @@
+"""The two example scripts (the reference demos' measurement loops against this package)
+run end to end on the GPU and recover the simulated parameters."""
+import importlib.util
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load(name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "examples", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("selection", ["optimal", "good"])
+def test_find_peak_example(hip, selection):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        true, mean, std = load("find_peak").main(n_measure=150, n_samples=20000, selection=selection, seed=3, quiet=True)
+    assert np.all(np.abs(mean - np.array(true)) < 5 * std + 1e-9)
+    assert std[0] < 0.01                                  # the peak position is pinned down
+
+
+def test_sweeper_example(hip):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        true, mean, std = load("sweeper").main(n_measure=1200, n_samples=20000, selection="good", seed=4, quiet=True)
+    assert np.all(np.abs(mean - np.array(true)) < 6 * std + 1e-9)
+    assert std[0] < 0.05
