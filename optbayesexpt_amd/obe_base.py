@@ -482,35 +482,48 @@ class OptBayesExpt(ParticlePDF):
         return self._utility_from_host_yvar(var_p)
 
     def _utility_from_host_yvar(self, var_p):
-        """sum_c var_p / var_n / cost on the device from a (C, N_s) variance (host array or
-        device tensor)."""
-        if isinstance(var_p, torch.Tensor):
+        """sum_c var_p / var_n / cost on the device from a (C, N_s) variance: a host array over
+        all settings, or a device tensor over this rank's settings slice (then the slices'
+        utilities are gathered, so every rank returns the full (N_s,) vector)."""
+        local = isinstance(var_p, torch.Tensor)
+        if local:
             yv = var_p
+            n = self._s_end - self._s_begin
         else:
+            if self._shard is not None:
+                raise NotImplementedError("a host-side variance with a sharded settings axis: evaluate on "
+                                          "the device (DeviceModel) or build the object without settings_shard")
+            n = self._n_settings
             yv = torch.from_numpy(np.array(np.broadcast_to(np.asarray(var_p, dtype=np.float64),
-                                                           (self.n_channels, self._n_settings)))).to(self._device)
-        if self._shard is not None:
-            raise NotImplementedError("this utility method with a sharded settings axis (SURVEY.md §8e, next)")
+                                                           (self.n_channels, n)))).to(self._device)
         noise, noise_ld = self._noise_var_device()
         cost_t, cost_s = self._cost_device()
-        util = torch.empty(self._n_settings, dtype=torch.float64, device=self._device)
-        self._lib.call("obe_utility_argmax", _ptr(yv), self.n_channels, self._n_settings, _ptr(noise), noise_ld,
-                       None if cost_t is None else _ptr(cost_t), cost_s,
-                       _ptr(util), None, None, _ptr(self._ws), self._ws_bytes, self._stream())
-        return util.cpu().numpy()
+        util = torch.empty(max(n, 1), dtype=torch.float64, device=self._device)
+        if n > 0:
+            self._lib.call("obe_utility_argmax", _ptr(yv), self.n_channels, n, _ptr(noise), noise_ld,
+                           None if cost_t is None else _ptr(cost_t), cost_s,
+                           _ptr(util), None, None, _ptr(self._ws), self._ws_bytes, self._stream())
+        return self._gather_settings(util[:n].reshape(1, -1))[0]
 
     # ---- the y-space utilities (obe_base.py:491-535, 602-626, 657-720; SURVEY.md §8f-3) ----
     def _yspace_device(self):
-        """utility_y_space on the device, (N_DRAWS, C, N_s): the model over all settings for
-        N_DRAWS fresh weighted draws (consumes N_DRAWS uniforms of self.rng)."""
-        nd, c, ns = self.N_DRAWS, self.n_channels, self._n_settings
+        """utility_y_space on the device, (N_DRAWS, C, n): the model over this rank's settings
+        (all of them unless sharded) for N_DRAWS fresh weighted draws (consumes N_DRAWS uniforms
+        of self.rng — the same ones on every rank of a sharded object)."""
+        nd, c = self.N_DRAWS, self.n_channels
         if self._device_model is not None and not _overridden(self, "eval_over_all_settings", OptBayesExpt):
             idx = self._draw_indices(nd)
             p = self._particles.tensor()
-            ysp = torch.empty((nd, c, ns), dtype=torch.float64, device=self._device)
-            self._mlib.call("obe_eval_draws", self._model_struct, _ptr(self._settings_dev), ns, ns, _ptr(p),
-                           p.shape[1], self.n_particles, _ptr(idx), nd, _ptr(ysp), self._stream())
-            return ysp
+            n = self._s_end - self._s_begin
+            ysp = torch.empty((nd, c, max(n, 1)), dtype=torch.float64, device=self._device)
+            if n > 0:
+                s_ptr = _P(self._settings_dev.data_ptr() + 8 * self._s_begin)
+                self._mlib.call("obe_eval_draws", self._model_struct, s_ptr, self._n_settings, n, _ptr(p),
+                                p.shape[1], self.n_particles, _ptr(idx), nd, _ptr(ysp), self._stream())
+            return ysp if n else ysp[:, :, :0]
+        if self._shard is not None:
+            raise NotImplementedError("y-space utilities of a host-callable model with a sharded settings axis")
+        ns = self._n_settings
         paramsets = self.randdraw(nd).T              # host-callable model: the user's function fills it
         for i, oneparamset in enumerate(paramsets):
             self.utility_y_space[i] = self.eval_over_all_settings(oneparamset)
@@ -525,30 +538,42 @@ class OptBayesExpt(ParticlePDF):
             raise ValueError(f"Window length ({m}) must be positive and less "
                              f"than half the sample size ({nd}).")
         out = torch.empty(ysp.shape[1:], dtype=torch.float64, device=self._device)
-        scratch = torch.empty(nd * cols, dtype=torch.float64, device=self._device)
-        self._lib.call("obe_yspace_entropy", _ptr(ysp), nd, cols, 1 if as_variance else 0, _ptr(scratch),
-                       _ptr(out), self._stream())
+        if cols:
+            scratch = torch.empty(nd * cols, dtype=torch.float64, device=self._device)
+            self._lib.call("obe_yspace_entropy", _ptr(ysp), nd, cols, 1 if as_variance else 0, _ptr(scratch),
+                           _ptr(out), self._stream())
         return out
 
     def yvar_from_entropy(self):
         """Variance of the normal distribution with the model outputs' differential entropy,
         per setting (obe_base.py:491-518)."""
-        return self._column_entropy(self._yspace_device(), True).cpu().numpy()
+        return self._gather_settings(self._yvar_from_entropy_device())
+
+    def _yvar_from_entropy_device(self):
+        return self._column_entropy(self._yspace_device(), True)
 
     def yvar_max_min(self):
         """(max - min)^2 of the model outputs over the draws (obe_base.py:520-535)."""
+        return self._gather_settings(self._yvar_max_min_device())
+
+    def _yvar_max_min_device(self):
         ysp = self._yspace_device()
         out = torch.empty(ysp.shape[1:], dtype=torch.float64, device=self._device)
-        self._lib.call("obe_yspace_maxmin", _ptr(ysp), ysp.shape[0], ysp[0].numel(), _ptr(out), self._stream())
-        return out.cpu().numpy()
+        if out.numel():
+            self._lib.call("obe_yspace_maxmin", _ptr(ysp), ysp.shape[0], ysp[0].numel(), _ptr(out), self._stream())
+        return out
 
     def utility_max_min(self):
         """obe_base.py:602-626."""
-        return self._utility_from_host_yvar(self.yvar_max_min())
+        if _overridden(self, "yvar_max_min", OptBayesExpt):
+            return self._utility_from_host_yvar(self.yvar_max_min())
+        return self._utility_from_host_yvar(self._yvar_max_min_device())
 
     def utility_pseudo(self):
         """obe_base.py:657-686."""
-        return self._utility_from_host_yvar(self.yvar_from_entropy())
+        if _overridden(self, "yvar_from_entropy", OptBayesExpt):
+            return self._utility_from_host_yvar(self.yvar_from_entropy())
+        return self._utility_from_host_yvar(self._yvar_from_entropy_device())
 
     def utility_full_kld(self):
         """exp(H(y + noise) - H(noise)) - 1, shape (C, N_s) (obe_base.py:688-720).  The
@@ -559,12 +584,14 @@ class OptBayesExpt(ParticlePDF):
         nvb = nva.reshape((c, nd))
         noisevalues = np.ascontiguousarray((nvb * np.sqrt(self.yvar_noise_model())).T)     # (N_d, C) glue
         noise_dev = torch.from_numpy(noisevalues).to(self._device)
-        self._lib.call("obe_yspace_add_noise", _ptr(ysp), nd, c, self._n_settings, _ptr(noise_dev), self._stream())
-        h_y = self._column_entropy(ysp, False)                          # (C, N_s)
-        h_n = self._column_entropy(noise_dev.reshape(nd, c, 1), False)  # (C, 1)
-        util = torch.empty((c, self._n_settings), dtype=torch.float64, device=self._device)
-        self._lib.call("obe_kld_utility", _ptr(h_y), c, self._n_settings, _ptr(h_n), _ptr(util), self._stream())
-        return util.cpu().numpy()
+        n = ysp.shape[2]                                                # this rank's settings
+        util = torch.empty((c, n), dtype=torch.float64, device=self._device)
+        if n:
+            self._lib.call("obe_yspace_add_noise", _ptr(ysp), nd, c, n, _ptr(noise_dev), self._stream())
+            h_y = self._column_entropy(ysp, False)                          # (C, n)
+            h_n = self._column_entropy(noise_dev.reshape(nd, c, 1), False)  # (C, 1)
+            self._lib.call("obe_kld_utility", _ptr(h_y), c, n, _ptr(h_n), _ptr(util), self._stream())
+        return self._gather_settings(util)
 
     def _gather_settings(self, local):
         """Host (rows, N_s) array from this rank's (rows, n_local) device slice."""

@@ -45,6 +45,29 @@ def _cycle_log(obe_mod, shard, n_cycles=8):
     return log, util
 
 
+def _yspace_log(obe_mod, shard):
+    """The y-space utilities (max_min, pseudo_utility, full_kld) on a sharded settings axis: each
+    rank evaluates its slice of the y-space and of the entropy columns, the utilities are gathered."""
+    from optbayesexpt_amd import obe_base
+    g = np.random.default_rng(5)
+    n = 4096
+    prior = np.array([g.uniform(2, 4, n), g.uniform(-2000, -400, n), g.normal(50000, 1000, n)])
+    sv = (np.linspace(1.5, 4.5, 203),)
+    out = {}
+    for method in ("max_min", "pseudo_utility", "full_kld_utility"):
+        o = obe_mod.OptBayesExpt(obe_mod.models.lorentzian(), sv, prior.copy(), (0.1,), scale=False,
+                                 utility_method=method, default_noise_std=500.0, settings_shard=shard)
+        o.rng = np.random.default_rng(31)
+        obe_base.rng = np.random.default_rng(32)
+        picks = []
+        for cyc in range(3):
+            x = o.opt_setting() if cyc != 1 else o.good_setting(pickiness=9)
+            picks.append(int(o.last_setting_index))
+            o.pdf_update((x, 49500.0, 500.0))
+        out[method] = (picks, np.asarray(o.utility()).reshape(-1))
+    return out
+
+
 def _worker(rank, world, port, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -53,7 +76,7 @@ def _worker(rank, world, port, ret):
     try:
         import optbayesexpt_amd as obe_mod
         log, util = _cycle_log(obe_mod, obe_mod.SettingsShard())
-        ret[rank] = (log, util)
+        ret[rank] = (log, util, _yspace_log(obe_mod, obe_mod.SettingsShard()))
     finally:
         dist.destroy_process_group()
 
@@ -61,11 +84,15 @@ def _worker(rank, world, port, ret):
 def test_two_ranks_share_one_gpu(hip):
     import optbayesexpt_amd as obe_mod
     ref_log, ref_util = _cycle_log(obe_mod, None)
+    ref_ysp = _yspace_log(obe_mod, None)
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
     for rank in (0, 1):
-        log, util = ret[rank]
+        log, util, ysp = ret[rank]
+        for method, (picks, u) in ysp.items():
+            assert picks == ref_ysp[method][0], method
+            np.testing.assert_allclose(u, ref_ysp[method][1], rtol=1e-12, err_msg=method)
         assert [l[:2] for l in log] == [l[:2] for l in ref_log]            # settings and resamples
         for a, b in zip(log, ref_log):
             np.testing.assert_allclose(a[3], b[3], rtol=1e-11)
