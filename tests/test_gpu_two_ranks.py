@@ -68,6 +68,31 @@ def _yspace_log(obe_mod, shard):
     return out
 
 
+def _sweeper_log(obe_mod, shard):
+    """The sweeper on a sharded settings axis: point utility per slice, gathered, then every rank
+    forms the same (start, stop) utilities and applies the same sweep."""
+    from optbayesexpt_amd import sweeper
+    g = np.random.default_rng(6)
+    n = 4096
+    prior = np.array([g.uniform(2, 4, n), g.uniform(400, 2000, n), g.normal(500, 1000, n), g.exponential(500, n)])
+    x = np.linspace(1.5, 4.5, 100)
+    o = obe_mod.OptBayesExptSweeper(obe_mod.models.lorentzian(), (x,), prior, (0.1,), 3, scale=False,
+                                    utility_method="variance_full", settings_shard=shard)
+    o.rng = np.random.default_rng(41)
+    sweeper.rng = np.random.default_rng(42)
+    sim = np.random.default_rng(43)
+    pairs = []
+    for cyc in range(3):
+        pair = o.opt_setting() if cyc != 1 else o.good_setting()
+        pairs.append((int(pair[0]), int(pair[1])))
+        xs = x[pair[0]:pair[1]]
+        ys = 300.0 + 1200.0 / (((xs - 3.1) / 0.1) ** 2 + 1) + 800.0 * sim.standard_normal(len(xs))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            o.pdf_update(((xs,), ys))
+    return pairs, o.sweep_utility(), o.mean()
+
+
 def _worker(rank, world, port, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -76,7 +101,8 @@ def _worker(rank, world, port, ret):
     try:
         import optbayesexpt_amd as obe_mod
         log, util = _cycle_log(obe_mod, obe_mod.SettingsShard())
-        ret[rank] = (log, util, _yspace_log(obe_mod, obe_mod.SettingsShard()))
+        ret[rank] = (log, util, _yspace_log(obe_mod, obe_mod.SettingsShard()),
+                     _sweeper_log(obe_mod, obe_mod.SettingsShard()))
     finally:
         dist.destroy_process_group()
 
@@ -85,11 +111,15 @@ def test_two_ranks_share_one_gpu(hip):
     import optbayesexpt_amd as obe_mod
     ref_log, ref_util = _cycle_log(obe_mod, None)
     ref_ysp = _yspace_log(obe_mod, None)
+    ref_sw = _sweeper_log(obe_mod, None)
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
     for rank in (0, 1):
-        log, util, ysp = ret[rank]
+        log, util, ysp, sw = ret[rank]
+        assert sw[0] == ref_sw[0]
+        np.testing.assert_allclose(sw[1], ref_sw[1], rtol=1e-11)
+        np.testing.assert_allclose(sw[2], ref_sw[2], rtol=1e-11)
         for method, (picks, u) in ysp.items():
             assert picks == ref_ysp[method][0], method
             np.testing.assert_allclose(u, ref_ysp[method][1], rtol=1e-12, err_msg=method)
