@@ -184,6 +184,11 @@ int obe_draw_indices(const double* d_weights, int64_t n_particles, int32_t stric
                      int32_t cdf_is_fresh, double* d_cdf, const double* h_uniforms,
                      int32_t n_draws, int64_t* d_idx, double* h_total_pinned,
                      void* d_ws, int64_t ws_bytes, void* stream);
+/* Systematic resampling (extension; BASELINE.json north_star names it, the reference itself is
+ * multinomial): idx[i] = searchsorted(cdf, (i + u0) / n_draws, 'right') for ONE uniform u0 in
+ * [0, 1).  Selected with tuning_parameters['resample_method'] = 'systematic'. */
+int obe_systematic_indices(const double* d_cdf, int64_t n, double u0, int64_t n_draws,
+                           int64_t* d_idx_out, void* stream);
 /* idx[j] = #{i : cdf[i] <= u[j]}  (searchsorted side='right'), int64. */
 int obe_cdf_search(const double* d_cdf, int64_t n, const double* d_uniforms, int64_t n_draws,
                    int64_t* d_idx_out, void* stream);

@@ -379,6 +379,25 @@ int obe_draw_indices(const double* d_weights, int64_t n_particles, int32_t stric
     return 0;
 }
 
+// Systematic resampling (extension): one uniform u0, draws at (i + u0) / n_draws — sorted, so
+// neighbouring threads probe neighbouring CDF entries.
+__global__ __launch_bounds__(kBlock) void systematic_search_kernel(const double* __restrict__ cdf, int64_t n,
+                                                                   double u0, int64_t nd,
+                                                                   int64_t* __restrict__ idx) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nd; i += (int64_t)gridDim.x * kBlock)
+        idx[i] = search_right(cdf, n, ((double)i + u0) / (double)nd);
+}
+
+int obe_systematic_indices(const double* d_cdf, int64_t n, double u0, int64_t n_draws, int64_t* d_idx_out,
+                           void* stream) {
+    if (!d_cdf || !d_idx_out || n <= 0 || n_draws <= 0 || !(u0 >= 0.0 && u0 < 1.0))
+        return bad_arg("obe_systematic_indices: bad pointer/size or u0 outside [0, 1)");
+    systematic_search_kernel<<<stream_blocks(n_draws, kBlock), kBlock, 0, as_stream(stream)>>>(d_cdf, n, u0, n_draws,
+                                                                                             d_idx_out);
+    OBE_CHECK_LAUNCH("systematic_search_kernel");
+    return 0;
+}
+
 int obe_cdf_search(const double* d_cdf, int64_t n, const double* d_uniforms, int64_t n_draws, int64_t* d_idx_out,
                    void* stream) {
     if (!d_cdf || !d_uniforms || !d_idx_out || n <= 0 || n_draws <= 0) return bad_arg("obe_cdf_search: bad pointer/size");

@@ -34,6 +34,10 @@ class ParticlePDF:
     Extension, ``tuning_parameters['strict_cdf']`` (default ``False``): build the
     resampling CDF in np.cumsum's serial rounding order (bit-identical CDF, ~ms at 1e6
     particles) instead of the parallel blocked scan.
+    Extension, ``tuning_parameters['resample_method']`` (default ``'multinomial'``, the
+    reference's ``rng.choice``): ``'systematic'`` draws the N new particles at the stratified
+    CDF points (i + u0)/N from ONE uniform of ``self.rng`` (lower resampling variance; the
+    nudge normals follow as usual).
     """
 
     def __init__(self, prior, a_param=0.98, resample_threshold=0.5,
@@ -353,8 +357,18 @@ class ParticlePDF:
         (particlepdf.py:260-310).  RNG order as in the reference: N uniforms, then
         N x D standard normals."""
         n, d = self.n_particles, self.n_dims
-        rstream = self._device_stream(n, n * d)       # exact continuation of self.rng, or None
-        idx = self._draw_indices(n, rstream)
+        method = self.tuning_parameters.get("resample_method", "multinomial")
+        if method == "multinomial":                       # the reference: N i.i.d. uniforms
+            rstream = self._device_stream(n, n * d)       # exact continuation of self.rng, or None
+            idx = self._draw_indices(n, rstream)
+        elif method == "systematic":                      # extension: ONE uniform, draws at (i + u0)/N
+            cdf = self._cdf()
+            u0 = float(self.rng.random())
+            idx = torch.empty(n, dtype=torch.int64, device=self._device)
+            self._lib.call("obe_systematic_indices", _ptr(cdf), n, u0, n, _ptr(idx), self._stream())
+            rstream = self._device_stream(0, n * d)
+        else:
+            raise ValueError(f"unknown resample_method {method!r} (multinomial or systematic)")
         m = self._moments(True)                       # pre-resample weights (:290-291)
         mean = m[2:2 + d].copy()
         cov = m[2 + 4 * d:2 + 4 * d + d * d].reshape((d, d))

@@ -19,7 +19,7 @@ import numpy as np
 __all__ = [
     "normalized_product", "effective_particles", "weighted_mean",
     "weighted_covariance", "weighted_std", "weight_cdf", "choice_indices",
-    "nudge_factor", "gauss_likelihood", "yvar_from_draws", "yvar_full_sweep",
+    "systematic_indices", "nudge_factor", "gauss_likelihood", "yvar_from_draws", "yvar_full_sweep",
     "utility_from_yvar", "mean_noise_variance", "flatten_settings",
     "OracleParticlePDF", "OracleOptBayesExpt", "OracleOptBayesExptNoiseParameter",
     "OracleOptBayesExptSweeper",
@@ -90,6 +90,13 @@ def choice_indices(weights, uniforms):
     """Multinomial draw of particlepdf.py:330-331 from explicit uniforms:
     index = number of CDF entries <= u  (searchsorted side='right'), int64."""
     return weight_cdf(weights).searchsorted(uniforms, side="right").astype(np.int64)
+
+
+def systematic_indices(weights, u0, n_draws):
+    """Systematic resampling (extension; BASELINE.json north_star): the CDF searched at the
+    stratified points (i + u0) / n_draws, one uniform u0 in [0, 1)."""
+    points = (np.arange(n_draws, dtype=np.float64) + u0) / np.float64(n_draws)
+    return weight_cdf(weights).searchsorted(points, side="right").astype(np.int64)
 
 
 def nudge_factor(cov):
@@ -253,7 +260,15 @@ class OracleParticlePDF:
         """particlepdf.py:260-310.  RNG order: N uniforms, then N*D normals
         (row-major (N, D)).  Mean/covariance use the pre-resample weights."""
         n, d = self.n_particles, self.n_dims
-        coords = self.randdraw(n)
+        if self.tuning_parameters.get("resample_method", "multinomial") == "systematic":
+            # extension (not in the reference): one uniform, draws at (i + u0) / N
+            idx = systematic_indices(self.particle_weights, self.rng.random(), n)
+            self.last_draw_indices = idx
+            coords = np.empty((d, n))
+            for i in range(d):
+                coords[i] = np.asarray(self.particles[i], dtype=np.float64)[idx]
+        else:
+            coords = self.randdraw(n)
         cov = self.covariance()
         center = self.mean().reshape((d, 1))
         a = self.tuning_parameters["a_param"]

@@ -78,6 +78,39 @@ def test_randdraw_and_resample_match_reference(obe, unit, tag, scale, strict):
     assert_array_equal(pdf.particle_weights, unit[f"rs_{tag}_weights"])
 
 
+def test_systematic_resampling_extension(obe):
+    """tuning_parameters['resample_method'] = 'systematic' (the scheme BASELINE.json's north_star
+    names; the reference is multinomial): one uniform, indices at the stratified CDF points —
+    against the oracle's restatement, plus the defining property of the scheme: particle i is
+    copied floor(N w_i) or ceil(N w_i) times."""
+    g = np.random.default_rng(99)
+    for n, scale in ((5000, False), (70001, True)):
+        x = np.array([g.uniform(2, 4, n), g.uniform(-2000, -400, n), g.normal(50000, 1000, n)])
+        w = g.exponential(1.0, n) ** 2
+        w /= w.sum()
+        a = obe.ParticlePDF(x.copy(), scale=scale)
+        b = oracle.OracleParticlePDF(x.copy(), scale=scale)
+        for o in (a, b):
+            o.tuning_parameters["resample_method"] = "systematic"
+            o.particle_weights = w.copy()
+            o.rng = np.random.default_rng(7)
+        a.tuning_parameters["strict_cdf"] = True              # same CDF bits as the oracle's np.cumsum
+        a.resample()
+        b.resample()
+        idx = a.last_resample_indices_device.cpu().numpy()
+        assert_array_equal(idx, b.last_draw_indices)
+        counts = np.bincount(idx, minlength=n)
+        assert np.all(counts >= np.floor(n * w - 1e-9)) and np.all(counts <= np.ceil(n * w + 1e-9))
+        assert np.all(np.diff(idx) >= 0)
+        assert_allclose(a.particles, b.particles, rtol=1e-10, atol=1e-9)
+        assert_allclose(a.particle_weights, 1.0 / n)
+        assert a.rng.bit_generator.state == b.rng.bit_generator.state or n > 30000   # device normals: same count
+    with pytest.raises(ValueError):
+        a.tuning_parameters["resample_method"] = "stratified"
+        a.particle_weights = w.copy()
+        a.resample()
+
+
 def test_strict_cdf_is_bitwise_numpy_cumsum(obe, hip):
     """tuning_parameters['strict_cdf']: the device CDF equals np.cumsum(w)/cumsum[-1] bit
     for bit; the parallel scan agrees to ~1e-13 and gives the same indices."""
