@@ -160,3 +160,31 @@ def from_expression(expression, settings, parameters, constants=(), name=None):
     lib = build.build_plugin(header, digest)
     return DeviceModel(name or f"expression[{digest}]", MODEL_PLUGIN, 0, len(parameters), len(settings),
                        n_channels, len(constants), numpy_form, plugin_path=lib)
+
+
+#: When True (or the environment has OBE_AUTO_DEVICE_MODEL=1), ``OptBayesExpt`` tries
+#: ``from_function`` on a plain Python ``model_function`` before settling for host-callable mode.
+#: Off by default: the first use of a model compiles its kernels with hipcc (tens of seconds).
+AUTO_TRANSLATE = False
+
+
+def from_function(model_function, name=None):
+    """A device model from the *source* of a reference-style ``model_function(sets, pars, cons)``
+    (the way every demo of the reference defines its model), if it is straight-line elementwise
+    arithmetic: argument unpacking, local assignments, NumPy / math functions, one ``return`` of
+    an expression or of a tuple / ``np.array((...))`` of them (channels).  The function is not
+    executed for the translation; afterwards the translated formula is checked against it, bit
+    for bit, on random inputs.  Raises ``ValueError`` if the function cannot be translated — the
+    caller can then still pass it to ``OptBayesExpt`` as a host-callable model.
+
+    The returned object calls the original function when used as ``model(sets, pars, cons)``."""
+    from . import _exprmodel, _fnmodel, build
+    exprs, settings, parameters, constants = _fnmodel.expressions_from_function(model_function)
+    header, numpy_form, digest = _exprmodel.translate(exprs, settings, parameters, constants)
+    _fnmodel.check_against_function(model_function, numpy_form, len(settings), len(parameters), len(constants))
+    lib = build.build_plugin(header, digest)
+    label = name or f"function[{getattr(model_function, '__name__', 'model')}:{digest}]"
+    dm = DeviceModel(label, MODEL_PLUGIN, 0, len(parameters), len(settings), len(exprs), len(constants),
+                     model_function, plugin_path=lib)
+    dm.expressions = exprs
+    return dm

@@ -27,10 +27,14 @@ Override points of the reference (``enforce_parameter_constraints``, ``cost_esti
 subclasses may replace with NumPy code; the fused kernels are used only while the
 corresponding methods are not overridden.
 """
+import os
+import warnings
+
 import numpy as np
 import torch
 
 from . import _lib
+from . import models as _models
 from ._mirror import Mirror, TrackedArray
 from .models import DeviceModel
 from .particlepdf import ParticlePDF, _P, _ptr
@@ -92,6 +96,14 @@ class OptBayesExpt(ParticlePDF):
                  default_noise_std=1.0, settings_shard=None, **kwargs):
         ParticlePDF.__init__(self, parameter_samples, use_jit=use_jit, **kwargs)
 
+        if not isinstance(measurement_model, DeviceModel) and callable(measurement_model) and \
+                (_models.AUTO_TRANSLATE or os.environ.get("OBE_AUTO_DEVICE_MODEL") == "1"):
+            # opt-in: a plain reference-style function is translated from its source when it is
+            # straight-line arithmetic; otherwise it stays a host-callable model
+            try:
+                measurement_model = _models.from_function(measurement_model)
+            except (ValueError, RuntimeError) as exc:
+                warnings.warn(f"model function kept on the host ({exc})", RuntimeWarning)
         self.model_function = measurement_model
         self._device_model = measurement_model if isinstance(measurement_model, DeviceModel) else None
         self._mlib = self._lib          # model-dependent entry points; an expression model brings its own

@@ -16,8 +16,12 @@ def expression_models():
          "p8/(1 + (s2 - p9)**2) + p10",
          "p11*s3 + p0*p1 - p2"),
         settings=("s0", "s1", "s2", "s3"), parameters=pn, name="limits_4x16x4")
+    import _fn_models
     return {
         "limits": big,
+        # translated from the source of plain reference-style functions (models.from_function)
+        "fn_lorentzian": models.from_function(_fn_models.lorentzian),
+        "fn_rabi": models.from_function(_fn_models.rabi),
         # a model with a true pole (tests the NaN semantics of the sweep)
         "pole": models.from_expression("a / (x - x0)", settings=("x",), parameters=("x0", "a")),
         # demos/find_peak/sequentialLorentzian.py:53-75 as a formula

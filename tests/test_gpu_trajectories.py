@@ -118,6 +118,35 @@ def test_trajectory_expression_model(hip, name, key):
     _replay.replay(fx, o, _replay.HIP_RTOL[name], get_draw_idx=lambda x: x.last_draw_indices, get_utility=get_u)
 
 
+@pytest.mark.parametrize("name,fn", [("lorentz3_opt", "lorentzian"), ("line_noiseparam", None), ("rabi_2set", "rabi")])
+def test_trajectory_plain_python_model_function_translated(hip, name, fn, monkeypatch):
+    """The reference's way of giving the model — a plain Python function — with the opt-in
+    switch models.AUTO_TRANSLATE: the function's source is translated (models.from_function), the
+    kernels compiled for it run the whole reference trajectory.  A function that cannot be
+    translated (here: one that indexes with a computed value) stays a host-callable model, with
+    a warning, and still reproduces the trajectory."""
+    import optbayesexpt_amd as obe
+    from optbayesexpt_amd import models
+    import _fn_models
+    monkeypatch.setattr(models, "AUTO_TRANSLATE", True)
+    fx = _replay.load_traj(name)
+    if fn is not None:
+        model = getattr(_fn_models, fn)
+        o = _replay.construct(fx, obe.OptBayesExpt, obe.OptBayesExptNoiseParameter, model)
+        assert o._device_model is not None and o._device_model.plugin_path and o._mlib is not o._lib
+        assert o.model_function((3.0,) * o._device_model.n_setdims, (2.5,) * o._device_model.n_read,
+                                fx["cons"]) == model((3.0,) * o._device_model.n_setdims,
+                                                     (2.5,) * o._device_model.n_read, fx["cons"])
+    else:
+        def line(sets, pars, cons):                      # not translatable: computed index
+            k = int(len(sets) - 1)
+            return pars[0] * sets[k] + pars[1]
+        with pytest.warns(RuntimeWarning, match="kept on the host"):
+            o = _replay.construct(fx, obe.OptBayesExpt, obe.OptBayesExptNoiseParameter, line)
+        assert o._device_model is None
+    _replay.replay(fx, o, _replay.HIP_RTOL[name], get_draw_idx=lambda x: x.last_draw_indices)
+
+
 def test_reference_inference_experiment(hip):
     """reference tests/test_zinference.py:46-121 (`test_experiment`): repeated 100-measurement
     inference runs with a constraint-enforcing subclass; the true mean must fall inside the

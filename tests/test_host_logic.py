@@ -157,3 +157,27 @@ def test_expression_translator():
             _exprmodel.translate(bad, ("x",), ("a", "b"), ())
     with pytest.raises(ValueError):
         _exprmodel.translate("x + exp", ("x",), ("exp",), ())      # a parameter may not shadow a function
+
+
+def test_model_function_source_translation():
+    """models.from_function's front end (no compilation here): reference-style functions become
+    expressions over generated names, the NumPy form of the result reproduces the function bit
+    for bit, and anything that is not straight-line arithmetic is refused."""
+    import _fn_models
+    from optbayesexpt_amd import _exprmodel, _fnmodel
+    e = _fnmodel.expressions_from_function(_fn_models.lorentzian)
+    assert e == (("p2 + p1 / (((s0 - p0) / c0) ** 2 + 1)",), ("s0",), ("p0", "p1", "p2"), ("c0",))
+    for fn, shape in ((_fn_models.lorentzian, (1, 1, 3, 1)), (_fn_models.rabi, (1, 2, 2, 3)),
+                      (_fn_models.two_channels, (2, 1, 2, 1))):
+        exprs, sets, pars, cons = _fnmodel.expressions_from_function(fn)
+        assert (len(exprs), len(sets), len(pars), len(cons)) == shape
+        _, numpy_form, _ = _exprmodel.translate(exprs, sets, pars, cons)
+        _fnmodel.check_against_function(fn, numpy_form, len(sets), len(pars), len(cons))
+    for fn in (_fn_models.with_branch, _fn_models.with_complex, _fn_models.with_global, _fn_models.with_loop,
+               lambda s, p, c: p[0], np.sin):
+        with pytest.raises(ValueError):
+            _fnmodel.expressions_from_function(fn)
+    # a wrong translation would be caught by the bitwise check
+    _, wrong, _ = _exprmodel.translate(("p2 + p1 / (((s0 - p0) / c0) ** 2 + 1.0000001)",), ("s0",), ("p0", "p1", "p2"), ("c0",))
+    with pytest.raises(ValueError):
+        _fnmodel.check_against_function(_fn_models.lorentzian, wrong, 1, 3, 1)
