@@ -22,6 +22,7 @@ import ast
 import copy
 import inspect
 import textwrap
+import types
 
 import numpy as np
 
@@ -32,11 +33,66 @@ _KINDS = ("s", "p", "c")          # generated names: s0.. settings, p0.. paramet
 _EXTRA_CALLS = {"square", "power", "absolute", "float64", "asarray", "array"}
 
 
+def _function_def(fn):
+    """The ast.FunctionDef of a plain Python function, from its source."""
+    try:
+        source = textwrap.dedent(inspect.getsource(fn))
+    except (OSError, TypeError) as exc:
+        raise ValueError(f"source of '{getattr(fn, '__name__', fn)}' is not available: {exc}")
+    try:
+        tree = ast.parse(source)
+    except SyntaxError:
+        raise ValueError("not a plain 'def' function (its source does not parse on its own)")
+    fdef = next((n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)), None)
+    if fdef is None:
+        raise ValueError("not a plain 'def' function")
+    a = fdef.args
+    if a.vararg or a.kwarg or a.kwonlyargs or a.posonlyargs or a.defaults:
+        raise ValueError(f"'{fdef.name}': only plain positional arguments are supported")
+    return fdef
+
+
 class _Translator(ast.NodeTransformer):
-    def __init__(self, arg_names):
+    def __init__(self, arg_names, scope=None, owner=None, depth=0):
         self.group = dict(zip(arg_names, _KINDS))     # function argument -> kind
-        self.count = {k: 0 for k in _KINDS}
+        self.count = {k: 0 for k in _KINDS} if owner is None else owner.count
         self.env = {}                                  # local name -> substituted expression
+        self.scope = scope or {}                       # the function's globals: helper functions live there
+        self.depth = depth
+
+    def run_body(self, fdef):
+        """Walk the statements of a function body; returns the list of returned expressions."""
+        for stmt in fdef.body:
+            if isinstance(stmt, ast.Expr) and isinstance(stmt.value, ast.Constant) and isinstance(stmt.value.value, str):
+                continue                                             # docstring
+            if isinstance(stmt, ast.Assign):
+                if len(stmt.targets) != 1:
+                    raise ValueError("chained assignment is not supported")
+                self.assign(stmt.targets[0], stmt.value)
+            elif isinstance(stmt, ast.Return):
+                if stmt.value is None:
+                    raise ValueError("the function returns nothing")
+                return self.channels(stmt.value)
+            else:
+                raise ValueError(f"unsupported statement: {type(stmt).__name__}")
+        raise ValueError("no return statement")
+
+    def inline(self, helper, args):
+        """A call of another plain Python function of the same module (the demos factor their
+        formulas out that way): its body is translated with the parameters bound to the
+        caller's argument expressions."""
+        if self.depth >= 8:
+            raise ValueError("helper functions nested too deeply (or recursive)")
+        fdef = _function_def(helper)
+        params = [a.arg for a in fdef.args.args]
+        if len(params) != len(args):
+            raise ValueError(f"'{fdef.name}' takes {len(params)} arguments, {len(args)} given")
+        sub = _Translator((), scope=getattr(helper, "__globals__", {}), owner=self, depth=self.depth + 1)
+        sub.env = dict(zip(params, args))
+        out = sub.run_body(fdef)
+        if len(out) != 1:
+            raise ValueError(f"'{fdef.name}' returns several values")
+        return out[0]
 
     def ref(self, kind, index):
         if index < 0:
@@ -76,6 +132,8 @@ class _Translator(ast.NodeTransformer):
         if node.keywords:
             raise ValueError("keyword arguments are not supported")
         args = [self.visit(a) for a in node.args]
+        if isinstance(f, ast.Name) and isinstance(self.scope.get(name), types.FunctionType):
+            return self.inline(self.scope[name], args)
         if name == "square" and len(args) == 1:
             return ast.BinOp(left=args[0], op=ast.Pow(), right=ast.Constant(value=2))
         if name == "power" and len(args) == 2:
@@ -129,46 +187,17 @@ class _Translator(ast.NodeTransformer):
                 value = value.args[0]
         if isinstance(value, (ast.Tuple, ast.List)):
             return [self.visit(v) for v in value.elts]
-        if isinstance(value, ast.Name) and isinstance(self.env.get(value.id), list):
-            return self.env[value.id]
         return [self.visit(value)]
 
 
 def expressions_from_function(fn):
     """(expressions, settings, parameters, constants) — strings in the expression language and the
     generated argument names — from the source of ``fn(sets, pars, cons)``."""
-    try:
-        source = textwrap.dedent(inspect.getsource(fn))
-    except (OSError, TypeError) as exc:
-        raise ValueError(f"source of the model function is not available: {exc}")
-    try:
-        tree = ast.parse(source)
-    except SyntaxError:
-        raise ValueError("not a plain 'def' function (its source does not parse on its own)")
-    fdef = next((n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)), None)
-    if fdef is None:
-        raise ValueError("not a plain 'def' function")
-    a = fdef.args
-    if len(a.args) != 3 or a.vararg or a.kwarg or a.kwonlyargs or a.posonlyargs or a.defaults:
+    fdef = _function_def(fn)
+    if len(fdef.args.args) != 3:
         raise ValueError("the model function must take exactly (sets, pars, cons)")
-    tr = _Translator([x.arg for x in a.args])
-    result = None
-    for stmt in fdef.body:
-        if isinstance(stmt, ast.Expr) and isinstance(stmt.value, ast.Constant) and isinstance(stmt.value.value, str):
-            continue                                             # docstring
-        if isinstance(stmt, ast.Assign):
-            if len(stmt.targets) != 1:
-                raise ValueError("chained assignment is not supported")
-            tr.assign(stmt.targets[0], stmt.value)
-        elif isinstance(stmt, ast.Return):
-            if stmt.value is None:
-                raise ValueError("the function returns nothing")
-            result = tr.channels(stmt.value)
-            break
-        else:
-            raise ValueError(f"unsupported statement: {type(stmt).__name__}")
-    if not result:
-        raise ValueError("no return statement")
+    tr = _Translator([x.arg for x in fdef.args.args], scope=getattr(fn, "__globals__", {}))
+    result = tr.run_body(fdef)
     exprs = tuple(ast.unparse(ast.fix_missing_locations(ast.Expression(body=r))) for r in result)
     names = [tuple(f"{k}{i}" for i in range(tr.count[k])) for k in _KINDS]
     return exprs, names[0], names[1], names[2]

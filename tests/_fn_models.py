@@ -25,6 +25,18 @@ def rabi(sets, pars, cons):
                        * (1 - np.cos(np.pi * 2 * f_rabi * pulsetime)) / (zz + 1))
 
 
+def peak(x, x0, a, b, d):
+    return b + a / (((x - x0) * 2 / d) ** 2 + 1)
+
+
+def lorentzian_via_helper(sets, pars, cons):
+    """The demos often factor the formula out into a helper of the same module."""
+    x, = sets
+    x0, a, b = pars
+    d, = cons
+    return peak(x, x0, a, b, d)
+
+
 def two_channels(sets, pars, cons):
     t = sets[0]
     w, ph = pars[0], pars[1]

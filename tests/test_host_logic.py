@@ -167,7 +167,10 @@ def test_model_function_source_translation():
     from optbayesexpt_amd import _exprmodel, _fnmodel
     e = _fnmodel.expressions_from_function(_fn_models.lorentzian)
     assert e == (("p2 + p1 / (((s0 - p0) / c0) ** 2 + 1)",), ("s0",), ("p0", "p1", "p2"), ("c0",))
+    assert _fnmodel.expressions_from_function(_fn_models.lorentzian_via_helper)[0] == \
+        ("p2 + p1 / (((s0 - p0) * 2 / c0) ** 2 + 1)",)                # the helper's body, inlined
     for fn, shape in ((_fn_models.lorentzian, (1, 1, 3, 1)), (_fn_models.rabi, (1, 2, 2, 3)),
+                      (_fn_models.lorentzian_via_helper, (1, 1, 3, 1)),
                       (_fn_models.two_channels, (2, 1, 2, 1))):
         exprs, sets, pars, cons = _fnmodel.expressions_from_function(fn)
         assert (len(exprs), len(sets), len(pars), len(cons)) == shape
