@@ -98,9 +98,9 @@ int obe_bayes_update_model(const obe_model* m,
  * each followed by the resample test of particlepdf.py:236-258) enqueued back to back, no
  * host round trip between the points.  h_settings (n_points, OBE_MAX_SETDIMS) and h_y_meas
  * (n_points, OBE_MAX_CHANNELS) row-major; sigma / noise rows / choke as obe_bayes_update_model.
- * With auto_resample != 0 the test runs on the device after every point: as soon as
- * n_eff < 0.1 N or n_eff / N < resample_threshold the remaining points are skipped (their
- * kernels return at once).  h_out[0] = sum t and h_out[1] = sum w'^2 of the last point applied,
+ * With auto_resample != 0 the test runs on the device after every point (in the prologue of
+ * the next point's first pass: two launches per point): as soon as n_eff < 0.1 N or
+ * n_eff / N < resample_threshold the remaining points are skipped (their kernels return at once).  h_out[0] = sum t and h_out[1] = sum w'^2 of the last point applied,
  * h_out[2] = 1 if a resample is due, h_out[3] = points applied (>= 1); the caller resamples and
  * submits the rest.  Sync. */
 int obe_bayes_update_sweep(const obe_model* m, const double* d_particles, int64_t ld_p,

@@ -49,13 +49,56 @@ struct SettingArg {
     double x[OBE_MAX_SETDIMS];
 };
 
+// A sweep batch (obe_bayes_update_sweep) runs the resample test of particlepdf.py:236-258 on the
+// device, in the prologue of the NEXT point's pass A: every workgroup folds the previous point's
+// sum-of-squares partials (the same fixed-order fold as fold2_kernel, so all agree), and if that
+// point asked for a resample the whole launch returns — workgroup 0 records it: scalars[0] = sum t,
+// [1] = sum w'^2 of the last point applied, [2] = stop flag (sticky: later launches return at
+// once), [3] = points applied.  Two launches per point instead of three.
+struct SweepCtl {
+    double* scalars;           // NULL: a single update, no sweep logic
+    const double* pa;          // partial sums of t      (previous point's, until this launch overwrites them)
+    const double* pb;          // partial sums of w'^2   (previous point's)
+    int nb;
+    int point;                 // index of the point this launch applies
+    int auto_resample;
+    double resample_threshold;
+    double n_particles;
+};
+
+__device__ __forceinline__ bool resample_due(double sum_w2, double n_particles, double threshold) {
+    const double n_eff = 1.0 / sum_w2;
+    return n_eff < 0.1 * n_particles || n_eff / n_particles < threshold;
+}
+
+// true: this launch must not touch the weights
+__device__ __forceinline__ bool sweep_prologue(const SweepCtl& c, double* red) {
+    if (!c.scalars) return false;
+    if (c.scalars[2] != 0.0) return true;
+    if (c.point == 0 || !c.auto_resample) return false;
+    const double b = block_sum_array(c.pb, c.nb, red);          // previous point's sum w'^2, in every thread
+    if (!resample_due(b, c.n_particles, c.resample_threshold)) return false;
+    if (blockIdx.x == 0) {
+        __syncthreads();
+        const double a = block_sum_array(c.pa, c.nb, red);
+        if (threadIdx.x == 0) {
+            c.scalars[0] = a;
+            c.scalars[1] = b;
+            c.scalars[3] = (double)c.point;
+            c.scalars[2] = 1.0;
+        }
+    }
+    return true;
+}
+
 // pass A, model fused
 template <class M>
 __global__ __launch_bounds__(kBlock) void update_model_kernel(
     obe_model m, SettingArg st, LikArgs la, const double* __restrict__ particles, int64_t ld,
-    int64_t n, double* __restrict__ weights, double* __restrict__ partials, const double* __restrict__ stop) {
+    int64_t n, double* __restrict__ weights, double* __restrict__ partials, SweepCtl ctl) {
     __shared__ double red[kBlock / kWave];
-    if (stop && stop[0] != 0.0) return;      // sweep batch: an earlier point asked for a resample
+    if (sweep_prologue(ctl, red)) return;
+    __syncthreads();
     double acc = 0.0;
     for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (int64_t)gridDim.x * kBlock) {
         double y[M::NC];
@@ -133,12 +176,13 @@ __global__ __launch_bounds__(kBlock) void fold2_kernel(const double* __restrict_
     }
 }
 
-// pass C of a sweep batch (obe_bayes_update_sweep): as fold2_kernel, plus the resample test
-// of particlepdf.py:236-258 on the device.  scalars[2] = stop flag, scalars[3] = points applied.
+// last launch of a sweep batch: fold the final point's partials and test it (unless an earlier
+// point already stopped the batch).
 __global__ __launch_bounds__(kBlock) void fold2_stop_kernel(const double* __restrict__ pa,
                                                             const double* __restrict__ pb, int n_partials,
                                                             double* __restrict__ scalars, double n_particles,
-                                                            int auto_resample, double resample_threshold) {
+                                                            int auto_resample, double resample_threshold,
+                                                            int n_points) {
     __shared__ double red[kBlock / kWave];
     if (scalars[2] != 0.0) return;
     const double a = block_sum_array(pa, n_partials, red);
@@ -147,11 +191,8 @@ __global__ __launch_bounds__(kBlock) void fold2_stop_kernel(const double* __rest
     if (threadIdx.x == 0) {
         scalars[0] = a;
         scalars[1] = b;
-        scalars[3] = scalars[3] + 1.0;
-        if (auto_resample) {
-            const double n_eff = 1.0 / b;
-            if (n_eff < 0.1 * n_particles || n_eff / n_particles < resample_threshold) scalars[2] = 1.0;
-        }
+        scalars[3] = (double)n_points;
+        if (auto_resample && resample_due(b, n_particles, resample_threshold)) scalars[2] = 1.0;
     }
 }
 
@@ -367,7 +408,7 @@ int obe_bayes_update_model(const obe_model* m, const double* d_particles, int64_
     int rc = dispatch_model(mm, [&](auto M) -> int {
         using Model = decltype(M);
         update_model_kernel<Model><<<nb, kBlock, 0, st>>>(mm, sa, la, d_particles, ld_p, n_particles, d_weights, w.pa,
-                                                          nullptr);
+                                                          SweepCtl{});
         OBE_CHECK_LAUNCH("update_model_kernel");
         return 0;
     });
@@ -399,20 +440,21 @@ int obe_bayes_update_sweep(const obe_model* m, const double* d_particles, int64_
             return rc;
         SettingArg sa{};
         for (int j = 0; j < mm.n_setdims; ++j) sa.x[j] = h_settings ? h_settings[k * OBE_MAX_SETDIMS + j] : 0.0;
+        const SweepCtl ctl{w.scalars, w.pa, w.pb, nb, (int)k, auto_resample, resample_threshold, (double)n_particles};
         int rc = dispatch_model(mm, [&](auto M) -> int {
             using Model = decltype(M);
             update_model_kernel<Model><<<nb, kBlock, 0, st>>>(mm, sa, la, d_particles, ld_p, n_particles, d_weights,
-                                                              w.pa, stop);
+                                                              w.pa, ctl);
             OBE_CHECK_LAUNCH("update_model_kernel");
             return 0;
         });
         if (rc) return rc;
         normalize_kernel<<<nb, kBlock, 0, st>>>(w.pa, nb, n_particles, d_weights, w.pb, stop);
         OBE_CHECK_LAUNCH("normalize_kernel");
-        fold2_stop_kernel<<<1, kBlock, 0, st>>>(w.pa, w.pb, nb, w.scalars, (double)n_particles, auto_resample,
-                                                resample_threshold);
-        OBE_CHECK_LAUNCH("fold2_stop_kernel");
     }
+    fold2_stop_kernel<<<1, kBlock, 0, st>>>(w.pa, w.pb, nb, w.scalars, (double)n_particles, auto_resample,
+                                            resample_threshold, (int)n_points);
+    OBE_CHECK_LAUNCH("fold2_stop_kernel");
     OBE_HIP_TRY(hipMemcpyAsync(h_out, w.scalars, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
     OBE_HIP_TRY(hipStreamSynchronize(st));
     return 0;
