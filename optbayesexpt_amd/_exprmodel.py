@@ -11,6 +11,7 @@ one correctly rounded operation per node, like NumPy does.
 """
 import ast
 import hashlib
+import re
 
 import numpy as np
 
@@ -259,8 +260,7 @@ class _SweepEmitter:
     def temp(self, code):
         k = self.count
         self.count += 1
-        self.phases.append(f"        double t{k}[SPT];\n"
-                           f"        _Pragma(\"unroll\") for (int j = 0; j < SPT; ++j) t{k}[j] = {code};")
+        self.phases.append(("temp", k, code))
         return f"t{k}[j]"
 
     def factors(self, n):
@@ -293,10 +293,8 @@ class _SweepEmitter:
         if key not in self.memo:
             k = self.count
             self.count += 1
-            self.phases.append(
-                f"        double den{k}[SPT], ip{k}[(SPT + 1) / 2];\n"
-                f"        _Pragma(\"unroll\") for (int j = 0; j < SPT; ++j) den{k}[j] = {self.emit(den)};\n"
-                f"        batch_div_poisoned<SPT>(den{k}, {self.emit(num)}, ip{k});")
+            den_code, num_code = self.emit(den), self.emit(num)
+            self.phases.append(("quot", k, den_code, num_code))
             self.memo[key] = (f"ip{k}[j / 2]", f"sibling_of<SPT>(den{k}, j)")
         return self.memo[key]
 
@@ -305,13 +303,59 @@ class _SweepEmitter:
         if key not in self.memo:
             k = self.count
             self.count += 1
-            self.phases.append(
-                f"        double den{k}[SPT], r{k}[SPT];\n"
-                f"        _Pragma(\"unroll\") for (int j = 0; j < SPT; ++j) den{k}[j] = {self.emit(den)};\n" +
-                (f"        _Pragma(\"unroll\") for (int j = 0; j < SPT; ++j) r{k}[j] = guarded_rcp(den{k}[j]);"
-                   if self.safe else f"        batch_rcp_poisoned<SPT>(den{k}, r{k});"))
+            self.phases.append(("rcp", k, self.emit(den)))
             self.memo[key] = f"r{k}[j]"
         return self.memo[key]
+
+    # ---- rendering: one particle per call, or two that share every inversion tree ----
+    _LOOP = "        _Pragma(\"unroll\") for (int j = 0; j < SPT; ++j) "
+
+    def render(self, outputs):
+        """sweep_eval body: the phases, then v[j][c] = outputs[c]."""
+        lines = []
+        for ph in self.phases:
+            if ph[0] == "temp":
+                lines += [f"        double t{ph[1]}[SPT];", f"{self._LOOP}t{ph[1]}[j] = {ph[2]};"]
+            elif ph[0] == "quot":
+                k = ph[1]
+                lines += [f"        double den{k}[SPT], ip{k}[(SPT + 1) / 2];", f"{self._LOOP}den{k}[j] = {ph[2]};",
+                          f"        batch_div_poisoned<SPT>(den{k}, {ph[3]}, ip{k});"]
+            else:
+                k = ph[1]
+                lines += [f"        double den{k}[SPT], r{k}[SPT];", f"{self._LOOP}den{k}[j] = {ph[2]};",
+                          (f"{self._LOOP}r{k}[j] = guarded_rcp(den{k}[j]);" if self.safe
+                           else f"        batch_rcp_poisoned<SPT>(den{k}, r{k});")]
+        lines += [f"{self._LOOP}v[j][{c}] = {code};" for c, code in enumerate(outputs)]
+        return "\n".join(lines)
+
+    @staticmethod
+    def _for_particle(code, x):
+        """The code of one of the two particles of a pair: its own temporaries and packed values."""
+        code = re.sub(r"\b(t|r|ip)(\d+)\[", lambda m: f"{m.group(1)}{m.group(2)}{x}[", code)
+        code = re.sub(r"\bden(\d+)\b", lambda m: f"den{m.group(1)}{x}", code)
+        return re.sub(r"\bpk\[", f"p{x}[", code)
+
+    def render_pair(self, outputs):
+        """sweep_eval_pair body: particles a and b side by side; every batched division runs ONE
+        inversion tree over both particles' denominators."""
+        fp, lines = self._for_particle, []
+        for ph in self.phases:
+            k = ph[1]
+            for x in "ab":
+                if ph[0] == "temp":
+                    lines += [f"        double t{k}{x}[SPT];", f"{self._LOOP}t{k}{x}[j] = {fp(ph[2], x)};"]
+                else:
+                    lines += [f"        double den{k}{x}[SPT];", f"{self._LOOP}den{k}{x}[j] = {fp(ph[2], x)};"]
+            if ph[0] == "quot":
+                lines += [f"        double ip{k}a[SPT / 2], ip{k}b[SPT / 2];",
+                          f"        batch_div_poisoned2<SPT>(den{k}a, den{k}b, {fp(ph[3], 'a')}, {fp(ph[3], 'b')}, "
+                          f"ip{k}a, ip{k}b);"]
+            elif ph[0] == "rcp":
+                lines += [f"        double r{k}a[SPT], r{k}b[SPT];",
+                          f"        batch_rcp_poisoned2<SPT>(den{k}a, den{k}b, r{k}a, r{k}b);"]
+        for c, code in enumerate(outputs):
+            lines += [f"{self._LOOP}va[j][{c}] = {fp(code, 'a')};", f"{self._LOOP}vb[j][{c}] = {fp(code, 'b')};"]
+        return "\n".join(lines)
 
     def emit(self, n):
         if n.op == "num":
@@ -346,21 +390,18 @@ class _SweepEmitter:
 
 
 def _sweep_code(trees, settings, parameters, constants):
-    """(prep_setting body, NXS, pack body, NPK, sweep_eval body, sweep_eval_safe body) of the
-    generated model."""
+    """(prep_setting body, NXS, pack body, NPK, sweep_eval body, sweep_eval_safe body,
+    sweep_eval_pair body) of the generated model."""
     build = _SweepBuilder(settings, parameters, constants)
     sw = _Node("sw", level=_LP)
     roots = [_mul(build.visit(t), sw) for t in trees]         # the kernel wants sqrt(w) * y
     fast = _SweepEmitter()
     safe = _SweepEmitter(safe=True, share=fast)
-    bodies = []
-    for em in (fast, safe):
-        out = [f"        _Pragma(\"unroll\") for (int j = 0; j < SPT; ++j) v[j][{c}] = {em.emit(root)};"
-               for c, root in enumerate(roots)]
-        bodies.append("\n".join(em.phases + out))
+    fast_out = [fast.emit(r) for r in roots]
+    safe_out = [safe.emit(r) for r in roots]
     nl = "\n"
     return (nl.join(fast.prep), max(1, len(fast.xs_slots)), nl.join(fast.pack), max(1, len(fast.pk_slots)),
-            bodies[0], bodies[1])
+            fast.render(fast_out), safe.render(safe_out), fast.render_pair(fast_out))
 
 
 def _check_names(names):
@@ -381,7 +422,8 @@ def translate(expressions, settings, parameters, constants):
     names = set(settings + parameters + constants)
     trees = [ast.parse(e.strip(), mode="eval") for e in expressions]
     c_exprs = [_ToC(names).visit(t) for t in trees]
-    prep_body, nxs, pack_body, npk, sweep_body, safe_body = _sweep_code(trees, settings, parameters, constants)
+    prep_body, nxs, pack_body, npk, sweep_body, safe_body, pair_body = _sweep_code(trees, settings, parameters,
+                                                                                     constants)
     ns, nc, npar, ncon = len(settings), len(expressions), len(parameters), len(constants)
     decl = [f"        const double u_{n} = x_[{i}];" for i, n in enumerate(settings)]
     decl += [f"        const double u_{n} = th_[{i}];" for i, n in enumerate(parameters)]
@@ -423,6 +465,16 @@ struct PluginModel {{
                                                       const obe_model&, double (&v)[SPT][NC]) {{
         (void)xs; (void)pk;
 {sweep_body}
+    }}
+    // two particles at once: their denominators share every inversion tree
+    static constexpr bool kHasPairEval = true;
+    template <int SPT>
+    __device__ __forceinline__ static void sweep_eval_pair(const double (&xs)[SPT][NXS], const double* pa,
+                                                           const double* pb, double (&va)[SPT][NC],
+                                                           double (&vb)[SPT][NC]) {{
+        static_assert(SPT >= 2, "pair evaluation needs an even number of settings per lane");
+        (void)xs; (void)pa; (void)pb;
+{pair_body}
     }}
     // the same with one guarded IEEE reciprocal per element: used for the repeat after a sweep
     // in which a batch above left its exact range (NaN-poisoned; include/obe_hip.h OBE_SWEEP_SAFE)

@@ -164,6 +164,63 @@ __device__ __forceinline__ double sibling_of(const double (&q)[N], int j) {
     else return q[j ^ 1];
 }
 
+// Two particles' denominators (N each, N even) through ONE inversion tree: pair inverses
+// ipa[h] = sa / (qa[2h] qa[2h+1]), ipb likewise.  The range check is tighter than for one
+// particle (sum of |pair products| < 1e18, total inverse < 1e150) because the root spans twice
+// as many factors; every partial product then lies in (1e-276, 1e72).
+template <int N>
+__device__ __forceinline__ void batch_div_poisoned2(const double (&qa)[N], const double (&qb)[N], double sa, double sb,
+                                                    double (&ipa)[N / 2], double (&ipb)[N / 2]) {
+    static_assert(N == 2 || N == 4 || N == 8, "batch_div_poisoned2: N must be 2, 4 or 8");
+    if constexpr (N == 2) {
+        const double a0 = qa[0] * qa[1], b0 = qb[0] * qb[1];
+        const double inv = fast_rcp(a0 * b0);
+        const double ok = poison_unless(fabs(a0) + fabs(b0) < 1e18 && fabs(inv) < 1e150, inv);
+        ipa[0] = ok * (b0 * sa);
+        ipb[0] = ok * (a0 * sb);
+    } else if constexpr (N == 4) {
+        const double a0 = qa[0] * qa[1], a1 = qa[2] * qa[3], b0 = qb[0] * qb[1], b1 = qb[2] * qb[3];
+        const double pa = a0 * a1, pb = b0 * b1;
+        const double inv = fast_rcp(pa * pb);
+        const double mag = (fabs(a0) + fabs(a1)) + (fabs(b0) + fabs(b1));
+        const double ok = poison_unless(mag < 1e18 && fabs(inv) < 1e150, inv);
+        const double ia = ok * (pb * sa), ib = ok * (pa * sb);
+        ipa[0] = ia * a1;
+        ipa[1] = ia * a0;
+        ipb[0] = ib * b1;
+        ipb[1] = ib * b0;
+    } else {
+        const double a0 = qa[0] * qa[1], a1 = qa[2] * qa[3], a2 = qa[4] * qa[5], a3 = qa[6] * qa[7];
+        const double b0 = qb[0] * qb[1], b1 = qb[2] * qb[3], b2 = qb[4] * qb[5], b3 = qb[6] * qb[7];
+        const double a01 = a0 * a1, a23 = a2 * a3, b01 = b0 * b1, b23 = b2 * b3;
+        const double pa = a01 * a23, pb = b01 * b23;
+        const double inv = fast_rcp(pa * pb);
+        const double mag = ((fabs(a0) + fabs(a1)) + (fabs(a2) + fabs(a3))) + ((fabs(b0) + fabs(b1)) + (fabs(b2) + fabs(b3)));
+        const double ok = poison_unless(mag < 1e18 && fabs(inv) < 1e150, inv);
+        const double ia = ok * (pb * sa), ib = ok * (pa * sb);
+        const double ia01 = ia * a23, ia23 = ia * a01, ib01 = ib * b23, ib23 = ib * b01;
+        ipa[0] = ia01 * a1;
+        ipa[1] = ia01 * a0;
+        ipa[2] = ia23 * a3;
+        ipa[3] = ia23 * a2;
+        ipb[0] = ib01 * b1;
+        ipb[1] = ib01 * b0;
+        ipb[2] = ib23 * b3;
+        ipb[3] = ib23 * b2;
+    }
+}
+template <int N>
+__device__ __forceinline__ void batch_rcp_poisoned2(const double (&qa)[N], const double (&qb)[N], double (&ra)[N],
+                                                    double (&rb)[N]) {
+    double ipa[N / 2], ipb[N / 2];
+    batch_div_poisoned2<N>(qa, qb, 1.0, 1.0, ipa, ipb);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        ra[j] = ipa[j / 2] * qa[j ^ 1];
+        rb[j] = ipb[j / 2] * qb[j ^ 1];
+    }
+}
+
 // r[j] = 1 / q[j]
 template <int N>
 __device__ __forceinline__ void batch_rcp_poisoned(const double (&q)[N], double (&r)[N]) {

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(SweepArgs a) {
             }
         };
         int i = 0;
-        if constexpr (has_pair_eval<M>::value && SPT >= 2) {
+        if constexpr (has_pair_eval<M>::value && SPT >= 2 && !SAFE) {
             // unrolled x4: the in-order wave then has other pairs' wide phases to issue while one
             // pair's inversion chain (product -> v_rcp_f64 -> 3 FMA -> back-substitution) is in
             // flight (measured at c3: 15.36 ms rolled, 14.73 x2, 14.43 x4, 14.8 x8; forcing 2

@@ -143,6 +143,9 @@ def test_expression_translator():
     assert "NXS = 1, NPK = 3" in header and "xs[0] = (x[0] * (1.0 / m.consts[0]));" in header
     assert "pk[1] = (th(1) * sw);" in header and "batch_div_poisoned<SPT>(den0, pk[1], ip0);" in header
     assert "v[j][0] = fma(ip0[j / 2], sibling_of<SPT>(den0, j), pk[2]);" in header
+    # two particles through one inversion tree
+    assert "batch_div_poisoned2<SPT>(den0a, den0b, pa[1], pb[1], ip0a, ip0b);" in header
+    assert "vb[j][0] = fma(ip0b[j / 2], sibling_of<SPT>(den0b, j), pb[2]);" in header
     # and its always-IEEE twin for the repeat after a poisoned sweep
     assert "sweep_eval_safe" in header and "r0[j] = guarded_rcp(den0[j]);" in header
     assert _exprmodel.translate("b + a / (((x - x0) / d)**2 + 1)", ("x",), ("x0", "a", "b"), ("d",))[2] == digest
