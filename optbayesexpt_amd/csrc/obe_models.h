@@ -394,7 +394,7 @@ struct FirstParam {
 // Rabi oscillation counts, demos/pipulse/pipulse.py:18-49
 // settings (pulsetime, delta_f); params (B1, f_center); consts (baseline, contrast, T1)
 struct Rabi {
-    static constexpr int NS = 2, NC = 1, NREAD = 2, NXS = 2, NPK = 2, NCONST = 3;
+    static constexpr int NS = 2, NC = 1, NREAD = 2, NXS = 3, NPK = 3, NCONST = 3;
     // the fraction removed from the baseline: y = baseline * (1 - frac)
     __device__ __forceinline__ static double frac(double tau, double df, double b1, double fc,
                                                    double contrast, double t1) {
@@ -411,29 +411,63 @@ struct Rabi {
     __device__ static void eval(const double* x, const ParamRef& th, const obe_model& m, double* y) {
         y[0] = m.consts[0] * (1.0 - frac(x[0], x[1], th(0), th(1), m.consts[1], m.consts[2]));
     }
-    __device__ static void prep_setting(const double* x, const obe_model&, double* xs) {
+    // Sweep form.  With f^2 = det^2 + B1^2:  1/(zz + 1) = B1^2 / f^2  and  1 - cos(2 pi f tau) =
+    // 2 sin^2(pi f tau), so
+    //   y - baseline = -baseline * [contrast exp(-tau/T1)] * [B1^2] * sin^2(pi f tau) / f^2
+    // with the first bracket per setting and the second per particle.  One v_rsq_f64 + two
+    // Newton steps give both f and 1/f^2 (no division, no hypot), and sin^2(pi x) needs no
+    // quadrant logic: r = x - rint(x) is exact and sin^2(pi r) is even in r.  ~35 issue slots per
+    // evaluation instead of ~150 for the literal formula (exp, hypot, cos, three IEEE divisions).
+    __device__ static void prep_setting(const double* x, const obe_model& m, double* xs) {
         xs[0] = x[0];
         xs[1] = x[1];
+        xs[2] = exp(-x[0] / m.consts[2]) * m.consts[1];       // contrast * exp(-tau / T1)
     }
-    __device__ static void pack(const ParamRef& th, const double*, const obe_model&, double, double* pk) {
-        pk[0] = th(0);
-        pk[1] = th(1);
+    __device__ static void pack(const ParamRef& th, const double*, const obe_model& m, double sw, double* pk) {
+        pk[0] = th(0) * th(0);                                  // B1^2
+        pk[1] = th(1);                                          // f_center
+        pk[2] = -(sw * m.consts[0]) * pk[0];                    // -sqrt(w) * baseline * B1^2
+    }
+    // sin(pi r) / r on |r| <= 1/2 as a polynomial in r^2: coefficients (-1)^k pi^(2k+1) / (2k+1)!,
+    // k = 0..10; the first neglected term is 1e-17 at the edge.
+    __device__ __forceinline__ static double sinpi_over_r(double r2) {
+        double p = 0x1.2877020d52cf0p-31;
+        p = fma(p, r2, -0x1.8a404211f9547p-26);
+        p = fma(p, r2, 0x1.aaec32af93359p-21);
+        p = fma(p, r2, -0x1.6fadb9f155744p-16);
+        p = fma(p, r2, 0x1.e8f434d018d63p-12);
+        p = fma(p, r2, -0x1.e3074fde8871fp-8);
+        p = fma(p, r2, 0x1.50783487ee782p-4);
+        p = fma(p, r2, -0x1.32d2cce62bd86p-1);
+        p = fma(p, r2, 0x1.466bc6775aae2p+1);
+        p = fma(p, r2, -0x1.4abbce625be53p+2);
+        return fma(p, r2, 0x1.921fb54442d18p+1);
     }
     template <int SPT>
-    __device__ __forceinline__ static void sweep_eval(const double (&xs)[SPT][NXS], const double* pk, double sw,
-                                                      const obe_model& m, double (&v)[SPT][NC]) {
-        // y - baseline: same variance, without the 1 - frac cancellation
-        const double scale = -(sw * m.consts[0]);
+    __device__ __forceinline__ static void sweep_eval(const double (&xs)[SPT][NXS], const double* pk, double,
+                                                      const obe_model&, double (&v)[SPT][NC]) {
 #pragma unroll
-        for (int j = 0; j < SPT; ++j)
-            v[j][0] = scale * frac(xs[j][0], xs[j][1], pk[0], pk[1], m.consts[1], m.consts[2]);
+        for (int j = 0; j < SPT; ++j) {
+            const double det = xs[j][1] - pk[1];
+            const double f2 = fma(det, det, pk[0]);
+            double y = __builtin_amdgcn_rsq(f2);                // 1/f to ~2^-23, then two Newton steps
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const double e = fma(-(f2 * y), y, 1.0);
+                y = fma(y * 0.5, e, y);
+            }
+            const double x = (f2 * y) * xs[j][0];               // f * tau
+            const double r = x - rint(x);
+            const double s = r * sinpi_over_r(r * r);           // +- sin(pi f tau)
+            v[j][0] = ((xs[j][2] * pk[2]) * (s * s)) * (y * y);
+        }
     }
 };
 
 // Parallel RLC coil impedance, demos/lockin/lockin_of_coil.py:63-102
 // setting w; params (L, R, C [, noise]); channels (Re Z, Im Z)
 struct Coil {
-    static constexpr int NS = 1, NC = 2, NREAD = 3, NXS = 1, NPK = 3, NCONST = 0;
+    static constexpr int NS = 1, NC = 2, NREAD = 3, NXS = 2, NPK = 7, NCONST = 0;
     // (1 + 0j) / (c + dj) the way NumPy's complex divide loop does it (Smith's method,
     // numpy/_core/src/umath/loops.c.src, complex _divide)
     __device__ __forceinline__ static void crecip(double c, double d, double& re, double& im) {
@@ -459,19 +493,52 @@ struct Coil {
     __device__ static void eval(const double* x, const ParamRef& th, const obe_model&, double* y) {
         formula(x[0], th(0), th(1), th(2), y);
     }
-    __device__ static void prep_setting(const double* x, const obe_model&, double* xs) { xs[0] = x[0]; }
-    __device__ static void pack(const ParamRef& th, const double*, const obe_model&, double, double* pk) {
-        pk[0] = th(0);
-        pk[1] = th(1);
-        pk[2] = th(2);
+    // Sweep form, one reciprocal per evaluation instead of two complex divisions:
+    //   Y = 1/(R + jwL) + jwC = (R - jwL)/n + jwC,  n = R^2 + w^2 L^2
+    //   Z = conj(Y)/|Y|^2 = n (R - jE) / (R^2 + E^2),  E = w (C n - L)
+    // The reciprocals of D = R^2 + E^2 are batched over the lane's settings; D has no fixed
+    // scale (units!), so the poisoned batch + exact twin of the generated models is used.
+    __device__ static void prep_setting(const double* x, const obe_model&, double* xs) {
+        xs[0] = x[0];
+        xs[1] = x[0] * x[0];
+    }
+    __device__ static void pack(const ParamRef& th, const double*, const obe_model&, double sw, double* pk) {
+        const double L = th(0), R = th(1), C = th(2);
+        pk[0] = L * L;
+        pk[1] = R * R;
+        pk[2] = C;
+        pk[3] = L;
+        pk[4] = sw * R;
+        pk[5] = -sw;
+        pk[6] = R;
     }
     template <int SPT>
-    __device__ __forceinline__ static void sweep_eval(const double (&xs)[SPT][NXS], const double* pk, double sw,
+    __device__ __forceinline__ static void sweep_eval(const double (&xs)[SPT][NXS], const double* pk, double,
                                                       const obe_model&, double (&v)[SPT][NC]) {
+        double n[SPT], e[SPT], d[SPT], rd[SPT];
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) {
+            n[j] = fma(xs[j][1], pk[0], pk[1]);
+            e[j] = xs[j][0] * fma(pk[2], n[j], -pk[3]);
+            d[j] = fma(e[j], e[j], pk[1]);
+        }
+        batch_rcp_poisoned<SPT>(d, rd);
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) {
+            const double t = n[j] * rd[j];
+            v[j][0] = pk[4] * t;
+            v[j][1] = (pk[5] * e[j]) * t;
+        }
+    }
+    // the exact NumPy operation sequence: the repeat after a poisoned batch (OBE_SWEEP_SAFE)
+    static constexpr bool kHasSafeEval = true;
+    template <int SPT>
+    __device__ __forceinline__ static void sweep_eval_safe(const double (&xs)[SPT][NXS], const double* pk, double sw,
+                                                           const obe_model&, double (&v)[SPT][NC]) {
 #pragma unroll
         for (int j = 0; j < SPT; ++j) {
             double y[2];
-            formula(xs[j][0], pk[0], pk[1], pk[2], y);
+            formula(xs[j][0], pk[3], pk[6], pk[2], y);
             v[j][0] = sw * y[0];
             v[j][1] = sw * y[1];
         }

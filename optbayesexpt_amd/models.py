@@ -37,9 +37,12 @@ class DeviceModel:
     """
 
     def __init__(self, name, model_id, aux, n_read, n_setdims, n_channels, n_consts, numpy_form,
-                 plugin_path=None):
+                 plugin_path=None, safe_sweep=None):
         #: path of the per-model plugin library (expression models), else None
         self.plugin_path = plugin_path
+        #: the model's fast sweep form poisons batches that leave their exact range and has an
+        #: always-IEEE twin for the repeat (include/obe_hip.h: OBE_SWEEP_SAFE)
+        self.safe_sweep = bool(plugin_path) if safe_sweep is None else bool(safe_sweep)
         self.name = name
         self.model_id = model_id
         self.aux = aux
@@ -138,7 +141,7 @@ def coil():
         L, R, C = pars[0], pars[1], pars[2]
         z = 1 / (1 / (R + 1j * w * L) + 1j * w * C)
         return np.array((np.real(z), np.imag(z)))
-    return DeviceModel("coil", MODEL_COIL, 0, 3, 1, 2, 0, form)
+    return DeviceModel("coil", MODEL_COIL, 0, 3, 1, 2, 0, form, safe_sweep=True)
 
 
 def from_expression(expression, settings, parameters, constants=(), name=None):

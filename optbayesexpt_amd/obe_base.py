@@ -459,7 +459,7 @@ class OptBayesExpt(ParticlePDF):
                 shifted = True
                 launch(True)
         safe = False
-        if np.isnan(kappa[0]) and self._device_model.plugin_path:
+        if np.isnan(kappa[0]) and self._device_model.safe_sweep:
             # an expression model's branch-free batched divisions left their exact range somewhere
             # (or the model really produces NaN): repeat with one IEEE reciprocal per element
             safe = shifted = True
