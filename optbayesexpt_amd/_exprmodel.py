@@ -98,6 +98,7 @@ class _ToC(ast.NodeVisitor):
 # Only the sweep uses this form (utilities agree with the exact form to ~1e-13 relative);
 # the Bayes update and eval_over_* use the exact one-operation-per-node `formula`.
 _LC, _LS, _LP, _LSP = 0, 1, 2, 3
+_FAST_CALLS = {"cos": "fast_cos", "sin": "fast_sin", "sqrt": "fast_sqrt", "hypot": "fast_hypot"}
 
 
 class _Node:
@@ -382,7 +383,10 @@ class _SweepEmitter:
         elif n.op == "neg":
             code = f"(-{self.emit(a)})"
         elif n.op == "call":
-            code = f"{n.val}({', '.join(self.emit(c) for c in n.args)})"
+            # inner-level calls of the fast form: range-checked polynomial / rsq versions
+            # (obe_models.h, "elementary functions for the inner level"); the safe twin keeps ocml
+            name = n.val if self.safe else _FAST_CALLS.get(n.val, n.val)
+            code = f"{name}({', '.join(self.emit(c) for c in n.args)})"
         else:
             raise AssertionError(n.op)
         self.memo[n.key] = code

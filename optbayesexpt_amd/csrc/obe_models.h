@@ -230,6 +230,68 @@ __device__ __forceinline__ void batch_rcp_poisoned(const double (&q)[N], double 
     for (int j = 0; j < N; ++j) r[j] = ip[j / 2] * sibling_of<N>(q, j);
 }
 
+// ---- elementary functions for the inner level of generated sweep forms ----
+// The exact forms (Bayes update, eval_over_*, sweep_eval_safe, everything hoisted to the setting
+// or particle level) call ocml; the inner level of the flop-bound sweep uses these: accurate to
+// ~2 ulp on the ranges stated, NaN outside them — a NaN reaches the setting's variance and the
+// host repeats the sweep with the safe twin (OBE_SWEEP_SAFE), as for the batched divisions.
+
+// sin r on |r| <= pi/2 (+1 %): odd Taylor polynomial through r^21 (truncation 2e-18)
+__device__ __forceinline__ double sin_poly(double r) {
+    const double r2 = r * r;
+    double p = 0x1.71b8ef6dcf572p-66;
+    p = fma(p, r2, -0x1.2f49b46814157p-57);
+    p = fma(p, r2, 0x1.952c77030ad4ap-49);
+    p = fma(p, r2, -0x1.ae7f3e733b81fp-41);
+    p = fma(p, r2, 0x1.6124613a86d09p-33);
+    p = fma(p, r2, -0x1.ae64567f544e4p-26);
+    p = fma(p, r2, 0x1.71de3a556c734p-19);
+    p = fma(p, r2, -0x1.a01a01a01a01ap-13);
+    p = fma(p, r2, 0x1.1111111111111p-7);
+    p = fma(p, r2, -0x1.5555555555555p-3);
+    return fma(r * r2, p, r);
+}
+// sin x = (-1)^k sin(x - k pi): two-constant Cody-Waite reduction with FMA (the product k*pi_hi is
+// exact inside the FMA, so the reduced argument is good to 1e-16 absolute for |x| < 1e9)
+__device__ __forceinline__ double fast_sin(double x) {
+    const double k = rint(x * 0x1.45f306dc9c883p-2);
+    double r = fma(-k, 0x1.921fb54442d18p+1, x);
+    r = fma(-k, 0x1.1a62633145c07p-53, r);
+    const double s = sin_poly(r);
+    const double v = (static_cast<int>(k) & 1) ? -s : s;
+    return fabs(x) < 1e9 ? v : __builtin_nan("");
+}
+// cos x = sin(x + pi/2)
+__device__ __forceinline__ double fast_cos(double x) {
+    const double k = rint(fma(x, 0x1.45f306dc9c883p-2, 0.5));
+    double r = fma(-k, 0x1.921fb54442d18p+1, x) + 0x1.921fb54442d18p+0;
+    r = r + fma(-k, 0x1.1a62633145c07p-53, 0x1.1a62633145c07p-54);
+    const double s = sin_poly(r);
+    const double v = (static_cast<int>(k) & 1) ? -s : s;
+    return fabs(x) < 1e9 ? v : __builtin_nan("");
+}
+// sqrt a = a * rsq(a): v_rsq_f64 (2^-23) + two Newton steps, then one correction of the root.
+// 0 -> 0, negative -> NaN, +inf -> NaN (repeat with the safe twin).
+__device__ __forceinline__ double fast_sqrt(double a) {
+    double y = __builtin_amdgcn_rsq(a);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double e = fma(-(a * y), y, 1.0);
+        y = fma(y * 0.5, e, y);
+    }
+    double s = a * y;
+    s = fma(fma(-s, s, a), y * 0.5, s);
+    return a == 0.0 ? 0.0 : s;
+}
+// hypot(a, b) with the larger magnitude scaled to [0.5, 1): no overflow / underflow of the squares
+__device__ __forceinline__ double fast_hypot(double a, double b) {
+    const double m = fmax(fabs(a), fabs(b));
+    const int e = __builtin_amdgcn_frexp_exp(m);
+    const double a1 = ldexp(a, -e), b1 = ldexp(b, -e);
+    const double h = fast_sqrt(fma(a1, a1, b1 * b1));
+    return m == 0.0 ? 0.0 : ldexp(h, e);
+}
+
 // ---------------------------------------------------------------------------
 // y = b + sum_{k<K} a / (((x - x0_k)/d)^2 + 1)
 // params: x0_0..x0_{K-1}, a, b [, anything]; const d

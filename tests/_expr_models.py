@@ -22,6 +22,9 @@ def expression_models():
         # translated from the source of plain reference-style functions (models.from_function)
         "fn_lorentzian": models.from_function(_fn_models.lorentzian),
         "fn_rabi": models.from_function(_fn_models.rabi),
+        # sin / cos / sqrt / hypot at the inner level of the sweep (the fast elementary functions)
+        "trig": models.from_expression("a*sin(w*t + p) + b*cos(w*t)*sqrt(t + c) + hypot(a*t, b)", settings=("t",),
+                                       parameters=("w", "p", "a", "b"), constants=("c",)),
         # a model with a true pole (tests the NaN semantics of the sweep)
         "pole": models.from_expression("a / (x - x0)", settings=("x",), parameters=("x0", "a")),
         # demos/find_peak/sequentialLorentzian.py:53-75 as a formula

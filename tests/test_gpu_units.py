@@ -625,6 +625,39 @@ def test_expression_model_out_of_range_batch_is_repeated_safely(obe):
     assert_allclose(got[0, keep], ref[0, keep], rtol=1e-9)
 
 
+def test_expression_model_fast_elementary_functions(obe):
+    """The inner level of a generated sweep form evaluates sin / cos / sqrt / hypot with the
+    range-checked fast versions (Cody-Waite + polynomial, rsq + Newton): arguments up to 1e6
+    radians must give the oracle's variances to 1e-10; beyond the checked range (1e9) the NaN
+    they return triggers the repeat with the safe twin, which calls ocml."""
+    import _expr_models
+    model = _expr_models.expression_models()["trig"]
+    g = np.random.default_rng(77)
+    n = 1024
+
+    def numpy_model(sets, pars, cons):
+        t, = sets
+        w, p, a, b = pars
+        c, = cons
+        return a * np.sin(w * t + p) + b * np.cos(w * t) * np.sqrt(t + c) + np.hypot(a * t, b)
+
+    t = np.linspace(0.0, 10.0, 4100)
+    wts = g.exponential(1.0, n)
+    wts /= wts.sum()
+    for w_scale, expect_safe in ((3.0, False), (1e5, False), (3e9, True)):
+        prior = np.array([g.uniform(0.5, 1.0, n) * w_scale, g.uniform(0, 6.0, n), g.normal(2.0, 0.5, n),
+                          g.normal(-1.0, 0.7, n)])
+        o = obe.OptBayesExpt(model, (t,), prior.copy(), (0.5,), utility_method="variance_full", auto_resample=False)
+        o.particle_weights = wts
+        got = o.yvar_from_parameter_draws()
+        assert o.last_sweep["safe"] is expect_safe, (w_scale, o.last_sweep)
+        if w_scale < 1e9:       # (beyond that the argument reduction of NumPy and of ocml differ themselves)
+            ref = oracle.yvar_full_sweep(numpy_model, oracle.flatten_settings((t,)), prior, wts, (0.5,))
+            assert_allclose(got, ref, rtol=1e-10, atol=1e-12 * ref.max())
+        else:
+            assert np.all(np.isfinite(got))
+
+
 def test_device_limits_4_settings_16_parameters_4_channels(obe):
     """OBE_MAX_SETDIMS / OBE_MAX_DIMS / OBE_MAX_CHANNELS exercised together through an
     expression model with a noise parameter per channel: cycles against the oracle."""
