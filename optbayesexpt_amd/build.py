@@ -81,7 +81,7 @@ def _source_fingerprint():
     for f in sorted(os.listdir(CSRC)) + [os.path.join(INCLUDE, "obe_hip.h")]:
         path = f if os.path.isabs(f) else os.path.join(CSRC, f)
         h.update(open(path, "rb").read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(FLAGS).replace(INCLUDE, "<include>").encode())      # not the checkout's absolute path
     h.update(open(os.path.join(HERE, "_exprmodel.py"), "rb").read())     # the header generator
     return h.hexdigest()[:12]
 
