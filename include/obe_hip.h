@@ -69,6 +69,9 @@ int obe_model_validate(obe_model* m);
 
 /* ---- library ---- */
 int obe_abi_version(void);
+/* Hash of the kernel sources this binary was compiled from (optbayesexpt_amd/build.py); the
+ * loader compares it with the sources next to it and refuses a stale library. */
+const char* obe_source_fingerprint(void);
 const char* obe_last_error(void);
 /* Name, CU count and memory of the current device; returns 0 if a gfx950 device is current. */
 int obe_device_info(char* name, int name_len, int* n_cu, int64_t* hbm_bytes);

@@ -49,6 +49,7 @@ _P = c_void_p   # any pointer (device or host) is passed as an integer address
 _SIGNATURES = {
     "obe_abi_version": (c_int, []),
     "obe_last_error": (ctypes.c_char_p, []),
+    "obe_source_fingerprint": (ctypes.c_char_p, []),
     "obe_model_validate": (c_int, [ctypes.POINTER(ObeModelStruct)]),
     "obe_device_info": (c_int, [ctypes.c_char_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int64)]),
     "obe_workspace_bytes": (c_int64, [c_int64, c_int64, c_int32, c_int32]),
@@ -121,7 +122,8 @@ class HipLib:
         import torch  # noqa: F401  (loads the HIP runtime the library will bind to)
         self.path = path
         self.cdll = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL if plugin else ctypes.RTLD_GLOBAL)
-        names = MODEL_ENTRY_POINTS + ("obe_abi_version", "obe_last_error") if plugin else tuple(_SIGNATURES)
+        names = MODEL_ENTRY_POINTS + ("obe_abi_version", "obe_last_error", "obe_source_fingerprint") if plugin \
+            else tuple(_SIGNATURES)
         for name in names:
             restype, argtypes = _SIGNATURES[name]
             fn = getattr(self.cdll, name)
@@ -130,6 +132,11 @@ class HipLib:
         abi = self.cdll.obe_abi_version()
         if abi != 1:
             raise ImportError(f"libobe_hip ABI {abi} does not match this package (1)")
+        from . import build
+        built_from = self.cdll.obe_source_fingerprint().decode()
+        if built_from != build._source_fingerprint():
+            raise ImportError(f"{path} was built from other kernel sources ({built_from}) than the ones next to it "
+                              f"({build._source_fingerprint()}): run `python -m optbayesexpt_amd.build`")
 
     def last_error(self):
         msg = self.cdll.obe_last_error()
@@ -171,10 +178,9 @@ def load():
     there is no CPU fallback."""
     global _LIB
     if _LIB is None:
-        if not os.path.exists(LIB_PATH):
-            from . import build
-            if os.path.exists(build.HIPCC):
-                build.build(verbose=True)
+        from . import build
+        if os.path.exists(build.HIPCC) and build.library_is_stale():
+            build.build(verbose=True)             # before the first dlopen: a loaded library cannot be replaced
         _LIB = HipLib()
     return _LIB
 

@@ -42,10 +42,24 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _stamp():
+    """obj/obe_fingerprint.h: the hash of the kernel sources, compiled into the library
+    (obe_source_fingerprint) so that a stale .so is recognised when it is loaded.  Rewritten only
+    when the hash changes."""
+    path = os.path.join(OBJ_DIR, "obe_fingerprint.h")
+    text = f'#define OBE_SOURCE_FINGERPRINT "{_source_fingerprint()}"\n'
+    if not os.path.exists(path) or open(path).read() != text:
+        with open(path, "w") as f:
+            f.write(text)
+    return path
+
+
 def _compile(src):
     obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
-    if _stale(obj, [src] + headers()):
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+    stamp = _stamp()
+    deps = [src] + headers() + ([stamp] if src.endswith("obe_capi.hip") else [])
+    if _stale(obj, deps):
+        cmd = [HIPCC] + FLAGS + ["-include", stamp, "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -66,9 +80,20 @@ def build(force=False, verbose=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    with open(LIB + ".fingerprint", "w") as f:          # what library_is_stale() reads without loading the .so
+        f.write(_source_fingerprint())
     if verbose:
         print(f"built {LIB} ({os.path.getsize(LIB) / 1024:.0f} KiB)")
     return LIB
+
+
+def library_is_stale():
+    """True if libobe_hip.so is missing or was built from other kernel sources than the ones
+    next to it (sidecar file written by build(); the library also carries the hash itself)."""
+    side = LIB + ".fingerprint"
+    if not (os.path.exists(LIB) and os.path.exists(side)):
+        return True
+    return open(side).read().strip() != _source_fingerprint()
 
 
 PLUGIN_DIR = os.path.join(OUT_DIR, "plugins")
@@ -109,10 +134,12 @@ def build_plugin(header_text, model_digest, verbose=False):
     with open(header, "w") as f:
         f.write(header_text)
     define = f'-DOBE_PLUGIN_MODEL_HEADER="{header}"'
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    stamp = _stamp()
 
     def one(src):
         obj = os.path.join(PLUGIN_DIR, f"{stem}_{src[:-4]}.o")
-        r = subprocess.run([HIPCC] + FLAGS + [define, "-c", os.path.join(CSRC, src), "-o", obj],
+        r = subprocess.run([HIPCC] + FLAGS + [define, "-include", stamp, "-c", os.path.join(CSRC, src), "-o", obj],
                            capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for the generated model ({src}):\n{r.stdout}\n{r.stderr}")

@@ -33,6 +33,11 @@ extern "C" {
 
 int obe_abi_version(void) { return OBE_ABI_VERSION; }
 
+#ifndef OBE_SOURCE_FINGERPRINT
+#define OBE_SOURCE_FINGERPRINT "unknown"
+#endif
+const char* obe_source_fingerprint(void) { return OBE_SOURCE_FINGERPRINT; }
+
 const char* obe_last_error(void) { return g_last_error.c_str(); }
 
 int obe_model_validate(obe_model* m) {
