@@ -78,6 +78,41 @@ def test_randdraw_and_resample_match_reference(obe, unit, tag, scale, strict):
     assert_array_equal(pdf.particle_weights, unit[f"rs_{tag}_weights"])
 
 
+@pytest.mark.parametrize("n", [65536, 65537, 300001])
+def test_small_draws_on_large_clouds(obe, n):
+    """randdraw(30)-sized draws go through obe_draw_indices: one launch up to 65 536 particles, the
+    three-kernel scan + by-value search beyond; fresh-CDF draws skip the scan.  Indices against
+    the oracle (strict CDF: exact by construction; blocked scan: exact on these seeds), and an
+    invalid weight vector raises numpy's ValueError with the generator left where it was."""
+    g = np.random.default_rng(n)
+    x = g.normal(size=(2, n))
+    w = g.exponential(1.0, n) ** 2
+    w /= w.sum()
+    for strict in (True, False):
+        pdf = obe.ParticlePDF(x.copy())
+        pdf.tuning_parameters["strict_cdf"] = strict
+        pdf.particle_weights = w.copy()
+        pdf.rng = np.random.default_rng(11)
+        ref = np.random.default_rng(11)
+        for n_draws in (30, 1, 64):                      # the second and third draw reuse the CDF
+            got = pdf.randdraw(n_draws)
+            idx = oracle.choice_indices(w, ref.random(n_draws))
+            assert_array_equal(pdf.last_draw_indices, idx)
+            assert_array_equal(got, x[:, idx])
+        assert pdf.rng.bit_generator.state == ref.bit_generator.state
+    bad = w.copy()
+    bad[5] = np.nan
+    pdf.particle_weights = bad
+    state = pdf.rng.bit_generator.state
+    with pytest.raises(ValueError, match="NaN"):
+        pdf.randdraw(30)
+    assert pdf.rng.bit_generator.state == state
+    pdf.particle_weights = 2.0 * w
+    with pytest.raises(ValueError, match="sum to 1"):
+        pdf.randdraw(30)
+    assert pdf.rng.bit_generator.state == state
+
+
 def test_systematic_resampling_extension(obe):
     """tuning_parameters['resample_method'] = 'systematic' (the scheme BASELINE.json's north_star
     names; the reference is multinomial): one uniform, indices at the stratified CDF points —
