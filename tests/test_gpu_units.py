@@ -379,6 +379,32 @@ def test_sweep_shapes_ragged(obe):
         assert_allclose(got, ref2, rtol=RTOL, atol=1e-13 * ref2.max() + 1e-18)   # 1e-18: (eps*y)^2 of identical draws
 
 
+@pytest.mark.parametrize("ns,n,nd", [(7, 50, 1), (40, 5, 256), (500, 1000, 257), (4500, 2049, 30), (1, 3, 2),
+                                      (513, 70000, 255)])
+def test_draws_mode_on_both_sides_of_the_one_workgroup_limit(obe, ns, n, nd):
+    """Reference-semantics sweeps: the one-workgroup kernel serves N_s * N_d <= 131072 with
+    N_d <= 256, the tiled kernels everything else; draw indices exact, variances and the chosen
+    setting against the oracle."""
+    g = np.random.default_rng(ns * 1000 + nd)
+    prior = np.array([g.uniform(2, 4, n), g.uniform(-2000, -400, n), g.normal(50000, 1000, n)])
+    sv = (np.linspace(1.5, 4.5, ns),)
+    w = g.exponential(1.0, n)
+    w /= w.sum()
+    o = obe.OptBayesExpt(obe.models.lorentzian(), sv, prior.copy(), (0.1,), n_draws=nd, auto_resample=False,
+                         default_noise_std=3.0)
+    o.particle_weights = w
+    o.rng = np.random.default_rng(8)
+    x = o.opt_setting()
+    idx = o.last_draw_indices
+    assert_array_equal(idx, oracle.choice_indices(w, np.random.default_rng(8).random(nd)))
+    ref = oracle.yvar_from_draws(omodels.lorentzian, oracle.flatten_settings(sv), prior[:, idx], (0.1,))
+    assert_allclose(o._yvar_dev.cpu().numpy(), ref, rtol=RTOL, atol=1e-13 * ref.max() + 1e-18)
+    util = oracle.utility_from_yvar(ref, 9.0, 1.0)
+    got_u = o._utility_dev.cpu().numpy()
+    assert_allclose(got_u, util, rtol=RTOL, atol=1e-13 * util.max() + 1e-18)
+    assert got_u[o.last_setting_index] == got_u.max() and x == (sv[0][o.last_setting_index],)
+
+
 def test_argmax_semantics(obe, hip):
     """np.argmax: first maximum wins, NaN beats everything."""
     import torch
