@@ -96,7 +96,8 @@ def library_is_stale():
     return open(side).read().strip() != _source_fingerprint()
 
 
-PLUGIN_DIR = os.path.join(OUT_DIR, "plugins")
+#: where generated models are compiled to; OBE_PLUGIN_DIR overrides (e.g. a read-only installation)
+PLUGIN_DIR = os.environ.get("OBE_PLUGIN_DIR", os.path.join(OUT_DIR, "plugins"))
 PLUGIN_SOURCES = ["obe_capi.hip", "obe_update.hip", "obe_sweep.hip", "obe_yspace.hip"]   # model-dependent
 
 

@@ -102,7 +102,7 @@ class OptBayesExpt(ParticlePDF):
             # straight-line arithmetic; otherwise it stays a host-callable model
             try:
                 measurement_model = _models.from_function(measurement_model)
-            except (ValueError, RuntimeError) as exc:
+            except (ValueError, RuntimeError, OSError) as exc:
                 warnings.warn(f"model function kept on the host ({exc})", RuntimeWarning)
         self.model_function = measurement_model
         self._device_model = measurement_model if isinstance(measurement_model, DeviceModel) else None
