@@ -10,13 +10,26 @@ namespace obe {
 
 constexpr int kMomBlocks = 1024;   // grid cap for the moment passes
 
+// The NV block sums with ONE barrier: every wavefront reduces all its values by shuffles and
+// parks them in LDS, then thread k adds the wave sums of value k in wave order — the same
+// arithmetic as NV calls of block_sum (shuffle tree, then the waves in order), which cost two
+// barriers each (110 of them at D = 10).
 template <int NV>
 __device__ __forceinline__ void store_block_partials(double (&v)[NV], double* __restrict__ partials) {
-    __shared__ double red[kBlock / kWave];
+    constexpr int NW = kBlock / kWave;
+    __shared__ double red[NW][NV];
+    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-        const double s = block_sum(v[k], red);
-        if (threadIdx.x == 0) partials[(int64_t)blockIdx.x * NV + k] = s;
+        const double s = wave_sum(v[k]);
+        if (lane == 0) red[wid][k] = s;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < NV; k += kBlock) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) s += red[i][k];
+        partials[(int64_t)blockIdx.x * NV + k] = s;
     }
 }
 
