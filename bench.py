@@ -15,9 +15,14 @@ all-gather; total work is fixed, so ``scaling`` is "strong".
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      — the dominant kernel (K1 sweep): achieved FP64 TFLOP/s from HIP events
                   around the kernel on its launch stream, against the FP64 vector peak;
-                  the algorithmic HBM figure the north_star asks for rides along.
+                  the algorithmic HBM figure the north_star asks for rides along, and
+                  ``valu_issue`` prices the kernel in FP64 issue slots counted in its ISA
+                  (tools/count_isa.py) against the chip's issue rate — the flop roofline
+                  treats every slot as an FMA, the kernel's mix is half mul/add.
   roofline_update — the HBM-bound Bayes update (K2), bytes / time.
-  cpu_baseline  — the NumPy oracle on one host core, on a bounded sub-grid (N = 1 only).
+  cpu_baseline  — the NumPy oracle on one host core, on a bounded sub-grid (N = 1 only);
+                  for c1 the oracle class itself through whole reference-semantics cycles.
+  cpu_baseline_allcores — the plain C + OpenMP restatement on every host core (full-sweep configs).
 """
 import argparse
 import ctypes
