@@ -87,7 +87,10 @@ class OptBayesExpt(ParticlePDF):
         maxima with one all-gather.
     """
 
-    KAPPA_ENTER, KAPPA_LEAVE = 30.0, 100.0     # hysteresis of the unshifted sweep (see _sweep_device)
+    #: hysteresis of the unshifted sweep (see _sweep_device).  Measured (tools/kappa_error.py, 262 144
+    #: and 1 048 576 particles): the unshifted variance is off by ~1e-15 * kappa relative, so 3000
+    #: keeps it 30x inside the 1e-10 parity tolerance
+    KAPPA_ENTER, KAPPA_LEAVE = 1000.0, 3000.0
 
     def __init__(self, measurement_model, setting_values, parameter_samples,
                  constants, n_draws=DEFAULT_N_DRAWS, choke=None,
@@ -443,10 +446,11 @@ class OptBayesExpt(ParticlePDF):
         # (sharded: kappa is the worst over all ranks, so every rank takes the same branch and the
         # collectives stay in step)
         # Shift policy (full sweep only).  The unshifted kernel saves one FP64 instruction
-        # per evaluation (11 % of the sweep) but loses ~eps*kappa*sqrt(N) relative accuracy,
-        # kappa = (mean of y)^2 / var being reported by every sweep.  It is used only while
-        # the previous sweep saw kappa < 30, and a sweep that comes back with kappa > 100
-        # is repeated with the shift: the variance is always good to ~1e-12.
+        # per evaluation (12 % of the sweep) but loses accuracy in proportion to
+        # kappa = (mean of y)^2 / var, which every sweep reports: measured ~1e-15 * kappa
+        # relative (worst case eps*kappa*sqrt(N)).  It is used only while the previous sweep saw
+        # kappa < KAPPA_ENTER, and a sweep that comes back with kappa > KAPPA_LEAVE is repeated
+        # with the shift: the variance is always good to a few 1e-12.
         mode = self.tuning_parameters.get("sweep_shift", "auto")
         shifted = (not full) or mode == "always" or (mode == "auto" and not self._sweep_unshifted)
         launch(shifted)

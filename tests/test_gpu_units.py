@@ -588,6 +588,35 @@ def test_adaptive_variance_shift(obe):
     assert_allclose(got, ref, rtol=RTOL, atol=1e-13 * ref.max())
 
 
+def test_unshifted_sweep_accuracy_below_the_kappa_threshold(obe):
+    """Clouds whose cancellation factor sits just under KAPPA_LEAVE (the largest kappa at which an
+    unshifted result is accepted): the unshifted variance must still agree with the shifted one —
+    and with the oracle — far inside the 1e-10 parity tolerance."""
+    g = np.random.default_rng(123)
+    n, ns = 200000, 600
+    sv = (np.linspace(1.5, 4.5, ns),)
+    w = g.exponential(1.0, n)
+    w /= w.sum()
+    z = g.normal(size=(3, n))
+    seen = []
+    for scale in (0.2, 0.1, 0.06, 0.04):
+        cloud = np.array([3.0 + 0.02 * scale * z[0], -1000.0 + 300.0 * scale * z[1], 50000.0 + 200.0 * scale * z[2]])
+        res = {}
+        for mode in ("always", "never"):
+            o = obe.OptBayesExpt(obe.models.lorentzian(), sv, cloud.copy(), (0.1,), utility_method="variance_full",
+                                 auto_resample=False)
+            o.tuning_parameters["sweep_shift"] = mode
+            o.particle_weights = w
+            res[mode] = o.yvar_from_parameter_draws()[0]
+            kappa = o.last_sweep["kappa"]
+        seen.append(kappa)
+        if kappa < obe.OptBayesExpt.KAPPA_LEAVE:
+            assert_allclose(res["never"], res["always"], rtol=2e-11, atol=1e-13 * res["always"].max())
+    assert any(0.3 * obe.OptBayesExpt.KAPPA_LEAVE < k < obe.OptBayesExpt.KAPPA_LEAVE for k in seen), seen
+    ref = oracle.yvar_full_sweep(omodels.lorentzian, oracle.flatten_settings(sv), cloud, w, (0.1,))
+    assert_allclose(res["always"], ref[0], rtol=RTOL, atol=1e-13 * ref.max())
+
+
 def test_update_back_to_back_stress(obe, hip):
     """2000 back-to-back Bayes updates whose totals differ by orders of magnitude: the
     partial sums of one launch must never leak into the next (workspace reuse, kernel-boundary
