@@ -324,6 +324,11 @@ __global__ __launch_bounds__(kBlock) void sweep_finalize(const double* __restric
                 a1 += acc1[c][g][lane];
                 a2 += acc2[c][g][lane];
             }
+            // (Measured alternative: chunk partials combined with TwoSum and S1*(S1/W) formed exactly
+            // with FMAs, plus per-tile flushing of the running sums, lowers the error of the
+            // unshifted variance from ~1e-15*kappa to ~2e-16*kappa — but the exact product then
+            // exposes the rounding of S2 itself, e.g. a non-zero variance for a single draw where
+            // the plain formula cancels to the reference's exact 0.  Not kept.)
             const double mu = a1 / W;
             double v = (a2 - a1 * mu) / W;
             v = v > 0.0 ? v : (v != v ? v : 0.0);          // rounding may leave -0 / tiny negatives; NaN stays NaN (np.var)
