@@ -72,6 +72,8 @@ class DeviceStream:
     def __init__(self, lib, device, stream, rng, n_uniform, n_normal):
         got = pcg64_state(rng)
         assert got is not None
+        if not isinstance(lib, _lib.DeviceBound):
+            lib = _lib.DeviceBound(lib, torch.device(device))
         self.lib, self.device, self.stream, self.rng = lib, device, stream, rng
         self.st, self.h_state = got
         self.n_uniform, self.n_normal = int(n_uniform), int(n_normal)
@@ -100,10 +102,11 @@ class DeviceStream:
             n_tail = self.n_raw - self.n_uniform
             ws_bytes = int(self.lib.cdll.obe_ziggurat_workspace_bytes(n_tail))
             ws = torch.empty(ws_bytes // 8 + 1, dtype=torch.float64, device=self.device)
-            rc = self.lib.cdll.obe_ziggurat_normal(_P(self.raw.data_ptr() + 8 * self.n_uniform), n_tail, 0,
-                                                   _P(tables.data_ptr()), self.n_normal, _P(out.data_ptr()),
-                                                   _lib.host_ptr(consumed), _P(ws.data_ptr()),
-                                                   ws.numel() * 8, self.stream)
+            with self.lib.guard():
+                rc = self.lib.cdll.obe_ziggurat_normal(_P(self.raw.data_ptr() + 8 * self.n_uniform), n_tail, 0,
+                                                       _P(tables.data_ptr()), self.n_normal, _P(out.data_ptr()),
+                                                       _lib.host_ptr(consumed), _P(ws.data_ptr()),
+                                                       ws.numel() * 8, self.stream)
             if rc == 0:
                 break
             if rc != 1:

@@ -161,6 +161,38 @@ class HipLib:
         return dict(name=buf.value.decode(), n_cu=ncu.value, hbm_bytes=mem.value, is_gfx950=(rc == 0))
 
 
+class DeviceBound:
+    """A HipLib (or plugin) bound to one GPU.  The C ABI launches on the calling thread's *current*
+    HIP device with the stream and pointers it is given; an object created with ``device='cuda:1'``
+    while device 0 is current would otherwise launch on the wrong GPU.  Every call through this
+    wrapper runs with the object's device current (a no-op test when it already is)."""
+
+    def __init__(self, lib, device):
+        import torch
+        self._lib = lib._lib if isinstance(lib, DeviceBound) else lib
+        self._torch = torch
+        self.index = device.index if device.index is not None else torch.cuda.current_device()
+
+    def guard(self):
+        if self._torch.cuda.current_device() == self.index:
+            return _NO_GUARD
+        return self._torch.cuda.device(self.index)
+
+    def call(self, name, *args):
+        with self.guard():
+            return self._lib.call(name, *args)
+
+    def device_info(self):
+        with self.guard():
+            return self._lib.device_info()
+
+    def __getattr__(self, name):          # cdll, path, workspace_bytes, moments_len, last_error
+        return getattr(self._lib, name)
+
+
+import contextlib                         # noqa: E402
+_NO_GUARD = contextlib.nullcontext()
+
 _LIB = None
 _PLUGINS = {}
 
@@ -180,7 +212,9 @@ def load():
     if _LIB is None:
         from . import build
         if os.path.exists(build.HIPCC) and build.library_is_stale():
-            build.build(verbose=True)             # before the first dlopen: a loaded library cannot be replaced
+            # before the first dlopen (a loaded library cannot be replaced); serialised across the
+            # ranks of a multi-GPU job by build()'s file lock, silent on stdout
+            build.build(only_if_stale=True)
         _LIB = HipLib()
     return _LIB
 

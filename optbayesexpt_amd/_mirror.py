@@ -23,8 +23,17 @@ _STAMP = itertools.count(1)
 
 
 class TrackedArray(np.ndarray):
-    """ndarray that tells its owning mirror about in-place modification.  Views
-    (slices, rows) keep the link; copies and arithmetic results are plain arrays."""
+    """Read-only-flagged ndarray view of a mirror's host buffer that lets the two in-place idioms
+    of the reference's callers through — item assignment (``w[bad] = 0``) and ufuncs with ``out=``
+    (``w *= 2``) — and reports them to the owning mirror.  Views (slices, rows) keep the link;
+    copies and arithmetic results are plain writable arrays.
+
+    Because the view is flagged read-only, every *other* way of writing into it (``np.copyto``,
+    ``np.put``/``putmask``, ``ndarray.fill``/``sort``/``partition``, ``.flat[...] =``,
+    ``np.nan_to_num(copy=False)``) raises numpy's "destination is read-only" ValueError instead of
+    silently leaving the device copy stale.  A view of a buffer the mirror has since replaced (the
+    cloud was updated on the device after the view was taken) is a snapshot, as an array kept across
+    ``pdf_update`` is in the reference: writes go to the snapshot only."""
 
     _obe_owner = None
 
@@ -35,11 +44,19 @@ class TrackedArray(np.ndarray):
 
     def _touch(self):
         owner = self._obe_owner
-        if owner is not None:
+        if owner is not None and owner._host is not None and np.may_share_memory(self, owner._host):
             owner.mark_host_written()
 
+    def _unlocked(self):
+        """A plain writable ndarray over the same memory (allowed: the mirror's buffer, the
+        ultimate base of every view, is itself writable)."""
+        alias = self.view(np.ndarray)
+        if self._obe_owner is not None:
+            alias.flags.writeable = True
+        return alias
+
     def __setitem__(self, key, value):
-        np.ndarray.__setitem__(self, key, value)
+        self._unlocked()[key] = value
         self._touch()
 
     def __array_ufunc__(self, ufunc, method, *inputs, out=None, **kwargs):
@@ -47,7 +64,7 @@ class TrackedArray(np.ndarray):
         touched = []
         if out is not None:
             touched = [o for o in out if isinstance(o, TrackedArray)]
-            kwargs["out"] = tuple(np.asarray(o) if isinstance(o, TrackedArray) else o for o in out)
+            kwargs["out"] = tuple(o._unlocked() if isinstance(o, TrackedArray) else o for o in out)
         result = getattr(ufunc, method)(*plain_in, **kwargs)
         for o in touched:
             o._touch()
@@ -89,6 +106,7 @@ class Mirror:
             self._host_valid = True
         view = self._host.view(TrackedArray)
         view._obe_owner = self
+        view.flags.writeable = False        # writes go through TrackedArray's tracked paths or raise
         return view
 
     def mark_host_written(self):

@@ -10,9 +10,14 @@ correctly rounded operations, like NumPy; the sweep kernel requests its FMAs
 explicitly with fma().
 """
 import concurrent.futures
+import contextlib
+import fcntl
 import os
+import re
+import shutil
 import subprocess
 import sys
+import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -66,24 +71,57 @@ def _compile(src):
     return obj
 
 
-def build(force=False, verbose=False):
-    """Compile (if stale) and return the path of libobe_hip.so."""
-    os.makedirs(OBJ_DIR, exist_ok=True)
-    if force:
-        for f in os.listdir(OBJ_DIR):
-            os.remove(os.path.join(OBJ_DIR, f))
-    srcs = sources()
-    with concurrent.futures.ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
-        objs = list(ex.map(_compile, srcs))
-    if force or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    with open(LIB + ".fingerprint", "w") as f:          # what library_is_stale() reads without loading the .so
-        f.write(_source_fingerprint())
-    if verbose:
-        print(f"built {LIB} ({os.path.getsize(LIB) / 1024:.0f} KiB)")
+@contextlib.contextmanager
+def _locked(directory):
+    """Exclusive inter-process lock on ``directory/.lock``: with one process per GPU every rank may
+    find the same library or plugin missing at the same moment; one of them builds, the others wait
+    and then see the finished file."""
+    os.makedirs(directory, exist_ok=True)
+    with open(os.path.join(directory, ".lock"), "a+") as fh:
+        fcntl.flock(fh, fcntl.LOCK_EX)
+        try:
+            yield
+        finally:
+            fcntl.flock(fh, fcntl.LOCK_UN)
+
+
+def _write_atomically(path, text):
+    tmp = f"{path}.tmp{os.getpid()}"
+    with open(tmp, "w") as f:
+        f.write(text)
+    os.replace(tmp, path)
+
+
+def build(force=False, verbose=False, only_if_stale=False):
+    """Compile (if stale) and return the path of libobe_hip.so.  Serialised across processes by a
+    file lock; the library is linked under a temporary name and renamed into place, so a concurrent
+    dlopen never sees a half-written file.  ``only_if_stale`` re-checks the source fingerprint under
+    the lock (the caller's own check may be out of date by the time the lock is granted).  Messages
+    go to stderr: stdout belongs to the caller (bench.py prints one JSON line there)."""
+    with _locked(OUT_DIR):
+        if only_if_stale and not library_is_stale():
+            return LIB
+        os.makedirs(OBJ_DIR, exist_ok=True)
+        if force:
+            for f in os.listdir(OBJ_DIR):
+                if f.endswith(".o") and os.path.isfile(os.path.join(OBJ_DIR, f)):
+                    os.remove(os.path.join(OBJ_DIR, f))
+        srcs = sources()
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
+            objs = list(ex.map(_compile, srcs))
+        if force or _stale(LIB, objs):
+            tmp = f"{LIB}.tmp{os.getpid()}"
+            cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+                raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+            os.replace(tmp, LIB)
+        # what library_is_stale() reads without loading the .so
+        _write_atomically(LIB + ".fingerprint", _source_fingerprint())
+        if verbose:
+            print(f"built {LIB} ({os.path.getsize(LIB) / 1024:.0f} KiB)", file=sys.stderr)
     return LIB
 
 
@@ -116,48 +154,73 @@ def plugin_path(model_digest):
     return os.path.join(PLUGIN_DIR, f"libobe_model_{model_digest}_{_source_fingerprint()}.so")
 
 
+_PLUGIN_FILE = re.compile(r"^(?:lib)?obe_model_[0-9a-f]{16}_([0-9a-f]{12})\.(?:so|h)$")
+
+
+def _remove_outdated_plugins(fp):
+    """Plugins (and their generated headers) built from older kernel sources are dead weight.  Only
+    regular files carrying this package's own naming pattern are touched: PLUGIN_DIR may be a
+    shared directory (OBE_PLUGIN_DIR=/tmp, ~/.cache, ...) holding files that are not ours."""
+    for f in os.listdir(PLUGIN_DIR):
+        m = _PLUGIN_FILE.match(f)
+        path = os.path.join(PLUGIN_DIR, f)
+        if m and m.group(1) != fp and os.path.isfile(path) and not os.path.islink(path):
+            try:
+                os.remove(path)
+            except OSError:
+                pass
+
+
 def build_plugin(header_text, model_digest, verbose=False):
     """Compile the model-dependent kernel sources for ONE generated model
     (``OBE_PLUGIN_MODEL_HEADER``) into a plugin library with the same entry points as
-    libobe_hip.so.  Cached by the hash of the model header and of the kernel sources."""
+    libobe_hip.so.  Cached by the hash of the model header and of the kernel sources.  Safe with
+    one process per GPU: the build happens under a file lock in a private scratch directory and the
+    finished library is renamed into place; ranks that lose the race find it there."""
     lib = plugin_path(model_digest)
-    os.makedirs(PLUGIN_DIR, exist_ok=True)
-    fp = _source_fingerprint()
-    for f in os.listdir(PLUGIN_DIR):          # plugins of older kernel sources are dead weight
-        if not f.rsplit(".", 1)[0].endswith(fp):
-            os.remove(os.path.join(PLUGIN_DIR, f))
     if os.path.exists(lib):
         return lib
-    if not os.path.exists(HIPCC):
-        raise RuntimeError(f"{lib} is not built and hipcc ({HIPCC}) is not available to build it")
-    stem = os.path.basename(lib)[3:-3]
-    header = os.path.join(PLUGIN_DIR, stem + ".h")
-    with open(header, "w") as f:
-        f.write(header_text)
-    define = f'-DOBE_PLUGIN_MODEL_HEADER="{header}"'
-    os.makedirs(OBJ_DIR, exist_ok=True)
-    stamp = _stamp()
+    with _locked(PLUGIN_DIR):
+        fp = _source_fingerprint()
+        _remove_outdated_plugins(fp)
+        if os.path.exists(lib):               # another process built it while we waited for the lock
+            return lib
+        if not os.path.exists(HIPCC):
+            raise RuntimeError(f"{lib} is not built and hipcc ({HIPCC}) is not available to build it")
+        stem = os.path.basename(lib)[3:-3]
+        scratch = tempfile.mkdtemp(prefix=f".build_{os.getpid()}_", dir=PLUGIN_DIR)
+        try:
+            header = os.path.join(scratch, stem + ".h")
+            with open(header, "w") as f:
+                f.write(header_text)
+            stamp = os.path.join(scratch, "obe_fingerprint.h")
+            with open(stamp, "w") as f:
+                f.write(f'#define OBE_SOURCE_FINGERPRINT "{fp}"\n')
+            define = f'-DOBE_PLUGIN_MODEL_HEADER="{header}"'
 
-    def one(src):
-        obj = os.path.join(PLUGIN_DIR, f"{stem}_{src[:-4]}.o")
-        r = subprocess.run([HIPCC] + FLAGS + [define, "-include", stamp, "-c", os.path.join(CSRC, src), "-o", obj],
-                           capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"hipcc failed for the generated model ({src}):\n{r.stdout}\n{r.stderr}")
-        return obj
+            def one(src):
+                obj = os.path.join(scratch, src[:-4] + ".o")
+                r = subprocess.run([HIPCC] + FLAGS + [define, "-include", stamp, "-c", os.path.join(CSRC, src),
+                                                      "-o", obj], capture_output=True, text=True)
+                if r.returncode != 0:
+                    raise RuntimeError(f"hipcc failed for the generated model ({src}):\n{r.stdout}\n{r.stderr}")
+                return obj
 
-    with concurrent.futures.ThreadPoolExecutor(max_workers=4) as ex:
-        objs = list(ex.map(one, PLUGIN_SOURCES))
-    # -Bsymbolic: calls between the plugin's own entry points must not be interposed by
-    # the same-named symbols of libobe_hip.so already loaded in the process
-    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic"] + objs + ["-o", lib],
-                       capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"plugin link failed:\n{r.stdout}\n{r.stderr}")
-    for o in objs:
-        os.remove(o)
-    if verbose:
-        print(f"built {lib}")
+            with concurrent.futures.ThreadPoolExecutor(max_workers=4) as ex:
+                objs = list(ex.map(one, PLUGIN_SOURCES))
+            # -Bsymbolic: calls between the plugin's own entry points must not be interposed by
+            # the same-named symbols of libobe_hip.so already loaded in the process
+            tmp = os.path.join(scratch, os.path.basename(lib))
+            r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic"] + objs
+                               + ["-o", tmp], capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"plugin link failed:\n{r.stdout}\n{r.stderr}")
+            shutil.copyfile(header, os.path.join(PLUGIN_DIR, stem + ".h"))     # kept for inspection
+            os.replace(tmp, lib)
+        finally:
+            shutil.rmtree(scratch, ignore_errors=True)
+        if verbose:
+            print(f"built {lib}", file=sys.stderr)
     return lib
 
 

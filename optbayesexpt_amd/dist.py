@@ -88,6 +88,18 @@ class SettingsShard:
         dist.all_gather_into_tensor(gathered, record.contiguous().to(dev), group=self.group)
         return gathered.cpu().reshape(w, 4)
 
+    def broadcast_from_rank0(self, values, device="cpu"):
+        """Rank 0's host array on every rank (same shape and dtype everywhere): used for random
+        draws that must be taken once for the whole job."""
+        values = np.ascontiguousarray(values)
+        if self.world_size == 1:
+            return values
+        dev = self._comm_device(device)
+        t = torch.from_numpy(values.copy()).to(dev)
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        dist.broadcast(t, src=src, group=self.group)
+        return t.cpu().numpy()
+
     @staticmethod
     def make_record(value, local_index, kappa=0.0, device="cpu"):
         """A record as the sweep kernels leave it in the workspace (for tests / host paths)."""

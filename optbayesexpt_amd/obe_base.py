@@ -130,7 +130,7 @@ class OptBayesExpt(ParticlePDF):
                 raise ValueError(f"{dm.name} takes {dm.n_setdims} setting(s), got {self.allsettings.shape[0]}")
             self._model_struct = dm.struct(self.n_dims, constants)
             # expression models are served by their own plugin library (same entry points)
-            self._mlib = _lib.load_plugin(dm.plugin_path) if dm.plugin_path else self._lib
+            self._mlib = _lib.DeviceBound(_lib.load_plugin(dm.plugin_path), self._device) if dm.plugin_path else self._lib
             self._mlib.call("obe_model_validate", self._model_struct)
             self.n_channels = dm.n_channels
         else:
@@ -596,7 +596,7 @@ class OptBayesExpt(ParticlePDF):
         N_DRAWS*C standard normals come from the module-level ``rng`` as in the reference."""
         nd, c = self.N_DRAWS, self.n_channels
         ysp = self._yspace_device()
-        nva = rng.normal(0, 1.0, nd * c)
+        nva = self._rank0_values(rng.normal(0, 1.0, nd * c))
         nvb = nva.reshape((c, nd))
         noisevalues = np.ascontiguousarray((nvb * np.sqrt(self.yvar_noise_model())).T)     # (N_d, C) glue
         noise_dev = torch.from_numpy(noisevalues).to(self._device)
@@ -663,9 +663,22 @@ class OptBayesExpt(ParticlePDF):
 
     def random_setting(self):
         """A uniformly random setting (obe_base.py:791-805)."""
-        settingindex = rng.choice(self.setting_indices)
+        settingindex = int(self._rank0_values(rng.choice(self.setting_indices))[0])
         self.last_setting_index = settingindex
         return self.allsettings[:, settingindex]
+
+    def _rank0_values(self, values):
+        """Draws the reference takes from its *module-level* generators (obe_base.py:18:
+        random_setting, the full_kld noise; obe_sweeper.py:3-6) are not reproducible across the
+        processes of a sharded object: every process has its own unseeded module generator, ranks
+        would pick different settings and the replicated clouds would drift apart.  Every rank draws
+        (its generator moves as in an unsharded run) and rank 0's values are used everywhere — one
+        tiny broadcast; a run whose rank 0 seeds the module generator like an unsharded run
+        reproduces it.  Unsharded: the values pass through."""
+        values = np.atleast_1d(np.asarray(values))
+        if self._shard is None:
+            return values
+        return self._shard.broadcast_from_rank0(values, self._device)
 
     def _model_output_len(self):
         """Number of output channels of a host-callable model, by a trial evaluation

@@ -42,12 +42,16 @@ class ParticlePDF:
 
     def __init__(self, prior, a_param=0.98, resample_threshold=0.5,
                  auto_resample=True, scale=True, use_jit=True, device=None):
-        self._lib = _lib.load()
+        lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("optbayesexpt_amd needs a HIP device (MI355X / gfx950); "
                                "there is no CPU fallback")
         self._device = torch.device(device) if device is not None else \
             torch.device("cuda", torch.cuda.current_device())
+        if self._device.index is None:
+            self._device = torch.device("cuda", torch.cuda.current_device())
+        # kernels are launched with this object's device current, whatever the caller's is
+        self._lib = _lib.DeviceBound(lib, self._device)
 
         #: dict: a_param / resample_threshold / auto_resample / scale, read at call time
         self.tuning_parameters = {"a_param": a_param,
@@ -117,9 +121,18 @@ class ParticlePDF:
     @particles.setter
     def particles(self, value):
         value = np.asarray(value)
+        if value.ndim != 2:
+            raise ValueError("particles must be n_dims x n_particles")
+        resized = (value.shape[0], value.shape[-1]) != (self.n_dims, self.n_particles)
         self._particles.set_host(value)
         self.n_particles = value.shape[-1]
         self.n_dims = value.shape[0]
+        if resized:
+            # the workspace, CDF and moment blocks are sized for the cloud; the weights keep their
+            # length (as in the reference) and a mismatch is reported by the next kernel call
+            if self.n_dims > _lib.OBE_MAX_DIMS:
+                raise ValueError(f"at most {_lib.OBE_MAX_DIMS} parameters are supported on the device")
+            self._alloc_scratch()
 
     @property
     def particle_weights(self):

@@ -198,7 +198,8 @@ class OptBayesExptSweeper(OptBayesExptNoiseParameter):
 
     def good_setting(self):
         """A (start, stop) pair drawn with probability ~ utility**pickiness
-        (obe_sweeper.py:169-193); consumes one uniform of this module's ``rng``."""
+        (obe_sweeper.py:169-193); consumes one uniform of this module's ``rng`` (rank 0's value on a
+        sharded object, see ``_rank0_values``)."""
         u = self._sweep_utility_device()
         n = u.numel()
         ws, wsb = self._pair_ws, self._pair_ws.numel() * 8
@@ -206,7 +207,7 @@ class OptBayesExptSweeper(OptBayesExptNoiseParameter):
         cdf = torch.empty(n, dtype=torch.float64, device=self._device)
         self._lib.call("obe_power_normalize", _ptr(u), n, float(self.pickiness), _ptr(prob), _ptr(ws), wsb,
                        self._stream())
-        uni = np.atleast_1d(rng.random())
+        uni = self._rank0_values(rng.random())
         idx = torch.empty(1, dtype=torch.int64, device=self._device)
         self._lib.call("obe_draw_indices", _ptr(prob), n, 0, 0, _ptr(cdf), _lib.host_ptr(uni), 1, _ptr(idx), None,
                        _ptr(ws), wsb, self._stream())
@@ -216,7 +217,7 @@ class OptBayesExptSweeper(OptBayesExptNoiseParameter):
 
     def random_setting(self):
         """A uniformly random (start, stop) pair (obe_sweeper.py:195-205)."""
-        index = rng.choice(self.start_stop_choice_indices)
+        index = int(self._rank0_values(rng.choice(self.start_stop_choice_indices))[0])
         self.last_setting_index = index
         return self.start_stop_indices[index]
 

@@ -68,7 +68,12 @@ def _worker(rank, world, port, ret):
             rows[1, :e - b] = 2 * local
             full = shard.gather_rows(torch.from_numpy(rows), u.size)
             results.append((best_idx, best_val, full))
+        # draws that must be taken once for the whole job: rank 0's values everywhere
+        mine = np.random.default_rng(100 + rank)
+        f = shard.broadcast_from_rank0(mine.normal(0, 1, 7))
+        i = shard.broadcast_from_rank0(np.atleast_1d(mine.choice(np.arange(1000))))
         ret[rank] = results
+        ret[f"bcast{rank}"] = (f, i)
     finally:
         dist.destroy_process_group()
 
@@ -85,3 +90,7 @@ def test_sharded_argmax_and_gather_match_single_process(world):
             np.testing.assert_array_equal(best_val, u[int(np.argmax(u))])
             np.testing.assert_array_equal(full[0], u)
             np.testing.assert_array_equal(full[1], 2 * u)
+        rank0 = np.random.default_rng(100)
+        np.testing.assert_array_equal(ret[f"bcast{rank}"][0], rank0.normal(0, 1, 7))
+        got = ret[f"bcast{rank}"][1]
+        assert got.dtype == np.int64 and got[0] == rank0.choice(np.arange(1000))

@@ -58,7 +58,9 @@ def _yspace_log(obe_mod, shard):
         o = obe_mod.OptBayesExpt(obe_mod.models.lorentzian(), sv, prior.copy(), (0.1,), scale=False,
                                  utility_method=method, default_noise_std=500.0, settings_shard=shard)
         o.rng = np.random.default_rng(31)
-        obe_base.rng = np.random.default_rng(32)
+        # module-level generator (full_kld noise): seeded like the unsharded run on rank 0 only —
+        # the other ranks' differ, as unseeded per-process generators do; rank 0's draws are broadcast
+        obe_base.rng = np.random.default_rng(32 if shard is None or shard.rank == 0 else 1000 + shard.rank)
         picks = []
         for cyc in range(3):
             x = o.opt_setting() if cyc != 1 else o.good_setting(pickiness=9)
@@ -79,7 +81,7 @@ def _sweeper_log(obe_mod, shard):
     o = obe_mod.OptBayesExptSweeper(obe_mod.models.lorentzian(), (x,), prior, (0.1,), 3, scale=False,
                                     utility_method="variance_full", settings_shard=shard)
     o.rng = np.random.default_rng(41)
-    sweeper.rng = np.random.default_rng(42)
+    sweeper.rng = np.random.default_rng(42 if shard is None or shard.rank == 0 else 2000 + shard.rank)
     sim = np.random.default_rng(43)
     pairs = []
     for cyc in range(3):

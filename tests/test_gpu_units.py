@@ -781,3 +781,49 @@ def test_device_limits_4_settings_16_parameters_4_channels(obe):
             assert_allclose(a.particle_weights, b.particle_weights, rtol=RTOL,
                             atol=1e-13 * b.particle_weights.max())
         assert_allclose(a.covariance(), b.covariance(), rtol=1e-9, atol=1e-12)
+
+
+# ------------------------------------------------- host mirrors, device binding, sharded draws
+def test_host_views_are_tracked_or_refused(obe):
+    """The reference's in-place idioms reach the device; any other in-place write is refused
+    loudly (never a silently stale device copy); resizing the cloud re-plans the workspace."""
+    g = np.random.default_rng(11)
+    x = g.normal(0, 1, (2, 1000))
+    pdf = obe.ParticlePDF(x)
+    pdf.mean()                                        # device copy in use
+    w = pdf.particle_weights
+    w[x[0] < 0] = 0                                   # obe_noiseparam.py:71 idiom
+    pdf.particle_weights = pdf.particle_weights / np.sum(pdf.particle_weights)
+    ref_w = np.where(x[0] < 0, 0.0, 1e-3)
+    ref_w /= ref_w.sum()
+    assert_allclose(pdf.mean(), oracle.weighted_mean(x, ref_w), rtol=1e-12)
+    pdf.particle_weights *= 1.0                       # ufunc with out=
+    with pytest.raises(ValueError, match="read-only"):
+        np.copyto(pdf.particle_weights, 1e-3)
+    with pytest.raises(ValueError, match="read-only"):
+        pdf.particles.sort()
+    assert_allclose(pdf.mean(), oracle.weighted_mean(x, ref_w), rtol=1e-12)
+    # a bigger cloud through the setter: scratch is re-planned, stale weights are reported
+    big = g.normal(0, 1, (2, 300000))
+    pdf.particles = big
+    assert pdf.n_particles == 300000
+    with pytest.raises(ValueError, match="different lengths"):
+        pdf.mean()
+    pdf.particle_weights = np.full(300000, 1 / 300000)
+    assert_allclose(pdf.mean(), big.mean(axis=1), rtol=1e-11, atol=1e-14)
+    assert_allclose(pdf.covariance(), oracle.weighted_covariance(big, np.full(300000, 1 / 300000)), rtol=1e-10,
+                    atol=1e-13)
+
+
+def test_object_on_a_device_that_is_not_current(obe):
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    g = np.random.default_rng(12)
+    x = g.normal(0, 1, (3, 5000))
+    torch.cuda.set_device(0)
+    pdf = obe.ParticlePDF(x, device="cuda:1")
+    assert torch.cuda.current_device() == 0
+    assert_allclose(pdf.mean(), x.mean(axis=1), rtol=1e-11, atol=1e-14)
+    pdf.bayesian_update(np.exp(-x[0] ** 2))
+    assert torch.cuda.current_device() == 0 and pdf._weights.tensor().device.index == 1

@@ -1,6 +1,8 @@
 """Host-side logic that needs no GPU: the model registry's NumPy forms, the in-place
 write tracking of the host mirrors, settings sharding arithmetic, demo helpers, and the
 "fail loudly without a GPU" contract."""
+import os
+
 import numpy as np
 import pytest
 from numpy.testing import assert_allclose, assert_array_equal
@@ -38,32 +40,49 @@ def test_device_model_numpy_forms_match_demo_formulas():
 
 
 def test_tracked_array_reports_in_place_writes():
-    class Owner:
-        n = 0
+    from optbayesexpt_amd._mirror import Mirror
+    m = Mirror("cpu", host=np.arange(12, dtype=float).reshape(3, 4))
+    m._dev_valid = True              # pretend the device copy is current
+    base, stamps = m._host, [m.version]
 
-        def mark_host_written(self):
-            self.n += 1
-    o = Owner()
-    base = np.arange(12, dtype=float).reshape(3, 4)
-    v = base.view(TrackedArray)
-    v._obe_owner = o
+    def writes():                    # a tracked write invalidates the device copy and bumps the version
+        seen = (not m._dev_valid) and m.version != stamps[-1]
+        stamps.append(m.version)
+        m._dev_valid = True
+        return seen
+    v = m.host()
+    assert isinstance(v, TrackedArray) and not v.flags.writeable
     v[1, 2] = 5.0
-    assert o.n == 1
+    assert writes() and base[1, 2] == 5.0
     row = v[1]                       # views stay linked (self.parameters[1][idx] = 0)
     row[0] = 3.0
-    assert o.n == 2
+    assert writes() and base[1, 0] == 3.0
     for i in np.argwhere(v[2] > 0):  # the reference's loop-of-index-writes idiom
         v[2][i] = 0
-    assert o.n == 2 + 4 - 0 and not base[2].any() or o.n >= 5
-    c = v.copy()                     # copies are plain data
+    assert writes() and not base[2].any()
+    c = v.copy()                     # copies are plain, writable data
     c[0, 0] = -1
-    n = o.n
+    c.fill(7.0)
+    assert not writes()
     assert isinstance(v / v.sum(), np.ndarray) and not isinstance(v / 2, TrackedArray)
     v /= 2.0                         # in-place ufunc
-    assert o.n == n + 1
+    assert writes()
     np.multiply(v, 2.0, out=v)
-    assert o.n == n + 2
+    assert writes()
     assert v.tolist()[0][1] == 1.0 and np.sum(v) == base.sum()
+    # every untracked way of writing in place is refused loudly instead of being lost
+    before = base.copy()
+    for bad in (lambda: np.copyto(v, 0.0), lambda: v.fill(0.0), lambda: v.sort(), lambda: np.put(v, [0], 9.0),
+                lambda: np.putmask(v, v > 1, 0.0), lambda: v.flat.__setitem__(0, 9.0),
+                lambda: np.nan_to_num(v, copy=False), lambda: v[0].partition(1)):
+        with pytest.raises(ValueError, match="read-only"):
+            bad()
+    assert not writes() and np.array_equal(base, before)
+    # a view taken before the mirror replaced its buffer is a snapshot (an array kept across
+    # pdf_update in the reference): writable through the same idioms, without effect on the mirror
+    m._host = base.copy()
+    v[0, 0] = 123.0
+    assert not writes() and m._host[0, 0] != 123.0 and v[0, 0] == 123.0
 
 
 def test_shard_bounds_partition():
@@ -187,3 +206,110 @@ def test_model_function_source_translation():
     _, wrong, _ = _exprmodel.translate(("p2 + p1 / (((s0 - p0) / c0) ** 2 + 1.0000001)",), ("s0",), ("p0", "p1", "p2"), ("c0",))
     with pytest.raises(ValueError):
         _fnmodel.check_against_function(_fn_models.lorentzian, wrong, 1, 3, 1)
+
+
+def test_plugin_cleanup_only_touches_our_own_files(tmp_path, monkeypatch):
+    """A shared OBE_PLUGIN_DIR may hold files that are not ours: only regular files that carry the
+    package's plugin naming pattern *and* an outdated source fingerprint are removed."""
+    from optbayesexpt_amd import build
+    monkeypatch.setattr(build, "PLUGIN_DIR", str(tmp_path))
+    fp = build._source_fingerprint()
+    old = "0" * 12 if fp != "0" * 12 else "1" * 12
+    keep = ["notes.txt", "libfoo.so", f"libobe_model_{'a' * 16}_{fp}.so", f"obe_model_{'a' * 16}_{fp}.h",
+            f"libobe_model_{'a' * 16}_{old}.so.bak", f"xlibobe_model_{'a' * 16}_{old}.so",
+            f"obe_model_{'a' * 16}_{old}_obe_sweep.o"]
+    gone = [f"libobe_model_{'b' * 16}_{old}.so", f"obe_model_{'b' * 16}_{old}.h"]
+    for f in keep + gone:
+        (tmp_path / f).write_text("x")
+    (tmp_path / "subdir").mkdir()
+    (tmp_path / f"libobe_model_{'c' * 16}_{old}.so").mkdir()        # a directory with a plugin's name
+    build._remove_outdated_plugins(fp)
+    left = set(os.listdir(tmp_path))
+    assert left == set(keep) | {"subdir", f"libobe_model_{'c' * 16}_{old}.so"}
+
+
+_RACE = r"""
+import os, sys, time
+sys.path.insert(0, {root!r})
+from optbayesexpt_amd import build
+build.PLUGIN_DIR = {pdir!r}
+build.HIPCC = {hipcc!r}
+build.FLAGS = []
+build.PLUGIN_SOURCES = ["obe_capi.hip"]
+lib = build.build_plugin("// header\n", "d" * 16)
+assert os.path.getsize(lib) > 0
+print(open(lib).read().count("linked"))
+"""
+
+
+def test_concurrent_plugin_builds_are_serialised(tmp_path):
+    """One process per GPU: every rank asks for the same plugin at once.  With a slow stand-in
+    for hipcc, exactly one of three racing processes links; the others wait on the lock and find the
+    finished library (never a half-written one), and nobody deletes anybody's objects."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fake = tmp_path / "fake_hipcc"
+    log = tmp_path / "calls.log"
+    fake.write_text(f"""#!/usr/bin/env python3
+import sys, time
+out = sys.argv[sys.argv.index("-o") + 1]
+kind = "linked" if "-shared" in sys.argv else "compiled"
+open({str(log)!r}, "a").write(kind + "\\n")
+with open(out, "w") as f:          # a slow, non-atomic writer
+    f.write(kind[:3]); f.flush(); time.sleep(0.4); f.write(kind[3:] + "\\n")
+""")
+    fake.chmod(0o755)
+    pdir = tmp_path / "plugins"
+    (pdir).mkdir()
+    (pdir / "notes.txt").write_text("mine")
+    script = _RACE.format(root=root, pdir=str(pdir), hipcc=str(fake))
+    procs = [subprocess.Popen([sys.executable, "-c", script], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for _ in range(3)]
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert [o[0].strip() for o in outs] == ["1", "1", "1"]          # everyone read a complete library
+    calls = log.read_text().split()
+    assert calls.count("linked") == 1 and calls.count("compiled") == 1
+    assert (pdir / "notes.txt").read_text() == "mine"
+    assert not [f for f in os.listdir(pdir) if f.startswith(".build_")]
+
+
+def test_device_bound_library_switches_device_around_calls(monkeypatch):
+    """An object created for another GPU than the current one launches with ITS device current:
+    DeviceBound wraps every library call in torch.cuda.device(index) unless it already is."""
+    import contextlib
+    import torch
+    from optbayesexpt_amd import _lib
+    log = []
+
+    class FakeLib:
+        def call(self, name, *args):
+            log.append(("call", name, current[0]))
+            return 0
+
+        def workspace_bytes(self, *a):
+            return 64
+
+    current = [0]
+
+    @contextlib.contextmanager
+    def fake_device(idx):
+        prev, current[0] = current[0], idx
+        log.append(("enter", idx))
+        try:
+            yield
+        finally:
+            current[0] = prev
+            log.append(("exit", idx))
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: current[0])
+    monkeypatch.setattr(torch.cuda, "device", fake_device)
+    same = _lib.DeviceBound(FakeLib(), torch.device("cuda", 0))
+    other = _lib.DeviceBound(FakeLib(), torch.device("cuda", 1))
+    same.call("obe_x")
+    assert log == [("call", "obe_x", 0)]
+    del log[:]
+    other.call("obe_y")
+    assert log == [("enter", 1), ("call", "obe_y", 1), ("exit", 1)] and current[0] == 0
+    assert other.workspace_bytes(1, 1, 1, 1) == 64                     # plain delegation
+    assert _lib.DeviceBound(other, torch.device("cuda", 1))._lib is other._lib      # no double wrapping
