@@ -29,6 +29,8 @@ def main(n_measure=200, n_samples=50000, selection="optimal", seed=0, quiet=Fals
 
     my_obe = optbayesexpt.OptBayesExpt(my_model_function, settings, parameters, constants, scale=False)
     my_obe.rng = np.random.default_rng(seed + 1)
+    # the simulator's noise comes from the module-level generator of obe_utils, as in the reference
+    optbayesexpt.obe_utils.rng = np.random.default_rng(seed + 2)
 
     true_pars = (rng.uniform(2.5, 3.5), rng.uniform(-2000, -400), 50000.0)
     noise_level = 500.0

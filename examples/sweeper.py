@@ -25,6 +25,8 @@ def main(n_measure=2000, n_samples=50000, selection="good", seed=0, quiet=False)
                                               utility_method="variance_approx", selection_method=selection,
                                               pickiness=20, noise_parameter_index=3)
     my_obe.rng = np.random.default_rng(seed + 1)
+    # the simulator's noise comes from the module-level generator of obe_utils, as in the reference
+    optbayesexpt.obe_utils.rng = np.random.default_rng(seed + 2)
     noise_level = 2000.0
     true_pars = [rng.uniform(2.5, 3.5), rng.uniform(400, 2000), 500.0, noise_level]
     my_sim = optbayesexpt.MeasurementSimulator(model, true_pars, (0.1,), noise_level=noise_level)

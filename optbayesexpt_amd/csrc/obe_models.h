@@ -230,6 +230,64 @@ __device__ __forceinline__ void batch_rcp_poisoned(const double (&q)[N], double 
     for (int j = 0; j < N; ++j) r[j] = ip[j / 2] * sibling_of<N>(q, j);
 }
 
+// Pair inverses ip[h] = s / (q[2h] q[2h+1]) for denominators known to be >= 1 (products of
+// Lorentzian denominators): nothing can underflow, so the only range check is on the root product.
+// Beyond 1e250 (where s * inv could leave the normal range) the root inverse is replaced by NaN; the
+// NaN reaches the setting's variance, the sweep reports kappa = NaN and the host repeats it with the
+// model's sweep_eval_safe().  An inf or NaN product fails the comparison as well.
+template <int N>
+__device__ __forceinline__ void batch_div_ge1(const double (&q)[N], double s, double (&ip)[(N + 1) / 2]) {
+    if constexpr (N == 1) {
+        ip[0] = s * fast_rcp(q[0]);
+    } else if constexpr (N == 2) {
+        const double pp = q[0] * q[1];
+        ip[0] = poison_unless(pp < 1e250, fast_rcp(pp)) * s;
+    } else if constexpr (N == 4) {
+        const double p0 = q[0] * q[1], p1 = q[2] * q[3];
+        const double root = p0 * p1;
+        const double is = poison_unless(root < 1e250, fast_rcp(root)) * s;
+        ip[0] = is * p1;
+        ip[1] = is * p0;
+    } else {
+        static_assert(N == 8, "batch_div_ge1: N must be 1, 2, 4 or 8");
+        const double p0 = q[0] * q[1], p1 = q[2] * q[3], p2 = q[4] * q[5], p3 = q[6] * q[7];
+        const double p01 = p0 * p1, p23 = p2 * p3;
+        const double root = p01 * p23;
+        const double is = poison_unless(root < 1e250, fast_rcp(root)) * s;
+        const double i01 = is * p23, i23 = is * p01;
+        ip[0] = i01 * p1;
+        ip[1] = i01 * p0;
+        ip[2] = i23 * p3;
+        ip[3] = i23 * p2;
+    }
+}
+
+// sum_{k in [LO, HI)} 1/q[k] as ONE fraction num/den (all q > 0, so num and den are sums and
+// products of positive numbers: no cancellation).  (na/da) + (nb/db) = (na db + nb da)/(da db):
+// 3 operations per combination, 2 for a leaf pair, 2 for a fraction plus a single term — 2K
+// operations for K terms, against the ~3.4 a separate batched inversion costs per term.
+template <int LO, int HI>
+__device__ __forceinline__ void sum_of_reciprocals(const double* q, double& num, double& den) {
+    if constexpr (HI - LO == 1) {
+        num = 1.0;
+        den = q[LO];
+    } else if constexpr (HI - LO == 2) {
+        num = q[LO] + q[LO + 1];
+        den = q[LO] * q[LO + 1];
+    } else if constexpr (HI - LO == 3) {
+        const double n2 = q[LO] + q[LO + 1], d2 = q[LO] * q[LO + 1];
+        num = fma(n2, q[LO + 2], d2);
+        den = d2 * q[LO + 2];
+    } else {
+        constexpr int MID = LO + (HI - LO + 1) / 2;
+        double na, da, nb, db;
+        sum_of_reciprocals<LO, MID>(q, na, da);
+        sum_of_reciprocals<MID, HI>(q, nb, db);
+        num = fma(na, db, nb * da);
+        den = da * db;
+    }
+}
+
 // ---- elementary functions for the inner level of generated sweep forms ----
 // The exact forms (Bayes update, eval_over_*, sweep_eval_safe, everything hoisted to the setting
 // or particle level) call ocml; the inner level of the flop-bound sweep uses these: accurate to
@@ -325,9 +383,42 @@ struct Lorentz {
         pk[K] = sw * th(K);
         pk[K + 1] = sw * (th(K + 1) - thbar[K + 1]);
     }
+    // K >= 3: the K peaks of one evaluation are combined into ONE fraction (sum_of_reciprocals,
+    // 2K operations) and the SPT fractions of a lane share one reciprocal: a * num/den with the
+    // amplitude folded into the pair inverses.  7 peaks: 35 instead of 39.6 FP64 issue slots per
+    // evaluation.  The denominators are products of K factors q >= 1, so the inversion tree of 8
+    // settings spans q^(8K): it is range-checked (batch_div_ge1, root < 1e250, i.e. |x - x0|/d up
+    // to ~170 at K = 7) and a sweep that leaves the range is repeated with sweep_eval_safe() — the
+    // peak-by-peak form, good to |x - x0|/d ~ 1e19.
+    static constexpr bool kCombinePeaks = K >= 3;
+    static constexpr bool kHasSafeEval = kCombinePeaks;
     template <int SPT>
-    __device__ __forceinline__ static void sweep_eval(const double (&xs)[SPT][NXS], const double* pk, double,
-                                                      const obe_model&, double (&v)[SPT][NC]) {
+    __device__ __forceinline__ static void sweep_eval(const double (&xs)[SPT][NXS], const double* pk, double sw,
+                                                      const obe_model& m, double (&v)[SPT][NC]) {
+        if constexpr (!kCombinePeaks) {
+            sweep_eval_safe<SPT>(xs, pk, sw, m, v);
+        } else {
+            double num[SPT], den[SPT];
+#pragma unroll
+            for (int j = 0; j < SPT; ++j) {
+                double q[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const double t = xs[j][0] - pk[k];
+                    q[k] = fma(t, t, 1.0);
+                }
+                sum_of_reciprocals<0, K>(q, num[j], den[j]);
+            }
+            double ip[(SPT + 1) / 2];
+            batch_div_ge1<SPT>(den, pk[K], ip);                       // a / (den[2h] den[2h+1])
+#pragma unroll
+            for (int j = 0; j < SPT; ++j) v[j][0] = fma(ip[j / 2] * sibling_of<SPT>(den, j), num[j], pk[K + 1]);
+        }
+    }
+    // the peak-by-peak form: one batched inversion per peak
+    template <int SPT>
+    __device__ __forceinline__ static void sweep_eval_safe(const double (&xs)[SPT][NXS], const double* pk, double,
+                                                           const obe_model&, double (&v)[SPT][NC]) {
 #pragma unroll
         for (int j = 0; j < SPT; ++j) v[j][0] = pk[K + 1];
 #pragma unroll
@@ -359,7 +450,8 @@ struct Lorentz {
     }
     // Two particles at once: their 2*SPT/2 pair products share ONE reciprocal, and each
     // particle's amplitude enters the inversion tree at its root (2 multiplies per 16 evaluations).
-    static constexpr bool kHasPairEval = true;
+    // (Peak-by-peak models only: a combined fraction already spans q^(8K) per particle.)
+    static constexpr bool kHasPairEval = !kCombinePeaks;
     template <int SPT>
     __device__ __forceinline__ static void sweep_eval_pair(const double (&xs)[SPT][NXS], const double* pa,
                                                            const double* pb, double (&va)[SPT][NC],

@@ -93,7 +93,10 @@ def lorentzian(n_peaks=1):
         for k in range(n_peaks):
             y = y + a / (((x - pars[k]) / d) ** 2 + 1)
         return y
-    return DeviceModel(f"lorentzian[{n_peaks}]", MODEL_LORENTZ, n_peaks, n_peaks + 2, 1, 1, 1, form)
+    # 3 and more peaks: the sweep combines the peaks of an evaluation into one fraction, range-checked,
+    # with the peak-by-peak form as its safe twin (csrc/obe_models.h, Lorentz<K>::kCombinePeaks)
+    return DeviceModel(f"lorentzian[{n_peaks}]", MODEL_LORENTZ, n_peaks, n_peaks + 2, 1, 1, 1, form,
+                       safe_sweep=n_peaks >= 3)
 
 
 def line_ab():

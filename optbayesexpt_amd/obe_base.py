@@ -91,6 +91,9 @@ class OptBayesExpt(ParticlePDF):
     #: and 1 048 576 particles): the unshifted variance is off by ~1e-15 * kappa relative, so 3000
     #: keeps it 30x inside the 1e-10 parity tolerance
     KAPPA_ENTER, KAPPA_LEAVE = 1000.0, 3000.0
+    #: after this many consecutive sweeps that had to be repeated with the model's safe twin, the fast
+    #: attempt is skipped (the range violation is a property of the settings grid)
+    SAFE_STREAK = 3
 
     def __init__(self, measurement_model, setting_values, parameter_samples,
                  constants, n_draws=DEFAULT_N_DRAWS, choke=None,
@@ -148,6 +151,7 @@ class OptBayesExpt(ParticlePDF):
 
         # settings on the device; a shard sweeps only [s_begin, s_end)
         self._shard = settings_shard
+        self._sweep_safe_streak = 0           # consecutive sweeps that had to be repeated with the safe twin
         if settings_shard is not None:
             self._s_begin, self._s_end = settings_shard.bounds(self._n_settings)
         else:
@@ -453,21 +457,33 @@ class OptBayesExpt(ParticlePDF):
         # with the shift: the variance is always good to a few 1e-12.
         mode = self.tuning_parameters.get("sweep_shift", "auto")
         shifted = (not full) or mode == "always" or (mode == "auto" and not self._sweep_unshifted)
-        launch(shifted)
-        self._check_pending_total()
-        if full and mode == "auto":
-            if shifted:
-                self._sweep_unshifted = bool(kappa[0] < self.KAPPA_ENTER)
-            elif not kappa[0] <= self.KAPPA_LEAVE:
-                self._sweep_unshifted = False
-                shifted = True
-                launch(True)
         safe = False
-        if np.isnan(kappa[0]) and self._device_model.safe_sweep:
-            # an expression model's branch-free batched divisions left their exact range somewhere
-            # (or the model really produces NaN): repeat with one IEEE reciprocal per element
+        if self._sweep_safe_streak < self.SAFE_STREAK:
+            launch(shifted)
+            self._check_pending_total()
+            if full and mode == "auto":
+                if shifted:
+                    self._sweep_unshifted = bool(kappa[0] < self.KAPPA_ENTER)
+                elif not kappa[0] <= self.KAPPA_LEAVE:
+                    self._sweep_unshifted = False
+                    shifted = True
+                    if not (np.isnan(kappa[0]) and self._device_model.safe_sweep):
+                        launch(True)
+            if np.isnan(kappa[0]) and self._device_model.safe_sweep:
+                # a model's branch-free batched divisions left their exact range somewhere (or the
+                # model really produces NaN): repeat with its always-in-range twin
+                safe = shifted = True
+                launch(True, safe=True)
+                self._sweep_safe_streak += 1
+            else:
+                self._sweep_safe_streak = 0
+        else:
+            # the fast form has left its range SAFE_STREAK sweeps in a row: that is a property of the
+            # settings grid (its span against the model's width), not of one cloud — stop paying for a
+            # fast attempt that is thrown away
             safe = shifted = True
             launch(True, safe=True)
+            self._check_pending_total()
         self.last_sweep = dict(shifted=shifted, kappa=float(kappa[0]), safe=safe)
         if want_best:
             return result["best"]

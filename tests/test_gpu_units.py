@@ -827,3 +827,46 @@ def test_object_on_a_device_that_is_not_current(obe):
     assert_allclose(pdf.mean(), x.mean(axis=1), rtol=1e-11, atol=1e-14)
     pdf.bayesian_update(np.exp(-x[0] ** 2))
     assert torch.cuda.current_device() == 0 and pdf._weights.tensor().device.index == 1
+
+
+@pytest.mark.parametrize("k", [2, 3, 4, 5, 7, 8])
+def test_multi_peak_lorentzian_sweep_forms(obe, k):
+    """Lorentz<K>: up to 2 peaks are inverted peak by peak (two particles per reciprocal), from 3
+    peaks on the K peaks of an evaluation are combined into one fraction whose denominators the
+    settings of a lane invert together (range-checked; the peak-by-peak form is its safe twin).
+    Both against the oracle's two-pass weighted variance, for every settings-per-lane variant,
+    odd particle counts, and a grid so wide against d that the combined form leaves its range."""
+    g = np.random.default_rng(100 + k)
+    n = 1537
+    prior = np.vstack([g.uniform(2, 4, (k, n)), g.uniform(400, 2000, (1, n)), g.normal(500, 1000, (1, n))])
+    w = g.exponential(1.0, n)
+    w /= w.sum()
+    fn = omodels.multi_lorentzian(k)
+    for ns in (4100, 1030, 520, 300):                     # 8 / 4 / 2 / 1 settings per lane
+        sv = (np.linspace(1.5, 4.5, ns),)
+        for d in (0.1, 1e-3, 1e-7):
+            o = obe.OptBayesExpt(obe.models.lorentzian(k), sv, prior.copy(), (d,), utility_method="variance_full",
+                                 auto_resample=False, default_noise_std=500.0)
+            o.particle_weights = w
+            ref = oracle.yvar_full_sweep(fn, oracle.flatten_settings(sv), prior, w, (d,))
+            got = o.yvar_from_parameter_draws()
+            # q <= 1 + (2.5/d)^2; the combined tree of SPT settings spans q^(K*SPT) < 1e250
+            spt = 8 if ns >= 4096 else 4 if ns >= 1024 else 2 if ns >= 512 else 1
+            out_of_range = k >= 3 and spt > 1 and (k * spt) * np.log10(1 + (2.5 / d) ** 2) > 250
+            in_range = k < 3 or (k * spt) * np.log10(1 + (3.0 / d) ** 2) < 240
+            if out_of_range:
+                assert o.last_sweep["safe"], (k, ns, d, o.last_sweep)
+            if in_range:
+                assert not o.last_sweep["safe"], (k, ns, d, o.last_sweep)
+            assert_allclose(got, ref, rtol=2e-10, atol=1e-10 * ref.max(), err_msg=f"K={k} ns={ns} d={d}")
+    if k >= 3:
+        # a grid that always leaves the range: after SAFE_STREAK repeats the fast attempt is skipped
+        sv = (np.linspace(1.5, 4.5, 4100),)
+        o = obe.OptBayesExpt(obe.models.lorentzian(k), sv, prior.copy(), (1e-7,), utility_method="variance_full",
+                             auto_resample=False, default_noise_std=500.0)
+        o.particle_weights = w
+        ref = oracle.yvar_full_sweep(fn, oracle.flatten_settings(sv), prior, w, (1e-7,))
+        for rep in range(o.SAFE_STREAK + 2):
+            got = o.yvar_from_parameter_draws()
+            assert o.last_sweep["safe"] and o._sweep_safe_streak == min(rep + 1, o.SAFE_STREAK)
+            assert_allclose(got, ref, rtol=2e-10, atol=1e-10 * ref.max())
