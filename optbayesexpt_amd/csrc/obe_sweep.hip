@@ -7,13 +7,19 @@
 //   * lane <-> setting.  Each thread owns SPT settings in registers (prepared setting,
 //     shift, and the two running moments per channel); nothing is reduced across lanes
 //     inside the loop.
-//   * the particle axis is streamed: a workgroup stages a tile of particles with
-//     coalesced loads of the (D+1) SoA rows, packs each particle once (per-particle
-//     divisions hoisted out of the grid) into an AoS LDS tile, and every lane then
-//     reads the same LDS address (broadcast, conflict-free) per particle.
-//   * grid = setting tiles (x) x particle chunks (y): at 65 536 settings there are only
-//     64 setting tiles of 1024, so the particle axis is split to fill 256 CUs; chunk
-//     partial moments share one shift per setting, so they simply add (finalize pass).
+//   * sweep_pack_kernel packs every particle ONCE per sweep (per-particle divisions and
+//     sqrt(w) hoisted out of the grid) into an AoS array in the workspace.
+//   * the particle axis is streamed through the SCALAR path: a packed particle is the same
+//     for all 64 lanes, so it is fetched with s_load_dwordx8 into SGPRs (one group ahead of
+//     its use) and enters the FP64 instructions as their scalar operand — no LDS tile, no
+//     barrier, no VGPRs for broadcast values, and each wave runs on its own.
+//   * a workgroup is 4 waves that own the SAME 64*SPT settings and a quarter each of one
+//     particle chunk; their moments are added in a fixed order through LDS at the end, so a
+//     work item is (64*SPT settings) x (one chunk): ~5000 of them at 65 536 x 1 048 576, six
+//     per resident workgroup slot (the launch is one wave of equal items, so its duration is
+//     set by how evenly they finish), with partials of only n_chunks x N_s.
+//   * grid = setting tiles x particle chunks, XCD-aware; chunk partial moments share one
+//     shift per setting, so they simply add (finalize pass).
 //   * arithmetic: FP64 VALU only (no contraction over a shared operand => no MFMA).
 //     The roof is the FP64 vector rate, not HBM: compulsory traffic is
 //     8(D+1)N_p + 8 S N_s bytes for N_s*N_p evaluations.
@@ -23,13 +29,14 @@
 // catastrophically (np.var is two-pass; the shift plays the role of its first pass).
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 
 #include "obe_common.h"
 #include "obe_models.h"
 
 namespace obe {
 
-constexpr int kSweepLdsDoubles = 4096;   // 32 KiB tile per workgroup -> 4-5 workgroups per CU
+constexpr int kSweepWaves = kBlock / kWave;   // waves of a workgroup: same settings, a quarter of the chunk each
 constexpr int kMaxChunks = 1024;
 constexpr int kFinMaxBlocks = 65536;     // finalize workgroups (64 settings each) the argmax partials hold
 constexpr int kFinSettings = kWave;      // settings per finalize workgroup
@@ -41,28 +48,40 @@ static int64_t argmax_slots(int64_t n_settings) {
 // one-workgroup path for reference-semantics sweeps (sweep_small_kernel)
 constexpr int64_t kSmallSweepDraws = 256, kSmallSweepEvals = 131072;
 
+// packed particle: M::NPK doubles + sqrt(weight), padded to 16 bytes
+template <class M>
+constexpr int packed_width() { return (M::NPK + 2) & ~1; }
+#ifdef OBE_PLUGIN_MODEL_HEADER
+constexpr int kMaxPackedWidth = packed_width<PluginModel>();
+#else
+// every registry model: Lorentz<K> K + 2 <= n_dims, lines <= 2, Rabi 3, Coil 7
+static int max_packed_width(int n_dims) { return std::max(8, (n_dims + 2) & ~1); }
+#endif
+
 struct SweepPlan {
     int spt;           // settings per thread
-    int tiles_x;       // setting tiles
-    int nchunks;       // particle chunks (grid.y)
+    int tiles_x;       // setting tiles of 64 * spt
+    int nchunks;       // particle chunks
     int64_t chunk;     // draws per chunk
 };
 
-// Tuned on MI355X at 65 536 x 1 048 576 (tools/tune_sweep.sh): 8 settings per lane (one
-// batched reciprocal per 8 evaluations); 768 resident workgroups (3 per CU at 161 VGPRs).
-// 1536 workgroups = two full rounds: within 1 % of the best time (3072) with half the
-// chunk partials to write and re-read; 768 loses 5 % to the tail.
+// Tuned on MI355X at 65 536 x 1 048 576 (tools/exp_sweep_launch.sh): 8 settings per lane (one
+// batched reciprocal per 8 evaluations); 768 workgroups are resident (3 per CU at <= 168 VGPRs),
+// and the launch is fastest with about six work items per resident slot (4608: within 0.5 % of
+// the best; 1536 is 2 % slower).  Smaller grids get fewer (down to 1536: 4 096 x 262 144 takes
+// 0.27 ms with 1536 or 4608 items, 0.30 ms with 896), so that the chunk partials stay small.
 static SweepPlan plan_sweep(int64_t ns, int64_t nd) {
     static const int force_spt = getenv("OBE_SWEEP_SPT") ? atoi(getenv("OBE_SWEEP_SPT")) : 0;         // tuning aids
     static const int force_blocks = getenv("OBE_SWEEP_BLOCKS") ? atoi(getenv("OBE_SWEEP_BLOCKS")) : 0;
     SweepPlan p;
     p.spt = ns >= 4096 ? 8 : (ns >= 1024 ? 4 : (ns >= 512 ? 2 : 1));
     if (force_spt == 1 || force_spt == 2 || force_spt == 4 || force_spt == 8) p.spt = force_spt;
-    p.tiles_x = static_cast<int>((ns + (int64_t)kBlock * p.spt - 1) / ((int64_t)kBlock * p.spt));
-    const int target_blocks = force_blocks > 0 ? force_blocks : 1536;
+    p.tiles_x = static_cast<int>((ns + (int64_t)kWave * p.spt - 1) / ((int64_t)kWave * p.spt));
+    const int64_t by_work = static_cast<int64_t>((double)ns * (double)nd / 1.25e6);
+    const int64_t target_blocks = force_blocks > 0 ? force_blocks : std::max<int64_t>(1536, std::min<int64_t>(4608, by_work));
     int64_t want = (target_blocks + p.tiles_x - 1) / p.tiles_x;
-    int64_t cap = std::min<int64_t>(kMaxChunks, (nd + 511) / 512);     // >= 512 draws per chunk
-    if (cap < 1) cap = 1;
+    if (want > 8) want = (want + 7) / 8 * 8;          // whole groups of 8 chunks: one per XCD
+    const int64_t cap = std::max<int64_t>(1, std::min<int64_t>(kMaxChunks, nd / 256));   // >= 64 draws per wave
     p.nchunks = static_cast<int>(std::max<int64_t>(1, std::min(want, cap)));
     p.chunk = (nd + p.nchunks - 1) / p.nchunks;
     p.chunk = (p.chunk + 63) / 64 * 64;
@@ -70,11 +89,12 @@ static SweepPlan plan_sweep(int64_t ns, int64_t nd) {
     return p;
 }
 
-static int64_t sweep_ws_doubles(int64_t ns, int64_t nd, int nc) {
+static int64_t sweep_ws_doubles(int64_t ns, int64_t nd, int nc, int packed_w) {
     const SweepPlan p = plan_sweep(ns, nd);
     return 2 * (int64_t)p.nchunks * nc * ns      // partial S1, S2
            + (int64_t)nc * ns                      // per-setting shift
-           + 3 * argmax_slots(ns) + 16;            // argmax / kappa partials + scalars
+           + 3 * argmax_slots(ns) + 16             // argmax / kappa partials + scalars
+           + nd * packed_w + 8;                    // packed draws
 }
 
 struct SweepArgs {
@@ -91,19 +111,57 @@ struct SweepArgs {
     const double* moments;     // obe_moments output: mean parameters at +2
     int64_t chunk;
     int tiles_x, nchunks;      // logical grid: setting tiles x particle chunks
-    int tile;                  // particles per LDS tile
+    int one;                   // 1 (a run-time constant the prefetch address is built from)
+    double* packed;            // (nd, packed_width): written by sweep_pack_kernel, read by sweep_kernel
     double* part1;
     double* part2;
     double* cs_out;            // (C, ns): the shift each setting used (0 when unshifted)
 };
 
+// Every draw packed once per sweep: M::pack() (per-particle divisions, sqrt(w) folded into the
+// amplitudes) and sqrt(w), one 16-byte-aligned record per draw.
+template <class M>
+__global__ __launch_bounds__(kBlock) void sweep_pack_kernel(SweepArgs a) {
+    constexpr int NPK = M::NPK, NPKW = packed_width<M>();
+    const double* __restrict__ thbar = a.moments + 2;   // weighted-mean parameters (K3 output)
+    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < a.nd; p += (int64_t)gridDim.x * kBlock) {
+        int64_t src = p;
+        double w;
+        if (a.draw_idx) {
+            src = a.draw_idx[p];
+            src = src < 0 ? 0 : (src >= a.n_particles ? a.n_particles - 1 : src);
+            w = a.uniform_w;
+        } else {
+            w = a.weights[p];
+        }
+        const double sw = sqrt(w);
+        double pk[NPKW];
+        M::pack(ParamRef{a.particles + src, a.ld_p}, thbar, a.m, sw, pk);
+        pk[NPK] = sw;
+#pragma unroll
+        for (int k = NPK + 1; k < NPKW; ++k) pk[k] = 0.0;
+        double2* __restrict__ out = reinterpret_cast<double2*>(a.packed + p * NPKW);
+#pragma unroll
+        for (int k = 0; k < NPKW / 2; ++k) out[k] = double2{pk[2 * k], pk[2 * k + 1]};
+    }
+}
+
+// a wave-uniform 64-bit value, held in scalar registers
+__device__ __forceinline__ int64_t wave_uniform(int64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
+    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(static_cast<uint64_t>(v) >> 32));
+    return static_cast<int64_t>((static_cast<uint64_t>(hi) << 32) | lo);
+}
+
 // SAFE (models with kHasSafeEval only): evaluate with the model's sweep_eval_safe() — the repeat
 // after a sweep whose fast, branch-free batch inversions poisoned a variance (kappa = NaN).
 template <class M, int SPT, bool SHIFT, bool SAFE = false>
 __global__ __launch_bounds__(kBlock) void sweep_kernel(SweepArgs a) {
-    constexpr int NC = M::NC, NXS = M::NXS, NPK = M::NPK;
-    constexpr int NPKW = (NPK + 1 + 1) & ~1;   // packed particle + sqrt(weight), padded to 16 B
-    extern __shared__ __attribute__((aligned(16))) double tile[];
+    constexpr int NC = M::NC, NXS = M::NXS, NPK = M::NPK, NPKW = packed_width<M>();
+    constexpr bool PAIRS = has_pair_eval<M>::value && SPT >= 2 && !SAFE;
+    // particles per prefetched group: two groups of packed particles live in SGPRs (~100 per wave)
+    constexpr int G = PAIRS ? (NPKW <= 4 ? 4 : 2) : (NPKW <= 4 ? 4 : (NPKW <= 8 ? 2 : 1));
+    __shared__ double red[kSweepWaves][NC][2][kWave];
 
     // XCD-aware block -> (setting tile, particle chunk) map.  Workgroup b is dispatched to
     // XCD b % 8 (observed placement; only speed depends on it): give XCD x the chunks
@@ -113,6 +171,7 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(SweepArgs a) {
     const int chunk_id = (slot / a.tiles_x) * 8 + xcd;
     const int tile_x = slot % a.tiles_x;
     if (chunk_id >= a.nchunks) return;
+    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
 
     double xs[SPT][NXS], cs[SPT][NC], s1[SPT][NC], s2[SPT][NC];
     const double* __restrict__ thbar = a.moments + 2;   // weighted-mean parameters (K3 output)
@@ -122,7 +181,7 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(SweepArgs a) {
         M::pack(ParamRef{thbar, 1}, thbar, a.m, 1.0, pkbar);
 #pragma unroll
         for (int j = 0; j < SPT; ++j) {
-            int64_t s = ((int64_t)tile_x * SPT + j) * kBlock + threadIdx.x;
+            int64_t s = ((int64_t)tile_x * SPT + j) * kWave + lane;
             if (s >= a.ns) s = a.ns - 1;
             double x[M::NS];
 #pragma unroll
@@ -139,96 +198,120 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(SweepArgs a) {
 #pragma unroll
                 for (int c = 0; c < NC; ++c) cs[j][c] = 0.0;
         }
-        if (chunk_id == 0) {
-#pragma unroll
-            for (int j = 0; j < SPT; ++j) {
-                const int64_t s = ((int64_t)tile_x * SPT + j) * kBlock + threadIdx.x;
-                if (s < a.ns) {
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) a.cs_out[(int64_t)c * a.ns + s] = cs[j][c];
-                }
-            }
-        }
     }
 
-    const int64_t p_begin = (int64_t)chunk_id * a.chunk;
-    const int64_t p_end = p_begin + a.chunk < a.nd ? p_begin + a.chunk : a.nd;
-    for (int64_t t0 = p_begin; t0 < p_end; t0 += a.tile) {
-        const int n = static_cast<int>(p_end - t0 < a.tile ? p_end - t0 : a.tile);
-        __syncthreads();   // previous tile fully consumed
-        for (int i = threadIdx.x; i < n; i += kBlock) {
-            const int64_t p = t0 + i;
-            int64_t src = p;
-            double w;
-            if (a.draw_idx) {
-                src = a.draw_idx[p];
-                src = src < 0 ? 0 : (src >= a.n_particles ? a.n_particles - 1 : src);
-                w = a.uniform_w;
-            } else {
-                w = a.weights[p];
-            }
-            const double sw = sqrt(w);
-            double pk[NPK];
-            M::pack(ParamRef{a.particles + src, a.ld_p}, thbar, a.m, sw, pk);
-#pragma unroll
-            for (int k = 0; k < NPK; ++k) tile[i * NPKW + k] = pk[k];
-            tile[i * NPKW + NPK] = sw;
-        }
-        __syncthreads();
-        auto accumulate = [&](const double (&v)[SPT][NC], double sw) {
-#pragma unroll
-            for (int j = 0; j < SPT; ++j) {
-#pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    const double u = SHIFT ? fma(-cs[j][c], sw, v[j][c]) : v[j][c];   // sqrt(w) * (y' - c_s)
-                    s1[j][c] = fma(sw, u, s1[j][c]);                     // sum w (y' - c_s)
-                    s2[j][c] = fma(u, u, s2[j][c]);                      // sum w (y' - c_s)^2
-                }
-            }
-        };
-        int i = 0;
-        if constexpr (has_pair_eval<M>::value && SPT >= 2 && !SAFE) {
-            // unrolled x4: the in-order wave then has other pairs' wide phases to issue while one
-            // pair's inversion chain (product -> v_rcp_f64 -> 3 FMA -> back-substitution) is in
-            // flight (measured at c3: 15.36 ms rolled, 14.73 x2, 14.43 x4, 14.8 x8; forcing 2
-            // waves/SIMD for more registers: 15.7)
-#pragma unroll 4
-            for (; i + 1 < n; i += 2) {          // two particles share one reciprocal
-                double pa[NPK], pb[NPK];
-#pragma unroll
-                for (int k = 0; k < NPK; ++k) {
-                    pa[k] = tile[i * NPKW + k];                          // same address in every lane:
-                    pb[k] = tile[(i + 1) * NPKW + k];                    // LDS broadcast
-                }
-                const double swa = tile[i * NPKW + NPK], swb = tile[(i + 1) * NPKW + NPK];
-                double va[SPT][NC], vb[SPT][NC];
-                M::template sweep_eval_pair<SPT>(xs, pa, pb, va, vb);
-                accumulate(va, swa);
-                accumulate(vb, swb);
-            }
-        }
-#pragma unroll 4
-        for (; i < n; ++i) {
-            double pk[NPK];
-#pragma unroll
-            for (int k = 0; k < NPK; ++k) pk[k] = tile[i * NPKW + k];   // same address in every lane: LDS broadcast
-            const double sw = tile[i * NPKW + NPK];
-            double v[SPT][NC];
-            if constexpr (SAFE) M::template sweep_eval_safe<SPT>(xs, pk, sw, a.m, v);
-            else M::template sweep_eval<SPT>(xs, pk, sw, a.m, v);        // sqrt(w) * y'
-            accumulate(v, sw);
-        }
-    }
+    // this wave's quarter of the chunk
+    const int64_t c_begin = (int64_t)chunk_id * a.chunk;
+    const int64_t c_end = c_begin + a.chunk < a.nd ? c_begin + a.chunk : a.nd;
+    const int64_t per = ((c_end - c_begin + 4 * kSweepWaves - 1) / (4 * kSweepWaves)) * 4;
+    int64_t p_begin = c_begin + wid * per;
+    if (p_begin > c_end) p_begin = c_end;
+    const int64_t p_end = p_begin + per < c_end ? p_begin + per : c_end;
+    const int n = static_cast<int>(wave_uniform(p_end - p_begin));
+    const double* __restrict__ pk = a.packed + wave_uniform(p_begin * NPKW);   // uniform address: scalar loads
 
+    auto accumulate = [&](const double (&v)[SPT][NC], double sw) {
 #pragma unroll
-    for (int j = 0; j < SPT; ++j) {
-        const int64_t s = ((int64_t)tile_x * SPT + j) * kBlock + threadIdx.x;
-        if (s < a.ns) {
+        for (int j = 0; j < SPT; ++j) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
+                const double u = SHIFT ? fma(-cs[j][c], sw, v[j][c]) : v[j][c];   // sqrt(w) * (y' - c_s)
+                s1[j][c] = fma(sw, u, s1[j][c]);                     // sum w (y' - c_s)
+                s2[j][c] = fma(u, u, s2[j][c]);                      // sum w (y' - c_s)^2
+            }
+        }
+    };
+    auto load_group = [&](int i0, double (&g)[G][NPKW]) {
+#pragma unroll
+        for (int e = 0; e < G; ++e)
+#pragma unroll
+            for (int k = 0; k < NPKW; ++k) g[e][k] = pk[(i0 + e) * NPKW + k];
+    };
+    auto process_group = [&](const double (&g)[G][NPKW]) {
+        if constexpr (PAIRS) {
+#pragma unroll
+            for (int e = 0; e < G; e += 2) {              // two particles share one reciprocal
+                double va[SPT][NC], vb[SPT][NC];
+                M::template sweep_eval_pair<SPT>(xs, g[e], g[e + 1], va, vb);
+                accumulate(va, g[e][NPK]);
+                accumulate(vb, g[e + 1][NPK]);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < G; ++e) {
+                double v[SPT][NC];
+                if constexpr (SAFE) M::template sweep_eval_safe<SPT>(xs, g[e], g[e][NPK], a.m, v);
+                else M::template sweep_eval<SPT>(xs, g[e], g[e][NPK], a.m, v);   // sqrt(w) * y'
+                accumulate(v, g[e][NPK]);
+            }
+        }
+    };
+
+    int i = 0;
+    if (n >= G) {
+        // software pipeline: the next group's scalar loads are in flight while this one is evaluated
+        // (an L2 round trip is ~1 us; a group of the Lorentzian is 4 x 8 x 7.4 issue slots ~ 0.4 us)
+        double cur[G][NPKW];
+        load_group(0, cur);
+        asm("" : "+s"(cur[0][0]));     // the first group has landed before the loop: no wait at the loop head,
+                                       // where it would also wait for the prefetch just issued
+        for (; i + G <= n; i += G) {
+            double nxt[G][NPKW];
+            // (a.one == 1, unknown to the optimizer: it must not fold the prefetch into the next trip's
+            // own load; the last trip re-reads its own group)
+            load_group(i + 2 * G <= n ? i + G * a.one : i, nxt);
+            __builtin_amdgcn_sched_barrier(0);                // the loads stay ahead of the arithmetic
+            process_group(cur);
+#pragma unroll
+            for (int e = 0; e < G; ++e)
+#pragma unroll
+                for (int k = 0; k < NPKW; ++k) cur[e][k] = nxt[e][k];
+        }
+    }
+    for (; i < n; ++i) {
+        double g[NPKW], v[SPT][NC];
+#pragma unroll
+        for (int k = 0; k < NPKW; ++k) g[k] = pk[i * NPKW + k];
+        if constexpr (SAFE) M::template sweep_eval_safe<SPT>(xs, g, g[NPK], a.m, v);
+        else M::template sweep_eval<SPT>(xs, g, g[NPK], a.m, v);
+        accumulate(v, g[NPK]);
+    }
+
+    // (global stores only after the streaming loop: nothing may alias the packed draws before it,
+    // or their loads would not be scalar)
+    if (chunk_id == 0 && wid == 0) {
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) {
+            const int64_t s = ((int64_t)tile_x * SPT + j) * kWave + lane;
+            if (s < a.ns) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) a.cs_out[(int64_t)c * a.ns + s] = cs[j][c];
+            }
+        }
+    }
+    // the four waves' moments, added in wave order (fixed association); wave j % 4 writes setting j
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            red[wid][c][0][lane] = s1[j][c];
+            red[wid][c][1][lane] = s2[j][c];
+        }
+        __syncthreads();
+        const int64_t s = ((int64_t)tile_x * SPT + j) * kWave + lane;
+        if (wid == (j & (kSweepWaves - 1)) && s < a.ns) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                double t1 = red[0][c][0][lane], t2 = red[0][c][1][lane];
+#pragma unroll
+                for (int g = 1; g < kSweepWaves; ++g) {
+                    t1 += red[g][c][0][lane];
+                    t2 += red[g][c][1][lane];
+                }
                 const int64_t o = ((int64_t)chunk_id * NC + c) * a.ns + s;
-                a.part1[o] = s1[j][c];
-                a.part2[o] = s2[j][c];
+                a.part1[o] = t1;
+                a.part2[o] = t2;
             }
         }
     }
@@ -527,11 +610,12 @@ struct SweepWs {
     int64_t* out_i;
     double* bk;
     double* cs;
+    double* packed;
 };
 
 static int carve_sweep_ws(void* d_ws, int64_t ws_bytes, int64_t part_doubles, int64_t cs_doubles, SweepWs& w,
-                          int64_t slots = kMaxBlocks) {
-    const int64_t need = (2 * part_doubles + cs_doubles + 3 * slots + 16) * sizeof(double);
+                          int64_t slots = kMaxBlocks, int64_t packed_doubles = 0) {
+    const int64_t need = (2 * part_doubles + cs_doubles + 3 * slots + 16 + packed_doubles + 2) * sizeof(double);
     if (!d_ws || ws_bytes < need) return bad_arg("sweep workspace too small");
     double* base = static_cast<double*>(d_ws);
     w.out_v = base;                                     // [0] best value, [1] worst cancellation factor
@@ -542,6 +626,8 @@ static int carve_sweep_ws(void* d_ws, int64_t ws_bytes, int64_t part_doubles, in
     w.cs = base + 16 + 3 * slots;
     w.part1 = w.cs + cs_doubles;
     w.part2 = w.part1 + part_doubles;
+    double* pk = w.part2 + part_doubles;                // 16-byte aligned records
+    w.packed = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(pk) + 15) & ~uintptr_t(15));
     return 0;
 }
 
@@ -558,36 +644,40 @@ static int read_best(const SweepWs& w, double* h_best, int64_t* h_best_idx, hipS
 }
 
 template <class M, bool SHIFT, bool SAFE>
-static void launch_sweep_spt(int spt, unsigned grid, size_t lds, const SweepArgs& a, hipStream_t st) {
+static void launch_sweep_spt(int spt, unsigned grid, const SweepArgs& a, hipStream_t st) {
     switch (spt) {
-        case 8: sweep_kernel<M, 8, SHIFT, SAFE><<<grid, kBlock, lds, st>>>(a); break;
-        case 4: sweep_kernel<M, 4, SHIFT, SAFE><<<grid, kBlock, lds, st>>>(a); break;
-        case 2: sweep_kernel<M, 2, SHIFT, SAFE><<<grid, kBlock, lds, st>>>(a); break;
-        default: sweep_kernel<M, 1, SHIFT, SAFE><<<grid, kBlock, lds, st>>>(a); break;
+        case 8: sweep_kernel<M, 8, SHIFT, SAFE><<<grid, kBlock, 0, st>>>(a); break;
+        case 4: sweep_kernel<M, 4, SHIFT, SAFE><<<grid, kBlock, 0, st>>>(a); break;
+        case 2: sweep_kernel<M, 2, SHIFT, SAFE><<<grid, kBlock, 0, st>>>(a); break;
+        default: sweep_kernel<M, 1, SHIFT, SAFE><<<grid, kBlock, 0, st>>>(a); break;
     }
+}
+
+// pack (once per sweep; `repack` = false when the caller knows the packed draws are current)
+template <class M>
+static int launch_pack(const SweepArgs& a, hipStream_t st) {
+    sweep_pack_kernel<M><<<stream_blocks(a.nd, kBlock), kBlock, 0, st>>>(a);
+    OBE_CHECK_LAUNCH("sweep_pack_kernel");
+    return 0;
 }
 
 template <class M>
 static int launch_sweep(const SweepPlan& p, SweepArgs& a, int flags, hipStream_t st) {
-    constexpr int NPKW = (M::NPK + 2) & ~1;
-    int tile = kSweepLdsDoubles / NPKW;
-    tile = tile / 64 * 64;
-    a.tile = tile;
-    const size_t lds = (size_t)tile * NPKW * sizeof(double);
     a.tiles_x = p.tiles_x;
     a.nchunks = p.nchunks;
+    a.one = 1;
     const unsigned grid = (unsigned)p.tiles_x * (unsigned)((p.nchunks + 7) / 8 * 8);
     const bool shifted = flags & OBE_SWEEP_SHIFTED;
     bool safe = false;
     if constexpr (has_safe_eval<M>::value) safe = flags & OBE_SWEEP_SAFE;
     if (safe) {
         if constexpr (has_safe_eval<M>::value) {        // always shifted: the careful variant
-            launch_sweep_spt<M, true, true>(p.spt, grid, lds, a, st);
+            launch_sweep_spt<M, true, true>(p.spt, grid, a, st);
         }
     } else if (shifted) {
-        launch_sweep_spt<M, true, false>(p.spt, grid, lds, a, st);
+        launch_sweep_spt<M, true, false>(p.spt, grid, a, st);
     } else {
-        launch_sweep_spt<M, false, false>(p.spt, grid, lds, a, st);
+        launch_sweep_spt<M, false, false>(p.spt, grid, a, st);
     }
     OBE_CHECK_LAUNCH("sweep_kernel");
     return 0;
@@ -605,8 +695,12 @@ static int prepare_sweep(const obe_model* m, obe_model& mm, const double* d_sett
     if (nd <= 0) return bad_arg("sweep: n_draws must be positive");
     plan = plan_sweep(ns, nd);
     const int64_t part = (int64_t)plan.nchunks * mm.n_channels * ns;
-    if (int rc = carve_sweep_ws(d_ws, ws_bytes, part, (int64_t)mm.n_channels * ns, w, argmax_slots(ns))) return rc;
+    int packed_w = 0;
+    if (int rc = dispatch_model(mm, [&](auto M) -> int { packed_w = packed_width<decltype(M)>(); return 0; })) return rc;
+    if (int rc = carve_sweep_ws(d_ws, ws_bytes, part, (int64_t)mm.n_channels * ns, w, argmax_slots(ns), nd * packed_w))
+        return rc;
     a.cs_out = w.cs;
+    a.packed = w.packed;
     a.m = mm;
     a.settings = d_settings;
     a.ld_s = ld_s;
@@ -636,7 +730,12 @@ int64_t obe_workspace_bytes(int64_t n_particles, int64_t n_settings, int32_t n_c
     if (n_settings < 1) n_settings = 1;
     if (n_channels < 1) n_channels = 1;
     if (n_dims < 1) n_dims = 1;
-    int64_t d = sweep_ws_doubles(n_settings, n_particles, n_channels);
+#ifdef OBE_PLUGIN_MODEL_HEADER
+    const int packed_w = kMaxPackedWidth;
+#else
+    const int packed_w = max_packed_width(n_dims);
+#endif
+    int64_t d = sweep_ws_doubles(n_settings, n_particles, n_channels, packed_w);
     const int64_t nv = std::max<int64_t>(2 + 2 * n_dims, (int64_t)n_dims * (n_dims + 1) / 2);
     d = std::max<int64_t>(d, 1024 * nv + nv);                       // moments
     d = std::max<int64_t>(d, (n_particles + 2047) / 2048 + 8);      // cdf block sums
@@ -680,7 +779,10 @@ int obe_sweep_utility(const obe_model* m, const double* d_settings, int64_t ld_s
         if (rc) return rc;
         return read_best(w, h_best, h_best_idx, st, h_kappa);
     }
-    int rc = dispatch_model(mm, [&](auto M) -> int { return launch_sweep<decltype(M)>(plan, a, shifted, st); });
+    int rc = dispatch_model(mm, [&](auto M) -> int {
+        if (int e = launch_pack<decltype(M)>(a, st)) return e;
+        return launch_sweep<decltype(M)>(plan, a, shifted, st);
+    });
     if (rc) return rc;
     const int nb = static_cast<int>((n_settings + kFinSettings - 1) / kFinSettings);
     if (nb > kFinMaxBlocks) return bad_arg("obe_sweep_utility: more than 4 194 304 settings per call");
@@ -696,7 +798,7 @@ int obe_sweep_kernel_time(const obe_model* m, const double* d_settings, int64_t 
                           const double* d_particles, int64_t ld_p, int64_t n_particles, const double* d_weights,
                           const double* d_moments, int32_t shifted, void* d_ws, int64_t ws_bytes, int32_t iters,
                           float* h_ms_avg, void* stream) {
-    if (!h_ms_avg || iters < 1) return bad_arg("obe_sweep_kernel_time: bad arguments");
+    if (!h_ms_avg || iters == 0) return bad_arg("obe_sweep_kernel_time: bad arguments");
     obe_model mm;
     SweepPlan plan;
     SweepArgs a{};
@@ -709,17 +811,46 @@ int obe_sweep_kernel_time(const obe_model* m, const double* d_settings, int64_t 
     OBE_HIP_TRY(hipEventCreate(&e0));
     OBE_HIP_TRY(hipEventCreate(&e1));
     const int sh = shifted;
-    int rc = dispatch_model(mm, [&](auto M) -> int { return launch_sweep<decltype(M)>(plan, a, sh, st); });   // warm
-    if (!rc) {
-        (void)hipEventRecord(e0, st);
-        for (int i = 0; i < iters && !rc; ++i)
+    int rc = dispatch_model(mm, [&](auto M) -> int { return launch_pack<decltype(M)>(a, st); });
+    if (rc) {
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        return rc;
+    }
+    if (iters < 0) {
+        // isolated launches, as a measurement cycle issues them: the stream is drained before each
+        // one, so neither the previous launch's tail nor its clocks carry over
+        static const int gap_us = getenv("OBE_TIME_GAP_US") ? atoi(getenv("OBE_TIME_GAP_US")) : 0;   // tuning aid
+        double total = 0.0;
+        for (int i = 0; i < -iters && !rc; ++i) {
+            hipError_t e = hipStreamSynchronize(st);
+            if (gap_us > 0) {
+                timespec ts{0, gap_us * 1000L};
+                nanosleep(&ts, nullptr);
+            }
+            (void)hipEventRecord(e0, st);
             rc = dispatch_model(mm, [&](auto M) -> int { return launch_sweep<decltype(M)>(plan, a, sh, st); });
-        (void)hipEventRecord(e1, st);
-        hipError_t e = hipEventSynchronize(e1);
-        float ms = 0.f;
-        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-        if (e != hipSuccess) rc = fail(e, "sweep timing");
-        *h_ms_avg = ms / (float)iters;
+            (void)hipEventRecord(e1, st);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            float ms = 0.f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            if (e != hipSuccess && !rc) rc = fail(e, "sweep timing");
+            total += ms;
+        }
+        *h_ms_avg = (float)(total / (double)(-iters));
+    } else {
+        rc = dispatch_model(mm, [&](auto M) -> int { return launch_sweep<decltype(M)>(plan, a, sh, st); });   // warm
+        if (!rc) {
+            (void)hipEventRecord(e0, st);
+            for (int i = 0; i < iters && !rc; ++i)
+                rc = dispatch_model(mm, [&](auto M) -> int { return launch_sweep<decltype(M)>(plan, a, sh, st); });
+            (void)hipEventRecord(e1, st);
+            hipError_t e = hipEventSynchronize(e1);
+            float ms = 0.f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            if (e != hipSuccess) rc = fail(e, "sweep timing");
+            *h_ms_avg = ms / (float)iters;
+        }
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
