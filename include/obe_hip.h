@@ -328,8 +328,16 @@ int obe_timer_create(void** timer);
 int obe_timer_start(void* timer, void* stream);
 int obe_timer_stop(void* timer, void* stream, float* ms);   /* records, syncs, returns elapsed */
 int obe_timer_destroy(void* timer);
+/* Timing of the dominant sweep kernel inside real cycles: while enabled, every obe_sweep_utility
+ * call that returns its result to the host brackets the sweep kernel with two events on its
+ * stream and adds the elapsed time to a running total (the events are read after the stream
+ * synchronisation the result copy performs anyway).  Returns the total and the number of
+ * launches accumulated so far, then: enable > 0 starts a fresh accumulation, enable == 0 stops
+ * it, enable < 0 leaves the state alone (read only).  bench.py: roofline.achieved. */
+int obe_sweep_timing(int32_t enable, double* h_total_ms, int64_t* h_launches);
 /* Launches only the dominant sweep kernel `iters` times between two events on `stream`
- * and returns the average per-launch duration in ms (bench.py roofline.achieved). */
+ * and returns the average per-launch duration in ms; iters < 0: -iters isolated launches
+ * (the stream is drained before each one), as a measurement cycle issues them. */
 int obe_sweep_kernel_time(const obe_model* m,
                           const double* d_settings, int64_t ld_s, int64_t n_settings,
                           const double* d_particles, int64_t ld_p, int64_t n_particles,

@@ -99,6 +99,7 @@ _SIGNATURES = {
     "obe_timer_start": (c_int, [_P, _P]),
     "obe_timer_stop": (c_int, [_P, _P, ctypes.POINTER(ctypes.c_float)]),
     "obe_timer_destroy": (c_int, [_P]),
+    "obe_sweep_timing": (c_int, [c_int32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64)]),
     "obe_sweep_kernel_time": (c_int, [ctypes.POINTER(ObeModelStruct), _P, c_int64, c_int64, _P, c_int64, c_int64,
                                       _P, _P, c_int32, _P, c_int64, c_int32, ctypes.POINTER(ctypes.c_float), _P]),
 }
@@ -107,7 +108,8 @@ _SIGNATURES = {
 # entry points whose code depends on the model: a plugin library serves these
 MODEL_ENTRY_POINTS = ("obe_model_validate", "obe_bayes_update_model", "obe_bayes_update_sweep",
                       "obe_eval_over_particles",
-                      "obe_eval_over_settings", "obe_sweep_utility", "obe_sweep_kernel_time", "obe_eval_draws")
+                      "obe_eval_over_settings", "obe_sweep_utility", "obe_sweep_kernel_time", "obe_sweep_timing",
+                      "obe_eval_draws")
 
 
 class HipLib:

@@ -601,6 +601,17 @@ __global__ __launch_bounds__(kBlock) void yspace_var_kernel(const double* __rest
     }
 }
 
+// Optional timing of the sweep kernel inside real cycles (obe_sweep_timing): events around the
+// launch on its own stream, read after the stream synchronisation the result copy needs anyway.
+struct SweepTiming {
+    bool on = false;
+    int device = -1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    double total_ms = 0.0;
+    int64_t launches = 0;
+};
+static SweepTiming g_timing;
+
 struct SweepWs {
     double* part1;
     double* part2;
@@ -779,9 +790,24 @@ int obe_sweep_utility(const obe_model* m, const double* d_settings, int64_t ld_s
         if (rc) return rc;
         return read_best(w, h_best, h_best_idx, st, h_kappa);
     }
+    const bool timed = g_timing.on && (h_best || h_best_idx || h_kappa);
+    if (timed) {
+        int dev = 0;
+        OBE_HIP_TRY(hipGetDevice(&dev));
+        if (g_timing.device != dev) {
+            if (g_timing.e0) (void)hipEventDestroy(g_timing.e0);
+            if (g_timing.e1) (void)hipEventDestroy(g_timing.e1);
+            OBE_HIP_TRY(hipEventCreate(&g_timing.e0));
+            OBE_HIP_TRY(hipEventCreate(&g_timing.e1));
+            g_timing.device = dev;
+        }
+    }
     int rc = dispatch_model(mm, [&](auto M) -> int {
         if (int e = launch_pack<decltype(M)>(a, st)) return e;
-        return launch_sweep<decltype(M)>(plan, a, shifted, st);
+        if (timed) (void)hipEventRecord(g_timing.e0, st);
+        const int e = launch_sweep<decltype(M)>(plan, a, shifted, st);
+        if (timed) (void)hipEventRecord(g_timing.e1, st);
+        return e;
     });
     if (rc) return rc;
     const int nb = static_cast<int>((n_settings + kFinSettings - 1) / kFinSettings);
@@ -791,7 +817,26 @@ int obe_sweep_utility(const obe_model* m, const double* d_settings, int64_t ld_s
     OBE_CHECK_LAUNCH("sweep_finalize");
     argmax_fold<<<1, kBlock, 0, st>>>(w.bv, w.bi, nb, w.bk, w.out_v, w.out_i);
     OBE_CHECK_LAUNCH("argmax_fold");
-    return read_best(w, h_best, h_best_idx, st, h_kappa);
+    rc = read_best(w, h_best, h_best_idx, st, h_kappa);
+    if (timed && !rc) {                       // the stream is drained: both events have completed
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_timing.e0, g_timing.e1) == hipSuccess) {
+            g_timing.total_ms += ms;
+            g_timing.launches += 1;
+        }
+    }
+    return rc;
+}
+
+int obe_sweep_timing(int32_t enable, double* h_total_ms, int64_t* h_launches) {
+    if (h_total_ms) *h_total_ms = g_timing.total_ms;
+    if (h_launches) *h_launches = g_timing.launches;
+    if (enable >= 0) {
+        g_timing.on = enable != 0;
+        g_timing.total_ms = 0.0;
+        g_timing.launches = 0;
+    }
+    return 0;
 }
 
 int obe_sweep_kernel_time(const obe_model* m, const double* d_settings, int64_t ld_s, int64_t n_settings,

@@ -354,7 +354,10 @@ def test_sweep_shapes_ragged(obe):
     """Setting counts around every tile boundary, particle counts around chunk/tile
     boundaries, draws mode and full mode; against the oracle."""
     g = np.random.default_rng(3)
-    for ns, n in [(1, 1), (1, 300), (63, 64), (257, 1000), (1025, 2049), (4099, 513)]:
+    # (the last five: particle counts around the per-wave quarter of a chunk and the 4-particle
+    # prefetch group of the scalar-path sweep kernel, at 8 / 2 / 1 settings per lane)
+    for ns, n in [(1, 1), (1, 300), (63, 64), (257, 1000), (1025, 2049), (4099, 513),
+                  (4099, 2), (4099, 7), (4100, 21), (520, 4099), (130, 16389)]:
         prior = np.array([g.uniform(2, 4, n), g.uniform(-2000, -400, n), g.normal(50000, 1000, n)])
         sv = (np.linspace(1.5, 4.5, ns),)
         w = g.exponential(1.0, n)
