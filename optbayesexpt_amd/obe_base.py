@@ -413,15 +413,17 @@ class OptBayesExpt(ParticlePDF):
             # consumes N_DRAWS uniforms (randdraw); its check of sum(w) waits for the sweep's own sync
             idx = self._draw_indices(self.N_DRAWS, defer_validation=True)
             n_draws = self.N_DRAWS
-        mom = self._moments_on_device()
         p, w = self._pw_tensors()
-        noise, noise_ld = self._noise_var_device()
         cost_t, cost_s = self._cost_device()
         n_local = self._s_end - self._s_begin
         best = np.zeros(1)
         best_idx = np.zeros(1, dtype=np.int64)
         kappa = np.zeros(1)
         s_ptr = _P(self._settings_dev.data_ptr() + 8 * self._s_begin)
+        # last, so that the moments kernels and the sweep are enqueued back to back (every idle
+        # microsecond before the sweep kernel also costs clock ramp-up inside it)
+        mom = self._moments_on_device()
+        noise, noise_ld = self._noise_var_device()
 
         sharded = self._shard is not None     # every sweep of a sharded object gathers: ranks stay in lockstep
         result = {}

@@ -70,11 +70,16 @@ summary["calibration"] = corr
 sw = [k for k in summary["kernels"] if "sweep_kernel" in k]
 if sw and corr:
     s = summary["kernels"][sw[0]]
-    rd = s["FETCH_SIZE"]["avg_kib"] * 1024 * corr["fetch_factor"]
+    # The sweep kernel reads through the scalar path (s_load_dwordx16): FETCH_SIZE counts those
+    # requests at their true size (tools/microbench_sload: 1.0000 of a known 1 GiB; the same bytes read
+    # with 8-byte-per-lane vector loads report 0.5000, the factor the update kernel calibrates below).
+    rd = s["FETCH_SIZE"]["avg_kib"] * 1024 * 1.0
     wr = s["WRITE_SIZE"]["avg_kib"] * 1024 * corr["write_factor"]
     summary["sweep_kernel_hbm_bytes_per_launch"] = rd + wr
-    summary["sweep_kernel_note"] = ("calibrated FETCH+WRITE per launch; compulsory bytes are "
-                                    f"{8 * (d + 1) * n_p + 16 * n_s} (cloud + settings) plus the chunk partials")
+    summary["sweep_kernel_read_bytes"], summary["sweep_kernel_written_bytes"] = rd, wr
+    summary["sweep_kernel_note"] = ("FETCH (scalar loads, factor 1.0) + calibrated WRITE per launch; compulsory bytes are "
+                                    f"{8 * (d + 1) * n_p + 16 * n_s} (cloud + settings + utility); the reads are the packed "
+                                    "cloud once, the writes are the chunk partials (40 chunks x N_s x 16 B)")
 path = os.path.join(DST, f"{tag}_pmc_hbm_{cfg}.json")
 json.dump(summary, open(path, "w"), indent=1)
 print(json.dumps(summary, indent=1)[:4000])
