@@ -73,6 +73,13 @@ int obe_abi_version(void);
  * loader compares it with the sources next to it and refuses a stale library. */
 const char* obe_source_fingerprint(void);
 const char* obe_last_error(void);
+/* Deferred host results (per calling thread).  While on, the entry points that deliver results
+ * to host memory and would synchronise `stream` for it — obe_moments (h_out), obe_weight_cdf
+ * (h_total), obe_ziggurat_normal (h_consumed[2]) — only enqueue the copy and return; the values
+ * are valid once the caller has synchronised the stream (pass page-locked host memory, or the
+ * copy itself blocks).  resample() uses it to keep the device busy while the host factorises the
+ * covariance.  Returns the previous state. */
+int obe_defer_host_sync(int32_t on);
 /* Name, CU count and memory of the current device; returns 0 if a gfx950 device is current. */
 int obe_device_info(char* name, int name_len, int* n_cu, int64_t* hbm_bytes);
 
@@ -317,11 +324,15 @@ int obe_pcg64_uniform(const uint64_t* d_raw, int64_t n, double* d_out, void* str
 /* n standard normals by numpy's ziggurat from d_raw[offset...]: bit-identical values and
  * the exact number of raw values consumed (*h_consumed; sync), so the host generator can
  * be advanced to where numpy would have left it.  d_tables = ki[256] (uint64) | wi[256] |
- * fi[256] (float64).  Returns 1 if n_raw is too short (retry with a longer buffer). */
+ * fi[256] (float64).  Returns 1 if n_raw is too short (retry with a longer buffer).
+ * With obe_defer_host_sync on: h_consumed[0..1] receive {raw values consumed, normals found}
+ * asynchronously and the return value only reports launch errors; after synchronising, the
+ * caller checks them with obe_ziggurat_check (1 = buffer too short). */
 int64_t obe_ziggurat_workspace_bytes(int64_t n_raw);
 int obe_ziggurat_normal(const uint64_t* d_raw, int64_t n_raw, int64_t offset, const void* d_tables,
                         int64_t n, double* d_out, int64_t* h_consumed,
                         void* d_ws, int64_t ws_bytes, void* stream);
+int obe_ziggurat_check(int64_t consumed, int64_t found, int64_t n, int64_t n_raw, int64_t offset);
 
 /* ---- timing on the launch stream (bench.py roofline leg) ---- */
 int obe_timer_create(void** timer);

@@ -116,5 +116,33 @@ class DeviceStream:
         advance(self.rng, self.st, self.n_uniform + int(consumed[0]))
         return out
 
+    def normals_deferred(self, pinned_i64):
+        """Launch the normals without waiting for the device: returns the (n_normal,) device tensor;
+        ``pinned_i64[0:2]`` receive {raw values consumed, normals found} once the stream has been
+        synchronised, and ``finish_normals()`` then validates them and advances the host generator.
+        (obe_defer_host_sync must be on.)"""
+        out = torch.empty(self.n_normal, dtype=torch.float64, device=self.device)
+        tables = _tables(self.device)
+        n_tail = self.n_raw - self.n_uniform
+        ws_bytes = int(self.lib.cdll.obe_ziggurat_workspace_bytes(n_tail))
+        self._zig_ws = torch.empty(ws_bytes // 8 + 1, dtype=torch.float64, device=self.device)
+        self.lib.call("obe_ziggurat_normal", _P(self.raw.data_ptr() + 8 * self.n_uniform), n_tail, 0,
+                      _P(tables.data_ptr()), self.n_normal, _P(out.data_ptr()), _P(pinned_i64.data_ptr()),
+                      _P(self._zig_ws.data_ptr()), self._zig_ws.numel() * 8, self.stream)
+        return out
+
+    def finish_normals(self, pinned_i64):
+        """After the stream synchronisation that follows ``normals_deferred()``: True and the host
+        generator advanced if the raw buffer was long enough; False if the caller has to draw the
+        normals again with ``normals()`` (which regenerates a longer buffer)."""
+        consumed, found = int(pinned_i64[0]), int(pinned_i64[1])
+        n_tail = self.n_raw - self.n_uniform
+        if self.lib.cdll.obe_ziggurat_check(consumed, found, self.n_normal, n_tail, 0) != 0:
+            self.margin = 2 * self.margin + 65536
+            self._generate()
+            return False
+        advance(self.rng, self.st, self.n_uniform + consumed)
+        return True
+
     def finish_uniform_only(self):
         advance(self.rng, self.st, self.n_uniform)

@@ -49,6 +49,7 @@ _P = c_void_p   # any pointer (device or host) is passed as an integer address
 _SIGNATURES = {
     "obe_abi_version": (c_int, []),
     "obe_last_error": (ctypes.c_char_p, []),
+    "obe_defer_host_sync": (c_int, [c_int32]),
     "obe_source_fingerprint": (ctypes.c_char_p, []),
     "obe_model_validate": (c_int, [ctypes.POINTER(ObeModelStruct)]),
     "obe_device_info": (c_int, [ctypes.c_char_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int64)]),
@@ -95,6 +96,7 @@ _SIGNATURES = {
     "obe_pcg64_uniform": (c_int, [_P, c_int64, _P, _P]),
     "obe_ziggurat_workspace_bytes": (c_int64, [c_int64]),
     "obe_ziggurat_normal": (c_int, [_P, c_int64, c_int64, _P, c_int64, _P, _P, _P, c_int64, _P]),
+    "obe_ziggurat_check": (c_int, [c_int64, c_int64, c_int64, c_int64, c_int64]),
     "obe_timer_create": (c_int, [ctypes.POINTER(c_void_p)]),
     "obe_timer_start": (c_int, [_P, _P]),
     "obe_timer_stop": (c_int, [_P, _P, ctypes.POINTER(ctypes.c_float)]),
@@ -106,7 +108,7 @@ _SIGNATURES = {
 
 
 # entry points whose code depends on the model: a plugin library serves these
-MODEL_ENTRY_POINTS = ("obe_model_validate", "obe_bayes_update_model", "obe_bayes_update_sweep",
+MODEL_ENTRY_POINTS = ("obe_model_validate", "obe_workspace_bytes", "obe_bayes_update_model", "obe_bayes_update_sweep",
                       "obe_eval_over_particles",
                       "obe_eval_over_settings", "obe_sweep_utility", "obe_sweep_kernel_time", "obe_sweep_timing",
                       "obe_eval_draws")

@@ -8,6 +8,9 @@
 namespace obe {
 
 static thread_local std::string g_last_error;
+static thread_local bool g_defer_host_sync = false;
+
+bool defer_host_sync() { return g_defer_host_sync; }
 
 void set_error(const std::string& msg) { g_last_error = msg; }
 
@@ -39,6 +42,12 @@ int obe_abi_version(void) { return OBE_ABI_VERSION; }
 const char* obe_source_fingerprint(void) { return OBE_SOURCE_FINGERPRINT; }
 
 const char* obe_last_error(void) { return g_last_error.c_str(); }
+
+int obe_defer_host_sync(int32_t on) {
+    const int prev = g_defer_host_sync ? 1 : 0;
+    g_defer_host_sync = on != 0;
+    return prev;
+}
 
 int obe_model_validate(obe_model* m) {
     if (!m) return bad_arg("model is NULL");

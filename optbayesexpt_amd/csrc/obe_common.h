@@ -20,6 +20,7 @@ constexpr int kMaxBlocks = 2048;   // 256 CUs x 8: grid cap for streaming kernel
 constexpr double kDblMax = 1.7976931348623157e308;
 
 void set_error(const std::string& msg);
+bool defer_host_sync();    // obe_defer_host_sync: host results are copied asynchronously, the caller synchronises
 int fail(hipError_t e, const char* what);
 int bad_arg(const char* what);
 

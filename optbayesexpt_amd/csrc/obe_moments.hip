@@ -183,7 +183,7 @@ int obe_moments(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t
     if (h_out) {
         const int64_t len = want_cov ? obe_moments_len(n_dims) : 2 + 4 * (int64_t)n_dims;
         OBE_HIP_TRY(hipMemcpyAsync(h_out, d_out, len * sizeof(double), hipMemcpyDeviceToHost, st));
-        OBE_HIP_TRY(hipStreamSynchronize(st));
+        if (!defer_host_sync()) OBE_HIP_TRY(hipStreamSynchronize(st));
     }
     return 0;
 }

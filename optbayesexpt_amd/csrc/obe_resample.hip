@@ -304,7 +304,7 @@ static int scan_common(const char* who, const double* d_x, int64_t n, int32_t st
     }
     if (h_total) {
         OBE_HIP_TRY(hipMemcpyAsync(h_total, scalars, sizeof(double), hipMemcpyDeviceToHost, st));
-        OBE_HIP_TRY(hipStreamSynchronize(st));
+        if (!defer_host_sync()) OBE_HIP_TRY(hipStreamSynchronize(st));
     }
     return 0;
 }

@@ -342,17 +342,28 @@ int obe_ziggurat_normal(const uint64_t* d_raw, int64_t n_raw, int64_t offset, co
     OBE_CHECK_LAUNCH("flag_scan_offsets");
     zig_compact_kernel<<<(unsigned)nb, kBlock, 0, st>>>(flag, sums, val, len, n_raw, offset, n, d_out, result);
     OBE_CHECK_LAUNCH("zig_compact_kernel");
+    if (defer_host_sync()) {       // {consumed, found} -> h_consumed[0..1]; the caller checks them after its sync
+        OBE_HIP_TRY(hipMemcpyAsync(h_consumed, result, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        return 0;
+    }
     int64_t host[2];
     OBE_HIP_TRY(hipMemcpyAsync(host, result, sizeof(host), hipMemcpyDeviceToHost, st));
     OBE_HIP_TRY(hipStreamSynchronize(st));
-    // the n-th normal must exist and end well inside the buffer (positions within
-    // kMaxLen of the end may be unclassifiable and would break the chain)
-    if (host[1] < n || host[0] <= 0 || host[0] > n_raw - offset - 2 * kMaxLen) {
+    if (obe_ziggurat_check(host[0], host[1], n, n_raw, offset)) {
         *h_consumed = -1;
-        set_error("obe_ziggurat_normal: raw buffer too short for the requested normals");
         return 1;      /* OBE_RNG_NEED_MORE */
     }
     *h_consumed = host[0];
+    return 0;
+}
+
+int obe_ziggurat_check(int64_t consumed, int64_t found, int64_t n, int64_t n_raw, int64_t offset) {
+    // the n-th normal must exist and end well inside the buffer (positions within
+    // kMaxLen of the end may be unclassifiable and would break the chain)
+    if (found < n || consumed <= 0 || consumed > n_raw - offset - 2 * kMaxLen) {
+        set_error("obe_ziggurat_normal: raw buffer too short for the requested normals");
+        return 1;
+    }
     return 0;
 }
 

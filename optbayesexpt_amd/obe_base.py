@@ -410,6 +410,8 @@ class OptBayesExpt(ParticlePDF):
         idx = None
         n_draws = 0
         if not full:
+            if self.N_DRAWS > self._ws_draws:       # more draws than particles (N_DRAWS is a public attribute):
+                self._alloc_scratch()               # the packed draws of the sweep need the room
             # consumes N_DRAWS uniforms (randdraw); its check of sum(w) waits for the sweep's own sync
             idx = self._draw_indices(self.N_DRAWS, defer_validation=True)
             n_draws = self.N_DRAWS

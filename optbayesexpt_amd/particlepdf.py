@@ -95,10 +95,14 @@ class ParticlePDF:
     def _alloc_scratch(self):
         n, d = self.n_particles, self.n_dims
         n_settings, n_channels = self._scratch_dims()
-        nbytes = self._lib.workspace_bytes(n, n_settings, n_channels, d)
+        # the sweep packs its draws into the workspace: all particles, or N_DRAWS of them
+        self._ws_draws = max(n, int(getattr(self, "N_DRAWS", 0) or 0))
+        libs = {id(x): x for x in (self._lib, getattr(self, "_mlib", self._lib))}.values()   # a plugin knows its
+        sizes = [(n, n_settings), (self._ws_draws, n_settings)]                                # model's packed width
         n_local = getattr(self, "_s_end", n_settings) - getattr(self, "_s_begin", 0)
         if 0 < n_local < n_settings:       # a settings shard plans its sweep for its own slice
-            nbytes = max(nbytes, self._lib.workspace_bytes(n, n_local, n_channels, d))
+            sizes += [(n, n_local), (self._ws_draws, n_local)]
+        nbytes = max(lib.workspace_bytes(a, b, n_channels, d) for lib in libs for a, b in sizes)
         self._ws = torch.empty(nbytes // 8 + 1, dtype=torch.float64, device=self._device)
         self._ws_bytes = self._ws.numel() * 8
         self._moments_dev = torch.zeros(self._lib.moments_len(d), dtype=torch.float64, device=self._device)
@@ -108,6 +112,9 @@ class ParticlePDF:
         self._cdf_dev = torch.empty(n, dtype=torch.float64, device=self._device)
         self._cdf_key = None           # (weights version, strict)
         self._total_pinned = torch.zeros(8, dtype=torch.float64).pin_memory()   # async sum(w) of a small draw
+        # page-locked landing zones of the pipelined resample: [0] sum(w), [1:] the moments block; {consumed, found}
+        self._pinned_f64 = torch.zeros(self._lib.moments_len(d) + 8, dtype=torch.float64).pin_memory()
+        self._pinned_i64 = torch.zeros(8, dtype=torch.int64).pin_memory()
         self._pending_total = None     # (generator state before the draw,) while that sum is unchecked
         self._sumsq_key = None         # weights version for which _sumsq is valid
         self._sumsq = None
@@ -373,6 +380,8 @@ class ParticlePDF:
         method = self.tuning_parameters.get("resample_method", "multinomial")
         if method == "multinomial":                       # the reference: N i.i.d. uniforms
             rstream = self._device_stream(n, n * d)       # exact continuation of self.rng, or None
+            if rstream is not None and self.tuning_parameters.get("pipelined_resample", True):
+                return self._resample_pipelined(rstream)
             idx = self._draw_indices(n, rstream)
         elif method == "systematic":                      # extension: ONE uniform, draws at (i + u0)/N
             cdf = self._cdf()
@@ -383,28 +392,89 @@ class ParticlePDF:
         else:
             raise ValueError(f"unknown resample_method {method!r} (multinomial or systematic)")
         m = self._moments(True)                       # pre-resample weights (:290-291)
-        mean = m[2:2 + d].copy()
-        cov = m[2 + 4 * d:2 + 4 * d + d * d].reshape((d, d))
-        a = self.tuning_parameters["a_param"]
-        newcov = (1 - a ** 2) * cov
-        # Generator.multivariate_normal(method='svd'): x = z @ (u * sqrt(s)).T
-        u, s, vh = np.linalg.svd(newcov)
-        if not np.allclose(np.dot(vh.T * s, vh), newcov, rtol=1e-8, atol=1e-8):
-            warnings.warn("covariance is not symmetric positive-semidefinite.", RuntimeWarning)
-        factor = np.ascontiguousarray(u * np.sqrt(s))
+        factor, mean = self._nudge_factor(m)
         if rstream is not None:
             z_dev = rstream.normals()                 # (n*d,) row-major (n, d); advances self.rng
         else:
             z_dev = torch.from_numpy(self.rng.standard_normal((n, d))).to(self._device)
+        self._resample_apply(idx, z_dev, factor, mean)
+
+    def _nudge_factor(self, m):
+        """(F, mean) for the nudge of resample(): Generator.multivariate_normal(method='svd') draws
+        x = z @ (u * sqrt(s)).T from the SVD of (1 - a^2) cov."""
+        d = self.n_dims
+        mean = m[2:2 + d].copy()
+        cov = m[2 + 4 * d:2 + 4 * d + d * d].reshape((d, d))
+        a = self.tuning_parameters["a_param"]
+        newcov = (1 - a ** 2) * cov
+        u, s, vh = np.linalg.svd(newcov)
+        if not np.allclose(np.dot(vh.T * s, vh), newcov, rtol=1e-8, atol=1e-8):
+            warnings.warn("covariance is not symmetric positive-semidefinite.", RuntimeWarning)
+        return np.ascontiguousarray(u * np.sqrt(s)), mean
+
+    def _resample_apply(self, idx, z_dev, factor, mean):
+        n, d = self.n_particles, self.n_dims
         old = self._particles.tensor()
         new = torch.empty((d, n), dtype=torch.float64, device=self._device)
         w = self._weights.tensor()
         self._lib.call("obe_resample_particles", _ptr(old), old.shape[1], d, n, _ptr(idx), _ptr(z_dev),
-                       _lib.host_ptr(factor), _lib.host_ptr(mean), float(a),
+                       _lib.host_ptr(factor), _lib.host_ptr(mean), float(self.tuning_parameters["a_param"]),
                        1 if self.tuning_parameters["scale"] else 0, _ptr(new), n, _ptr(w), self._stream())
         self._particles = Mirror(self._device, tensor=new)
         self._weights.mark_device_written()
         self.last_resample_indices_device = idx
+
+    def _resample_pipelined(self, rstream):
+        """resample() with the device generator, enqueued so that the device never waits for the
+        host: CDF, uniforms, search, covariance and the ziggurat normals are launched back to back
+        with their host results (sum(w), moments, raw values consumed) copied asynchronously into
+        page-locked memory; the host waits once for the covariance, factorises it while the normals
+        are still being generated, launches the gather + nudge and only then synchronises for the
+        generator bookkeeping.  Same kernels, same numbers and the same generator state as the
+        step-by-step path."""
+        n, d = self.n_particles, self.n_dims
+        if self._weights.shape[0] != n:
+            raise ValueError("a and p must have same size")
+        strict = bool(self.tuning_parameters.get("strict_cdf", False))
+        key = (self._weights.version, strict)
+        p, w = self._pw_tensors()
+        if self._cdf_dev.numel() != n:
+            self._cdf_dev = torch.empty(n, dtype=torch.float64, device=self._device)
+        pin_f, pin_i = self._pinned_f64, self._pinned_i64
+        mlen = self._lib.moments_len(d)
+        stream = torch.cuda.current_stream(self._device)
+        idx = torch.empty(n, dtype=torch.int64, device=self._device)
+        prev = self._lib.cdll.obe_defer_host_sync(1)
+        try:
+            if self._cdf_key != key:
+                self._lib.call("obe_weight_cdf", _ptr(w), n, 1 if strict else 0, _ptr(self._cdf_dev),
+                               _P(pin_f.data_ptr()), _ptr(self._ws), self._ws_bytes, self._stream())
+            else:
+                pin_f[0] = 1.0
+            u_dev = rstream.uniforms()
+            self._lib.call("obe_cdf_search", _ptr(self._cdf_dev), n, _ptr(u_dev), n, _ptr(idx), self._stream())
+            self._lib.call("obe_moments", _ptr(p), p.shape[1], d, n, _ptr(w), 1, _ptr(self._moments_dev),
+                           _P(pin_f.data_ptr() + 8), _ptr(self._ws), self._ws_bytes, self._stream())
+            have_cov = torch.cuda.Event()
+            have_cov.record(stream)
+            z_dev = rstream.normals_deferred(pin_i)
+        finally:
+            self._lib.cdll.obe_defer_host_sync(prev)
+        have_cov.synchronize()                        # the normals are still being generated
+        self._validate_total(float(pin_f[0]))         # (raises before any generator state has moved)
+        self._cdf_key = key
+        self._moments_host[:mlen] = pin_f[1:1 + mlen].numpy()
+        mkey = (self._particles.version, self._weights.version)
+        self._mom_host_key = self._mom_dev_key = mkey + (True,)
+        factor, mean = self._nudge_factor(self._moments_host)
+        self.last_draw_indices_device = idx
+        before = self._particles
+        self._resample_apply(idx, z_dev, factor, mean)
+        stream.synchronize()
+        if not rstream.finish_normals(pin_i):         # unlucky stream: the raw buffer was too short
+            z_dev = rstream.normals()
+            self._particles = before
+            self._resample_apply(idx, z_dev, factor, mean)
 
     @staticmethod
     def _normalized_product(weight_array, likelihood_array):
