@@ -339,6 +339,29 @@ def main():
         if rnd >= 2:
             round_us.append(upd_ms.value * 1e3 / reps)
         wcopy.copy_(w)                            # every round starts from the same weights
+    # the same call on a cloud 16 x larger (the rows tiled): at 1 M particles the three launches are bound by
+    # launch latency and the A -> B dependency; this is what the kernels stream when the cloud is large
+    big = None
+    if world == 1:
+        rep16 = 16
+        p16 = p.repeat(1, rep16).contiguous()
+        w16 = (w / rep16).repeat(rep16).contiguous()
+        w16c = w16.clone()
+        big_us = []
+        for rnd in range(2 + 5):
+            lib.call("obe_timer_start", timer, stream)
+            for _ in range(10):
+                obe._mlib.call("obe_bayes_update_model", obe._model_struct, _ptr(p16), p16.shape[1], p16.shape[1],
+                         _ptr(w16c), _lib.host_ptr(st_arr), _lib.host_ptr(yy),
+                         _lib.host_ptr(ss) if rows is None else None,
+                         None if rows is None else _lib.host_ptr(rows), 1, float("nan"), _ptr(obe._ws),
+                         obe._ws_bytes, None, stream)
+            lib.call("obe_timer_stop", timer, stream, ctypes.byref(upd_ms))
+            if rnd >= 2:
+                big_us.append(upd_ms.value * 1e3 / 10)
+            w16c.copy_(w16)
+        big = (p16.shape[1], float(np.median(big_us)))
+        del p16, w16, w16c
     lib.call("obe_timer_destroy", timer)
     n_read = obe._device_model.n_read + (0 if noise_rec else 1)
     k2_bytes = 8 * (n_read + 1) * n_p + 8 * n_p + 16 * n_p
@@ -349,6 +372,13 @@ def main():
                        "call_us": k2_s * 1e6, "call_us_min_max": [min(round_us), max(round_us)],
                        "timing": f"median of {rounds} rounds of {reps} back-to-back calls, HIP events on the launch stream",
                        "traffic": None}
+    if big is not None:
+        b_bytes = k2_bytes // n_p * big[0]
+        roofline_update["large_cloud"] = {"n_particles": big[0], "bytes": b_bytes, "call_us": big[1],
+                                          "achieved": b_bytes / (big[1] * 1e-6) / 1e9, "unit": "GB/s",
+                                          "frac": b_bytes / (big[1] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                          "note": "same three launches on the cloud tiled 16 x: bandwidth-bound "
+                                                  "instead of launch-bound"}
 
     out = {"metric": "model-evals/sec (settings x particles) per opt_setting+update cycle, fp64",
            "value": value, "unit": "model-evals/s", "n_gpus": world, "steps": args.steps,

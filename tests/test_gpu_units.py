@@ -526,6 +526,65 @@ def test_device_rng_is_bitwise_numpy(obe, hip, seed, n_uniform, n_normal):
     assert_array_equal(rng.random(5), ref.random(5))           # and the streams stay in step
 
 
+@pytest.mark.parametrize("d,scale", [(3, False), (10, True)])
+def test_pipelined_resample_is_the_step_by_step_resample(obe, d, scale):
+    """resample() enqueued without host waits (asynchronous host results, one wait for the
+    covariance, SVD under the ziggurat kernels) against the same resample issued call by call:
+    same indices, same particles, same generator state; and numpy's validation of p still raises
+    before the generator has moved."""
+    g = np.random.default_rng(77 + d)
+    n = 70001
+    prior = g.normal(0.0, 1.0, (d, n)) * np.arange(1, d + 1)[:, None]
+    w = g.exponential(1.0, n) ** 3
+    w /= w.sum()
+    out = {}
+    for piped in (True, False):
+        pdf = obe.ParticlePDF(prior.copy(), scale=scale)
+        pdf.tuning_parameters["pipelined_resample"] = piped
+        pdf.particle_weights = w.copy()
+        pdf.rng = np.random.default_rng(99)
+        pdf.resample()
+        out[piped] = (pdf.last_resample_indices_device.cpu().numpy(), np.array(pdf.particles),
+                      np.array(pdf.particle_weights), pdf.rng.bit_generator.state, pdf.mean(), pdf.covariance())
+    for a, b in zip(out[True], out[False]):
+        if isinstance(a, dict):
+            assert a == b
+        else:
+            assert_array_equal(a, b)
+    ref = np.random.default_rng(99)
+    assert_array_equal(out[True][0], oracle.choice_indices(w, ref.random(n)))
+    # invalid probabilities: ValueError, generator untouched (numpy validates before drawing)
+    pdf = obe.ParticlePDF(prior.copy(), scale=scale)
+    pdf.particle_weights = w * 1.01
+    pdf.rng = np.random.default_rng(5)
+    before = pdf.rng.bit_generator.state
+    with pytest.raises(ValueError):
+        pdf.resample()
+    assert pdf.rng.bit_generator.state == before
+
+
+def test_sweep_timing_counts_the_launches_of_real_cycles(obe):
+    """obe_sweep_timing (bench.py's roofline leg): events around every sweep-kernel launch that
+    returns its result to the host."""
+    import ctypes
+    g = np.random.default_rng(3)
+    n, ns = 40000, 4200
+    prior = np.array([g.uniform(2, 4, n), g.uniform(-2000, -400, n), g.normal(50000, 1000, n)])
+    o = obe.OptBayesExpt(obe.models.lorentzian(), (np.linspace(1.5, 4.5, ns),), prior, (0.1,),
+                         utility_method="variance_full", default_noise_std=500.0, auto_resample=False)
+    o.tuning_parameters["sweep_shift"] = "always"
+    tot, cnt = ctypes.c_double(-1.0), ctypes.c_int64(-1)
+    o._mlib.call("obe_sweep_timing", 1, None, None)
+    for _ in range(3):
+        o.opt_setting()
+        o.pdf_update(((3.0,), 49000.0, 500.0))
+    o._mlib.call("obe_sweep_timing", 0, ctypes.byref(tot), ctypes.byref(cnt))
+    assert cnt.value == 3 and 0.0 < tot.value < 100.0
+    o.opt_setting()
+    o._mlib.call("obe_sweep_timing", -1, ctypes.byref(tot), ctypes.byref(cnt))
+    assert cnt.value == 0 and tot.value == 0.0          # stopped: nothing accumulates
+
+
 def test_device_rng_is_used_and_can_be_disabled(obe, unit):
     """Same resample through the device stream and through host calls on self.rng."""
     out = {}
