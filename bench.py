@@ -292,6 +292,9 @@ def main():
         except Exception:
             traffic = None
     roofline = {"kernel": "sweep_kernel (K1)", "bound": "fp64_valu",
+                "bound_note": "FP64 vector ALU roof: the sweep has no contraction over a shared operand, so nothing "
+                              "goes on MFMA, and it moves ~1e-4 bytes per flop, so HBM is not the limit either; "
+                              "78.6 TFLOP/s is also gfx950's dense FP64 MFMA peak",
                 "achieved": flop / k1_s / 1e12, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": flop / k1_s / 1e12 / FP64_VALU_PEAK_TFLOPS,
                 "flop_per_eval": FLOP_PER_EVAL[model], "evals_per_launch": n_local * n_p,
