@@ -86,18 +86,28 @@ __global__ __launch_bounds__(kBlock) void moments_pass2(const double* __restrict
     store_block_partials<NV>(v, partials);
 }
 
-// One wavefront per value: raw[k] = sum_b partials[b*nv + k], fixed order.
-__global__ __launch_bounds__(kWave) void fold_values(const double* __restrict__ partials, int nb, int nv,
-                                                     double* __restrict__ raw) {
-    const int k = blockIdx.x;
-    double s = 0.0;
-    for (int b = threadIdx.x; b < nb; b += kWave) s += partials[(int64_t)b * nv + k];
-    s = wave_sum(s);
-    if (threadIdx.x == 0) raw[k] = s;
+// raw[k] = sum_b partials[b*nv + k]: one wavefront per value (strided partial sums, then the
+// shuffle tree: a fixed order), the four waves of the block taking the values in turn; `vals` in LDS.
+__device__ __forceinline__ void fold_values_block(const double* __restrict__ partials, int nb, int nv,
+                                                  double* __restrict__ vals) {
+    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+    for (int k = wid; k < nv; k += kBlock / kWave) {
+        double s = 0.0;
+        for (int b = lane; b < nb; b += kWave) s += partials[(int64_t)b * nv + k];
+        s = wave_sum(s);
+        if (lane == 0) vals[k] = s;
+    }
+    __syncthreads();
 }
 
+constexpr int kMaxMomentValues = OBE_MAX_DIMS * (OBE_MAX_DIMS + 1) / 2;     // >= 2 + 2 D
+
+// fold + derive in one single-workgroup launch
 // out: [0]=W [1]=W2 [2..) mean [2+D..) m1 [2+2D..) m2 [2+3D..) std
-__global__ void derive_pass1(const double* __restrict__ raw, int d, double* __restrict__ out) {
+__global__ __launch_bounds__(kBlock) void fold_derive_pass1(const double* __restrict__ partials, int nb, int d,
+                                                            double* __restrict__ out) {
+    __shared__ double raw[kMaxMomentValues];
+    fold_values_block(partials, nb, 2 + 2 * d, raw);
     const int i = threadIdx.x;
     if (i == 0) {
         out[0] = raw[0];
@@ -113,18 +123,22 @@ __global__ void derive_pass1(const double* __restrict__ raw, int d, double* __re
 }
 
 // cov = S * (1 / (W - W2/W))  (np.cov scales by the reciprocal)
-__global__ void derive_pass2(const double* __restrict__ raw, int d, double* __restrict__ out) {
+__global__ __launch_bounds__(kBlock) void fold_derive_pass2(const double* __restrict__ partials, int nb, int d,
+                                                            double* __restrict__ out) {
+    __shared__ double raw[kMaxMomentValues];
+    fold_values_block(partials, nb, d * (d + 1) / 2, raw);
     const double fact = out[0] - out[1] / out[0];
     const double scale = 1.0 / fact;
     double* cov = out + 2 + 4 * d;
-    int k = 0;
-    if (threadIdx.x == 0) {
-        for (int i = 0; i < d; ++i)
-            for (int j = i; j < d; ++j) {
-                const double c = raw[k++] * scale;
-                cov[i * d + j] = c;
-                cov[j * d + i] = c;
-            }
+    for (int e = threadIdx.x; e < d * d; e += kBlock) {
+        int i = e / d, j = e % d;
+        if (i > j) {
+            const int t = i;
+            i = j;
+            j = t;
+        }
+        const int k = i * d - i * (i - 1) / 2 + (j - i);     // index of (i, j), i <= j, in the packed upper triangle
+        cov[e] = raw[k] * scale;
     }
 }
 
@@ -135,18 +149,13 @@ static int launch_moments(const double* x, int64_t ld, int64_t n, const double* 
     constexpr int NV1 = 2 + 2 * D;
     moments_pass1<D><<<nb, kBlock, 0, st>>>(x, ld, n, w, partials);
     OBE_CHECK_LAUNCH("moments_pass1");
-    fold_values<<<NV1, kWave, 0, st>>>(partials, nb, NV1, raw);
-    OBE_CHECK_LAUNCH("fold_values");
-    derive_pass1<<<1, kWave, 0, st>>>(raw, D, out);
-    OBE_CHECK_LAUNCH("derive_pass1");
+    fold_derive_pass1<<<1, kBlock, 0, st>>>(partials, nb, D, out);
+    OBE_CHECK_LAUNCH("fold_derive_pass1");
     if (want_cov) {
-        constexpr int NV2 = D * (D + 1) / 2;
         moments_pass2<D><<<nb, kBlock, 0, st>>>(x, ld, n, w, out, partials);
         OBE_CHECK_LAUNCH("moments_pass2");
-        fold_values<<<NV2, kWave, 0, st>>>(partials, nb, NV2, raw);
-        OBE_CHECK_LAUNCH("fold_values");
-        derive_pass2<<<1, kWave, 0, st>>>(raw, D, out);
-        OBE_CHECK_LAUNCH("derive_pass2");
+        fold_derive_pass2<<<1, kBlock, 0, st>>>(partials, nb, D, out);
+        OBE_CHECK_LAUNCH("fold_derive_pass2");
     }
     return 0;
 }
