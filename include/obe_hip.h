@@ -83,7 +83,9 @@ int obe_defer_host_sync(int32_t on);
 /* Name, CU count and memory of the current device; returns 0 if a gfx950 device is current. */
 int obe_device_info(char* name, int name_len, int* n_cu, int64_t* hbm_bytes);
 
-/* Scratch (device) bytes any call below may need for these sizes. */
+/* Scratch (device) bytes any call below may need for these sizes.  The sweep keeps its draws,
+ * packed once per call, in the workspace: pass n_particles >= the number of draws of any sweep
+ * (N_DRAWS may exceed the particle count).  A plugin library answers for its own model. */
 int64_t obe_workspace_bytes(int64_t n_particles, int64_t n_settings, int32_t n_channels, int32_t n_dims);
 
 /* ---- K2: Bayes update  (obe_base.py:385-394 eval_over_all_parameters + likelihood +
