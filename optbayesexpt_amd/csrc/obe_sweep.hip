@@ -155,8 +155,13 @@ __device__ __forceinline__ int64_t wave_uniform(int64_t v) {
 
 // SAFE (models with kHasSafeEval only): evaluate with the model's sweep_eval_safe() — the repeat
 // after a sweep whose fast, branch-free batch inversions poisoned a variance (kappa = NaN).
+#ifdef OBE_SWEEP_WAVES_PER_EU          // tuning aid (tools/build_variant.py): force an occupancy
+#define OBE_SWEEP_OCCUPANCY __attribute__((amdgpu_waves_per_eu(OBE_SWEEP_WAVES_PER_EU, OBE_SWEEP_WAVES_PER_EU)))
+#else
+#define OBE_SWEEP_OCCUPANCY
+#endif
 template <class M, int SPT, bool SHIFT, bool SAFE = false>
-__global__ __launch_bounds__(kBlock) void sweep_kernel(SweepArgs a) {
+__global__ __launch_bounds__(kBlock) OBE_SWEEP_OCCUPANCY void sweep_kernel(SweepArgs a) {
     constexpr int NC = M::NC, NXS = M::NXS, NPK = M::NPK, NPKW = packed_width<M>();
     constexpr bool PAIRS = has_pair_eval<M>::value && SPT >= 2 && !SAFE;
     // particles per prefetched group: two groups of packed particles live in SGPRs (~100 per wave)

@@ -11,6 +11,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, os.environ["OBE_AB_ROOT"]) if os.environ.get("OBE_AB_ROOT") else ROOT)   # A/B: another checkout
 import torch
 import bench
+if os.environ.get("OBE_VARIANT"):      # a library built by tools/build_variant.py instead of the product one
+    from optbayesexpt_amd import _lib as _l
+    _l._LIB = _l.HipLib(os.path.join(ROOT, "tools", "_variants", f"libobe_hip_{os.environ['OBE_VARIANT']}.so"))
 from optbayesexpt_amd.particlepdf import _ptr
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
@@ -36,7 +39,7 @@ def k1(n, shifted=0):
     return ms.value
 
 
-tag = f"{os.environ.get('OBE_AB_ROOT', 'tree')} {cfg} blocks={os.environ.get('OBE_SWEEP_BLOCKS', 'default')} spt={os.environ.get('OBE_SWEEP_SPT', 'default')} " \
+tag = f"{os.environ.get('OBE_AB_ROOT', os.environ.get('OBE_VARIANT', 'tree'))} {cfg} blocks={os.environ.get('OBE_SWEEP_BLOCKS', 'default')} spt={os.environ.get('OBE_SWEEP_SPT', 'default')} " \
       f"gap_us={os.environ.get('OBE_TIME_GAP_US', '0')}"
 b2b = [k1(iters) for _ in range(3)]
 iso = [k1(-iters) for _ in range(3)] if not os.environ.get("OBE_AB_ROOT") else [float("nan")]
