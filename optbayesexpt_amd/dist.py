@@ -84,9 +84,18 @@ class SettingsShard:
         if w == 1:
             return record.cpu().reshape(1, 4)
         dev = self._comm_device(record.device)        # nccl: stay on the GPU; gloo: host tensors
-        gathered = torch.empty(4 * w, dtype=torch.float64, device=dev)
+        bufs = self.__dict__.setdefault("_record_bufs", {})
+        if dev not in bufs:                           # receive buffer + page-locked landing zone, made once
+            host = torch.empty(4 * w, dtype=torch.float64)
+            bufs[dev] = (torch.empty(4 * w, dtype=torch.float64, device=dev),
+                         host.pin_memory() if dev.type == "cuda" else host)
+        gathered, host = bufs[dev]
         dist.all_gather_into_tensor(gathered, record.contiguous().to(dev), group=self.group)
-        return gathered.cpu().reshape(w, 4)
+        if dev.type != "cuda":
+            return gathered.clone().reshape(w, 4)
+        host.copy_(gathered, non_blocking=True)       # one asynchronous copy, one wait
+        torch.cuda.current_stream(dev).synchronize()
+        return host.clone().reshape(w, 4)
 
     def broadcast_from_rank0(self, values, device="cpu"):
         """Rank 0's host array on every rank (same shape and dtype everywhere): used for random

@@ -244,9 +244,9 @@ class ParticlePDF:
 
     def resample_test(self):
         """Resample if the effective particle number is low (particlepdf.py:236-258)."""
-        with np.errstate(divide="ignore"):
-            n_eff = np.float64(1.0) / np.float64(self._sum_w2())
-        self.last_n_eff = float(n_eff)
+        s2 = float(self._sum_w2())
+        n_eff = 1.0 / s2 if s2 != 0.0 else float("inf")        # np.float64(1) / np.float64(0) = inf
+        self.last_n_eff = n_eff
         if n_eff < 0.1 * self.n_particles:
             warnings.warn("\nParticle filter rejected > 90 % of particles. "
                           f"N_eff = {n_eff:.2f}. "

@@ -29,17 +29,18 @@ for cyc in range(3):
 mom = obe._moments_on_device()
 p, w = obe._pw_tensors()
 ns = obe.allsettings.shape[1]
+n_local = int(os.environ.get("OBE_NS_LOCAL", ns))       # a settings shard: the first n_local settings
 s_ptr = ctypes.c_void_p(obe._settings_dev.data_ptr())
 
 
 def k1(n, shifted=0):
     ms = ctypes.c_float(0.0)
-    obe._mlib.call("obe_sweep_kernel_time", obe._model_struct, s_ptr, ns, ns, _ptr(p), p.shape[1], p.shape[1],
+    obe._mlib.call("obe_sweep_kernel_time", obe._model_struct, s_ptr, ns, n_local, _ptr(p), p.shape[1], p.shape[1],
                    _ptr(w), _ptr(mom), shifted, _ptr(obe._ws), obe._ws_bytes, n, ctypes.byref(ms), obe._stream())
     return ms.value
 
 
-tag = f"{os.environ.get('OBE_AB_ROOT', os.environ.get('OBE_VARIANT', 'tree'))} {cfg} blocks={os.environ.get('OBE_SWEEP_BLOCKS', 'default')} spt={os.environ.get('OBE_SWEEP_SPT', 'default')} " \
+tag = f"{os.environ.get('OBE_AB_ROOT', os.environ.get('OBE_VARIANT', 'tree'))} {cfg} ns_local={n_local} blocks={os.environ.get('OBE_SWEEP_BLOCKS', 'default')} spt={os.environ.get('OBE_SWEEP_SPT', 'default')} " \
       f"gap_us={os.environ.get('OBE_TIME_GAP_US', '0')}"
 b2b = [k1(iters) for _ in range(3)]
 iso = [k1(-iters) for _ in range(3)] if not os.environ.get("OBE_AB_ROOT") else [float("nan")]
