@@ -239,12 +239,21 @@ __global__ __launch_bounds__(kBlock) void resample_kernel(NudgeArgs na, const do
                                                           int64_t n, const int64_t* __restrict__ idx,
                                                           const double* __restrict__ z, double* __restrict__ out,
                                                           int64_t ld_new, double* __restrict__ weights) {
-    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (int64_t)gridDim.x * kBlock) {
+    // the (N, D) row-major normals of a workgroup's 256 particles are one contiguous run: read it
+    // lane-contiguously into LDS (a thread reading its own row makes every load touch 64 lines)
+    __shared__ double zs[kBlock * D];
+    for (int64_t p0 = (int64_t)blockIdx.x * kBlock; p0 < n; p0 += (int64_t)gridDim.x * kBlock) {
+        const int64_t p = p0 + threadIdx.x;
+        const int64_t run = (n - p0 < kBlock ? n - p0 : kBlock) * D;
+        __syncthreads();       // the previous trip's rows have been consumed
+        for (int64_t e = threadIdx.x; e < run; e += kBlock) zs[e] = z[p0 * D + e];
+        __syncthreads();
+        if (p >= n) continue;
         int64_t src = idx[p];
         src = src < 0 ? 0 : (src >= n ? n - 1 : src);
         double zr[D], x0[D];
 #pragma unroll
-        for (int j = 0; j < D; ++j) zr[j] = z[p * D + j];
+        for (int j = 0; j < D; ++j) zr[j] = zs[threadIdx.x * D + j];
 #pragma unroll
         for (int i = 0; i < D; ++i) x0[i] = old[(int64_t)i * ld_old + src];      // D independent gathers in flight
 #pragma unroll

@@ -167,7 +167,8 @@ constexpr int kStartTile = kBlock * kStartItems;
 constexpr int kHalo = 2 * kMaxLen;        // room to step back over a few non-anchors
 
 __global__ __launch_bounds__(kBlock) void zig_starts_kernel(const uint8_t* __restrict__ len, int64_t n_raw,
-                                                            int64_t first, uint32_t* __restrict__ flag) {
+                                                            int64_t first, uint8_t* __restrict__ flag,
+                                                            uint32_t* __restrict__ sums) {
     __shared__ uint8_t sl[kStartTile + kHalo];
     const int64_t tile0 = (int64_t)blockIdx.x * kStartTile;
     for (int k = threadIdx.x; k < kStartTile + kHalo; k += kBlock) {
@@ -202,10 +203,26 @@ __global__ __launch_bounds__(kBlock) void zig_starts_kernel(const uint8_t* __res
         if (l == 0) break;                 // unclassifiable (only within kMaxLen of the buffer end)
         p += l;
     }
+    // one byte per position: a thread's 8 flags are one 8-byte store (lane-contiguous), and the
+    // number of starts in the tile goes to sums[] (the block sums of the scan that follows)
+    uint64_t packed = 0;
+    uint32_t mine = 0;
 #pragma unroll
     for (int k = 0; k < kStartItems; ++k) {
         const int64_t i = i0 + k;
-        if (i < n_raw) flag[i] = (i >= first) ? out[k] : 0u;
+        const uint32_t f = (i < n_raw && i >= first) ? out[k] : 0u;
+        packed |= (uint64_t)f << (8 * k);
+        mine += f;
+    }
+    if (i0 < n_raw) *reinterpret_cast<uint64_t*>(flag + i0) = packed;     // flag[] is padded to a multiple of 8
+    __shared__ uint32_t wsum[kBlock / kWave];
+    for (int o = kWave / 2; o > 0; o >>= 1) mine += __shfl_down(mine, o, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) wsum[threadIdx.x / kWave] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < kBlock / kWave; ++w) t += wsum[w];
+        sums[blockIdx.x] = t;
     }
 }
 
@@ -238,17 +255,6 @@ __device__ __forceinline__ uint32_t flag_tile_scan(uint32_t (&v)[kFlagItems], ui
     return total;
 }
 
-__global__ __launch_bounds__(kBlock) void flag_block_sums(const uint32_t* __restrict__ flag, int64_t n,
-                                                          uint32_t* __restrict__ sums) {
-    __shared__ uint32_t lds[kBlock / kWave];
-    uint32_t v[kFlagItems];
-    const int64_t i0 = (int64_t)blockIdx.x * kFlagTile + (int64_t)threadIdx.x * kFlagItems;
-#pragma unroll
-    for (int k = 0; k < kFlagItems; ++k) v[k] = (i0 + k < n) ? flag[i0 + k] : 0u;
-    const uint32_t total = flag_tile_scan(v, lds);
-    if (threadIdx.x == 0) sums[blockIdx.x] = total;
-}
-
 __global__ __launch_bounds__(kBlock) void flag_scan_offsets(uint32_t* __restrict__ sums, int64_t nb) {
     __shared__ uint32_t lds[kBlock + 1];
     block_exclusive_scan_inplace<uint32_t>(sums, nb, lds);
@@ -256,27 +262,47 @@ __global__ __launch_bounds__(kBlock) void flag_scan_offsets(uint32_t* __restrict
 
 // out[rank] = val[i] for the first n starts; result[0] = raw consumed by them (relative to `first`),
 // result[1] = number of starts found.
-__global__ __launch_bounds__(kBlock) void zig_compact_kernel(const uint32_t* __restrict__ flag,
+// The tile of candidate values is staged through LDS: a thread needs the flags of 8 CONSECUTIVE
+// positions for the scan, but reading val[] and writing out[] that way makes every load / store
+// instruction of a wave touch 64 different cache lines; instead the tile is read with lane-contiguous
+// loads, compacted inside LDS (98.8 % of the positions are starts) and written out lane-contiguously.
+__global__ __launch_bounds__(kBlock) void zig_compact_kernel(const uint8_t* __restrict__ flag,
                                                              const uint32_t* __restrict__ block_off,
                                                              const double* __restrict__ val,
                                                              const uint8_t* __restrict__ len, int64_t n_raw,
                                                              int64_t first, int64_t n, double* __restrict__ out,
                                                              int64_t* __restrict__ result) {
     __shared__ uint32_t lds[kBlock / kWave];
-    uint32_t v[kFlagItems], f[kFlagItems];
-    const int64_t i0 = (int64_t)blockIdx.x * kFlagTile + (int64_t)threadIdx.x * kFlagItems;
+    __shared__ double sval[kFlagTile];
+    __shared__ double sout[kFlagTile];
+    const int64_t tile0 = (int64_t)blockIdx.x * kFlagTile;
 #pragma unroll
-    for (int k = 0; k < kFlagItems; ++k) f[k] = v[k] = (i0 + k < n_raw) ? flag[i0 + k] : 0u;
-    const uint32_t total = flag_tile_scan(v, lds);
+    for (int j = 0; j < kFlagItems; ++j) {
+        const int64_t i = tile0 + threadIdx.x + j * kBlock;
+        sval[threadIdx.x + j * kBlock] = i < n_raw ? val[i] : 0.0;
+    }
+    uint32_t v[kFlagItems], f[kFlagItems];
+    const int64_t i0 = tile0 + (int64_t)threadIdx.x * kFlagItems;
+    const uint64_t packed = i0 < n_raw ? *reinterpret_cast<const uint64_t*>(flag + i0) : 0ull;   // 8 byte flags
+#pragma unroll
+    for (int k = 0; k < kFlagItems; ++k) f[k] = v[k] = (uint32_t)((packed >> (8 * k)) & 1u);
+    const uint32_t total = flag_tile_scan(v, lds);       // (contains the barriers that publish sval)
     const uint32_t off = block_off[blockIdx.x];
 #pragma unroll
     for (int k = 0; k < kFlagItems; ++k) {
         if (f[k]) {
-            const int64_t rank = (int64_t)off + v[k] - 1;      // v is inclusive
-            const int64_t i = i0 + k;
-            if (rank < n) out[rank] = val[i];
-            if (rank == n - 1) result[0] = i + (int64_t)len[i] - first;
+            sout[v[k] - 1] = sval[threadIdx.x * kFlagItems + k];      // v is inclusive
+            const int64_t rank = (int64_t)off + v[k] - 1;
+            if (rank == n - 1) {
+                const int64_t i = i0 + k;
+                result[0] = i + (int64_t)len[i] - first;
+            }
         }
+    }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < total; j += kBlock) {
+        const int64_t rank = (int64_t)off + j;
+        if (rank < n) out[rank] = sout[j];
     }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) result[1] = (int64_t)off + total;
 }
@@ -310,7 +336,7 @@ int obe_pcg64_uniform(const uint64_t* d_raw, int64_t n, double* d_out, void* str
 int64_t obe_ziggurat_workspace_bytes(int64_t n_raw) {
     if (n_raw < 1) n_raw = 1;
     const int64_t nb = (n_raw + kFlagTile - 1) / kFlagTile;
-    return n_raw * (8 + 4 + 1) + nb * 4 + 1024;
+    return n_raw * (8 + 1 + 1) + nb * 4 + 1024;       // candidate values, byte flags (padded to 8), lengths, block sums
 }
 
 int obe_ziggurat_normal(const uint64_t* d_raw, int64_t n_raw, int64_t offset, const void* d_tables, int64_t n,
@@ -324,8 +350,9 @@ int obe_ziggurat_normal(const uint64_t* d_raw, int64_t n_raw, int64_t offset, co
     char* base = static_cast<char*>(d_ws);
     int64_t* result = reinterpret_cast<int64_t*>(base);             // [0] consumed [1] starts found
     double* val = reinterpret_cast<double*>(base + 64);
-    uint32_t* flag = reinterpret_cast<uint32_t*>(base + 64 + n_raw * 8);
-    uint32_t* sums = flag + n_raw;
+    const int64_t n_pad = (n_raw + 7) / 8 * 8;
+    uint8_t* flag = reinterpret_cast<uint8_t*>(base + 64 + n_raw * 8);
+    uint32_t* sums = reinterpret_cast<uint32_t*>(flag + n_pad);
     uint8_t* len = reinterpret_cast<uint8_t*>(sums + nb);
     ZigTables t;
     t.ki = static_cast<const uint64_t*>(d_tables);
@@ -334,10 +361,9 @@ int obe_ziggurat_normal(const uint64_t* d_raw, int64_t n_raw, int64_t offset, co
     OBE_HIP_TRY(hipMemsetAsync(base, 0, 64, st));
     zig_classify_kernel<<<stream_blocks(n_raw, kBlock), kBlock, 0, st>>>(d_raw, n_raw, t, val, len);
     OBE_CHECK_LAUNCH("zig_classify_kernel");
-    zig_starts_kernel<<<(unsigned)((n_raw + kStartTile - 1) / kStartTile), kBlock, 0, st>>>(len, n_raw, offset, flag);
+    static_assert(kStartTile == kFlagTile && kStartItems == kFlagItems, "the start flags and their scan share one tiling");
+    zig_starts_kernel<<<(unsigned)nb, kBlock, 0, st>>>(len, n_raw, offset, flag, sums);
     OBE_CHECK_LAUNCH("zig_starts_kernel");
-    flag_block_sums<<<(unsigned)nb, kBlock, 0, st>>>(flag, n_raw, sums);
-    OBE_CHECK_LAUNCH("flag_block_sums");
     flag_scan_offsets<<<1, kBlock, 0, st>>>(sums, nb);
     OBE_CHECK_LAUNCH("flag_scan_offsets");
     zig_compact_kernel<<<(unsigned)nb, kBlock, 0, st>>>(flag, sums, val, len, n_raw, offset, n, d_out, result);
