@@ -57,6 +57,65 @@ def test_moments_large_ragged(obe):
             assert_allclose(pdf.covariance(), ref, rtol=1e-11, atol=1e-12 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("d", [1, 2, 7, 16])
+def test_moments_every_dimension_class(obe, d):
+    """The block partials are reduced by a wave reduce-scatter in groups of up to 64 values and
+    folded by one 16-wave workgroup: 2 + 2 D values in pass 1, D (D + 1) / 2 in pass 2 — 4 ... 136,
+    i.e. one partly filled group up to three groups.  Against the oracle, several workgroups."""
+    g = np.random.default_rng(40 + d)
+    n = 300007
+    x = g.normal(0.0, 1.0, (d, n)) * g.uniform(0.5, 20.0, (d, 1)) + g.normal(0.0, 5.0, (d, 1))
+    w = g.exponential(1.0, n) ** 2
+    w /= w.sum()
+    pdf = obe.ParticlePDF(x)
+    pdf.particle_weights = w
+    assert_allclose(pdf.mean(), oracle.weighted_mean(x, w), rtol=1e-12)
+    ref = oracle.weighted_covariance(x, w).reshape(d, d)
+    assert_allclose(pdf.covariance(), ref, rtol=1e-10, atol=1e-12 * np.abs(ref).max())
+    assert_allclose(pdf.std(), np.sqrt(np.maximum(np.sum(w * x * x, axis=1) - np.sum(w * x, axis=1) ** 2, 0.0)),
+                    rtol=1e-9)
+
+
+def test_deferred_host_results_at_the_abi(obe, hip):
+    """obe_defer_host_sync: moments and the CDF total land in page-locked memory without a stream
+    synchronisation inside the call; after the caller's own synchronisation they equal what the
+    synchronous calls deliver."""
+    import ctypes
+    import torch
+    from optbayesexpt_amd import _lib
+    P = ctypes.c_void_p
+    g = np.random.default_rng(9)
+    d, n = 4, 123457
+    x = torch.from_numpy(g.normal(1.0, 2.0, (d, n))).cuda()
+    wn = g.exponential(1.0, n)
+    w = torch.from_numpy(wn / wn.sum()).cuda()
+    mlen = hip.moments_len(d)
+    out = torch.zeros(mlen, dtype=torch.float64, device="cuda")
+    cdf = torch.empty(n, dtype=torch.float64, device="cuda")
+    ws = torch.empty(hip.workspace_bytes(n, 1, 1, d) // 8 + 1, dtype=torch.float64, device="cuda")
+    st = P(torch.cuda.current_stream().cuda_stream)
+    sync_m, sync_t = np.zeros(mlen), np.zeros(1)
+    hip.call("obe_moments", P(x.data_ptr()), n, d, n, P(w.data_ptr()), 1, P(out.data_ptr()), _lib.host_ptr(sync_m),
+             P(ws.data_ptr()), ws.numel() * 8, st)
+    hip.call("obe_weight_cdf", P(w.data_ptr()), n, 0, P(cdf.data_ptr()), _lib.host_ptr(sync_t), P(ws.data_ptr()),
+             ws.numel() * 8, st)
+    pinned = torch.full((mlen + 1,), -7.0, dtype=torch.float64).pin_memory()
+    assert hip.cdll.obe_defer_host_sync(1) == 0
+    try:
+        hip.call("obe_moments", P(x.data_ptr()), n, d, n, P(w.data_ptr()), 1, P(out.data_ptr()),
+                 P(pinned.data_ptr() + 8), P(ws.data_ptr()), ws.numel() * 8, st)
+        hip.call("obe_weight_cdf", P(w.data_ptr()), n, 0, P(cdf.data_ptr()), P(pinned.data_ptr()), P(ws.data_ptr()),
+                 ws.numel() * 8, st)
+    finally:
+        assert hip.cdll.obe_defer_host_sync(0) == 1
+    torch.cuda.synchronize()
+    assert_array_equal(pinned[1:].numpy(), sync_m)
+    assert pinned[0].item() == sync_t[0] and abs(sync_t[0] - 1.0) < 1e-12
+    assert hip.cdll.obe_ziggurat_check(100, 50, 50, 1000, 0) == 0          # enough raw values
+    assert hip.cdll.obe_ziggurat_check(100, 49, 50, 1000, 0) == 1          # too few normals found
+    assert hip.cdll.obe_ziggurat_check(990, 50, 50, 1000, 0) == 1          # ended too close to the buffer's end
+
+
 # ------------------------------------------------------- K4 draws and resample
 @pytest.mark.parametrize("tag,scale", [("s0", False), ("s1", True)])
 @pytest.mark.parametrize("strict", [False, True])
