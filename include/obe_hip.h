@@ -201,9 +201,12 @@ int obe_draw_indices(const double* d_weights, int64_t n_particles, int32_t stric
  * [0, 1).  Selected with tuning_parameters['resample_method'] = 'systematic'. */
 int obe_systematic_indices(const double* d_cdf, int64_t n, double u0, int64_t n_draws,
                            int64_t* d_idx_out, void* stream);
-/* idx[j] = #{i : cdf[i] <= u[j]}  (searchsorted side='right'), int64. */
+/* idx[j] = #{i : cdf[i] <= u[j]}  (searchsorted side='right'), int64.  d_ws (nullable): with at
+ * least n / 2 + 8 bytes of scratch, a search of many draws (n_draws >= n / 4, n >= 32 768: a
+ * resample) first builds a guide table of n / 8 + 1 bucket starts and then searches only the handful
+ * of entries a draw's bucket spans — the same indices, ~3 instead of ~11 cold accesses per draw. */
 int obe_cdf_search(const double* d_cdf, int64_t n, const double* d_uniforms, int64_t n_draws,
-                   int64_t* d_idx_out, void* stream);
+                   int64_t* d_idx_out, void* d_ws, int64_t ws_bytes, void* stream);
 /* randdraw gather: d_out (D, n_draws) = particles[:, idx]  (particlepdf.py:332-343). */
 int obe_gather_columns(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t n_particles,
                        const int64_t* d_idx, int64_t n_draws,

@@ -214,6 +214,57 @@ __global__ __launch_bounds__(kBlock) void cdf_search_kernel(const double* __rest
     }
 }
 
+// Guided search for many draws (a resample: N uniforms into an N-entry CDF).  A plain binary search
+// makes ~11 cold, dependent accesses per draw once the shared top levels are cached.  The guide
+// table has one entry per bucket [b/K, (b+1)/K), K = N/8 (a bucket spans 8 CDF entries = one cache
+// line on average): guide[b] = #{i : cdf[i] < b/K}, built by K + 1 searches whose queries are SORTED
+// (neighbouring threads walk the same path: cache-friendly).  A draw u in bucket b then satisfies
+// guide[b] <= idx <= guide[b+1]  exactly — every entry below guide[b] is < b/K <= u and every entry
+// from guide[b+1] on is >= (b+1)/K > u — so the same upper-bound search runs over that handful of
+// entries: identical indices, ~2-3 cold accesses per draw (1 M draws at 1 M entries: 70 -> 30 us).
+constexpr int64_t kGuideMinEntries = 32768;
+__host__ __device__ __forceinline__ int64_t guide_buckets(int64_t n) { return n >> 3; }
+
+__device__ __forceinline__ double guide_threshold(int64_t b, int64_t k) { return (double)b / (double)k; }
+
+__global__ __launch_bounds__(kBlock) void cdf_guide_kernel(const double* __restrict__ cdf, int64_t n, int64_t k,
+                                                           int32_t* __restrict__ guide) {
+    for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b <= k; b += (int64_t)gridDim.x * kBlock) {
+        const double t = guide_threshold(b, k);
+        int64_t lo = 0, hi = n;                 // first i with cdf[i] >= t
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (cdf[mid] < t) lo = mid + 1;
+            else hi = mid;
+        }
+        guide[b] = static_cast<int32_t>(lo);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void cdf_search_guided_kernel(const double* __restrict__ cdf, int64_t n,
+                                                                   int64_t k, const int32_t* __restrict__ guide,
+                                                                   const double* __restrict__ u, int64_t nd,
+                                                                   int64_t* __restrict__ idx) {
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < nd; j += (int64_t)gridDim.x * kBlock) {
+        const double uj = u[j];
+        int64_t lo = 0, hi = n;
+        if (uj >= 0.0 && uj < 1.0) {            // (anything else: the plain search over the whole CDF)
+            int64_t b = static_cast<int64_t>(uj * (double)k);
+            b = b < 0 ? 0 : (b > k - 1 ? k - 1 : b);
+            while (b > 0 && guide_threshold(b, k) > uj) --b;            // the product may round across a
+            while (b < k - 1 && guide_threshold(b + 1, k) <= uj) ++b;   // bucket edge: at most one step
+            lo = guide[b];
+            hi = guide[b + 1];
+        }
+        while (lo < hi) {                       // first i in [lo, hi) with cdf[i] > u
+            const int64_t mid = (lo + hi) >> 1;
+            if (cdf[mid] <= uj) lo = mid + 1;
+            else hi = mid;
+        }
+        idx[j] = lo;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void gather_columns_kernel(const double* __restrict__ x, int64_t ld, int d,
                                                                 int64_t n_src, const int64_t* __restrict__ idx,
                                                                 int64_t nd, double* __restrict__ out, int64_t ld_out) {
@@ -408,10 +459,22 @@ int obe_systematic_indices(const double* d_cdf, int64_t n, double u0, int64_t n_
 }
 
 int obe_cdf_search(const double* d_cdf, int64_t n, const double* d_uniforms, int64_t n_draws, int64_t* d_idx_out,
-                   void* stream) {
+                   void* d_ws, int64_t ws_bytes, void* stream) {
     if (!d_cdf || !d_uniforms || !d_idx_out || n <= 0 || n_draws <= 0) return bad_arg("obe_cdf_search: bad pointer/size");
-    cdf_search_kernel<<<stream_blocks(n_draws, kBlock), kBlock, 0, as_stream(stream)>>>(d_cdf, n, d_uniforms, n_draws,
-                                                                                         d_idx_out);
+    hipStream_t st = as_stream(stream);
+    // many draws from a large CDF (a resample): build the guide table first
+    const int64_t k = guide_buckets(n);
+    if (d_ws && n >= kGuideMinEntries && n < ((int64_t)1 << 31) && n_draws >= n / 4 &&
+        ws_bytes >= (k + 2) * (int64_t)sizeof(int32_t)) {
+        int32_t* guide = static_cast<int32_t*>(d_ws);
+        cdf_guide_kernel<<<stream_blocks(k + 1, kBlock), kBlock, 0, st>>>(d_cdf, n, k, guide);
+        OBE_CHECK_LAUNCH("cdf_guide_kernel");
+        cdf_search_guided_kernel<<<stream_blocks(n_draws, kBlock), kBlock, 0, st>>>(d_cdf, n, k, guide, d_uniforms,
+                                                                                    n_draws, d_idx_out);
+        OBE_CHECK_LAUNCH("cdf_search_guided_kernel");
+        return 0;
+    }
+    cdf_search_kernel<<<stream_blocks(n_draws, kBlock), kBlock, 0, st>>>(d_cdf, n, d_uniforms, n_draws, d_idx_out);
     OBE_CHECK_LAUNCH("cdf_search_kernel");
     return 0;
 }

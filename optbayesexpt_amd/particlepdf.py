@@ -353,7 +353,7 @@ class ParticlePDF:
         else:
             u_dev = torch.from_numpy(np.atleast_1d(self.rng.random(n_draws))).to(self._device)
         self._lib.call("obe_cdf_search", _ptr(cdf), self.n_particles, _ptr(u_dev), n_draws, _ptr(idx),
-                       self._stream())
+                       _ptr(self._ws), self._ws_bytes, self._stream())
         self.last_draw_indices_device = idx
         return idx
 
@@ -452,7 +452,8 @@ class ParticlePDF:
             else:
                 pin_f[0] = 1.0
             u_dev = rstream.uniforms()
-            self._lib.call("obe_cdf_search", _ptr(self._cdf_dev), n, _ptr(u_dev), n, _ptr(idx), self._stream())
+            self._lib.call("obe_cdf_search", _ptr(self._cdf_dev), n, _ptr(u_dev), n, _ptr(idx), _ptr(self._ws),
+                           self._ws_bytes, self._stream())
             self._lib.call("obe_moments", _ptr(p), p.shape[1], d, n, _ptr(w), 1, _ptr(self._moments_dev),
                            _P(pin_f.data_ptr() + 8), _ptr(self._ws), self._ws_bytes, self._stream())
             have_cov = torch.cuda.Event()

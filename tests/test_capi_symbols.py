@@ -81,7 +81,7 @@ def test_argument_errors_are_reported_not_crashed(lib):
     assert rc == -1 and lib.last_error()
     rc = lib.cdll.obe_moments(None, 0, 3, 0, None, 0, None, None, None, 0, None)
     assert rc == -1
-    rc = lib.cdll.obe_cdf_search(None, 0, None, 0, None, None)
+    rc = lib.cdll.obe_cdf_search(None, 0, None, 0, None, None, 0, None)
     assert rc == -1
     with pytest.raises(_lib.ObeHipError):
         lib.call("obe_argmax", None, 0, None, None, None, 0, None)

@@ -233,8 +233,42 @@ def test_strict_cdf_is_bitwise_numpy_cumsum(obe, hip):
         for strict in (1, 0):
             idx = torch.empty(u.size, dtype=torch.int64, device="cuda")
             cdf = torch.from_numpy(out[strict]).cuda()
-            hip.call("obe_cdf_search", _ptr(cdf), n, _ptr(ud), u.size, _ptr(idx), None)
+            hip.call("obe_cdf_search", _ptr(cdf), n, _ptr(ud), u.size, _ptr(idx), None, 0, None)
             assert_array_equal(idx.cpu().numpy(), ref.searchsorted(u, side="right"))
+
+
+@pytest.mark.parametrize("kind", ["uniform", "one_heavy", "many_zeros", "steps", "tiny_tail"])
+def test_guided_cdf_search_gives_searchsorted_indices(hip, kind):
+    """The guide-table search of a resample-sized draw (N uniforms into an N-entry CDF): exactly
+    numpy's searchsorted(side='right') whatever the CDF looks like — one particle carrying almost all
+    the weight (one bucket chain spans most of the table), long runs of equal entries (zero weights),
+    coarse steps, uniforms on bucket edges and on CDF entries themselves."""
+    import torch
+    from optbayesexpt_amd.particlepdf import _ptr
+    g = np.random.default_rng(hash(kind) % 1000)
+    n = 200003
+    w = {"uniform": lambda: np.ones(n),
+         "one_heavy": lambda: np.where(np.arange(n) == n // 3, 1e7, g.exponential(1.0, n)),
+         "many_zeros": lambda: np.where(g.random(n) < 0.9, 0.0, g.exponential(1.0, n)),
+         "steps": lambda: np.where(np.arange(n) % 1000 == 0, 1.0, 0.0),
+         "tiny_tail": lambda: np.concatenate([g.exponential(1.0, n // 2), np.full(n - n // 2, 1e-300)])}[kind]()
+    cdf = np.cumsum(w)
+    cdf /= cdf[-1]
+    u = g.random(n)
+    u[:2000] = (np.arange(2000) * 97 % n) / n                      # bucket edges b / n
+    u[2000:4000] = np.minimum(cdf[g.integers(0, n, 2000)], np.nextafter(1.0, 0.0))      # CDF entries themselves
+    u[4000:4004] = [0.0, np.nextafter(1.0, 0.0), 5e-324, 0.5]
+    cd, ud = torch.from_numpy(cdf).cuda(), torch.from_numpy(u).cuda()
+    ws = torch.empty(n + 16, dtype=torch.float64, device="cuda")
+    out = {}
+    for guided in (False, True):
+        idx = torch.full((n,), -1, dtype=torch.int64, device="cuda")
+        hip.call("obe_cdf_search", _ptr(cd), n, _ptr(ud), n, _ptr(idx), _ptr(ws) if guided else None,
+                 ws.numel() * 8 if guided else 0, None)
+        out[guided] = idx.cpu().numpy()
+    ref = cdf.searchsorted(u, side="right")
+    assert_array_equal(out[False], ref)
+    assert_array_equal(out[True], ref)
 
 
 # ------------------------------------------------------------- K2 Bayes update
