@@ -19,7 +19,8 @@ from numpy.testing import assert_allclose, assert_array_equal
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 TRAJECTORIES = ["lorentz3_opt", "lorentz3_scale_choke", "lorentz3_good",
-                "line_noiseparam", "coil_2ch_noise", "rabi_2set", "multilorentz7_noise"]
+                "line_noiseparam", "coil_2ch_noise", "rabi_2set", "multilorentz7_noise",
+                "lorentz3_demo"]      # the last one at the reference demo's own size: 200 settings x 50 000 particles
 
 # Relative tolerance of the HIP path per trajectory.  1e-10 is the bar of BASELINE.json.
 # The 10-parameter trajectory is the exception: there the *reference itself* is only

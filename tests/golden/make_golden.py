@@ -66,7 +66,7 @@ MODELS = {
 
 def run_trajectory(name, model, setting_values, prior, cons, true_pars, sigma_meas,
                    n_cycles, seed, cls="base", ctor=None, selection="opt",
-                   pickiness=None, max_particle_snaps=3):
+                   pickiness=None, max_particle_snaps=3, max_weight_snaps=None):
     ctor = dict(ctor or {})
     fn = MODELS[model]
     prior = np.asarray(prior, dtype=np.float64)
@@ -126,7 +126,11 @@ def run_trajectory(name, model, setting_values, prior, cons, true_pars, sigma_me
                 p_cycles.append(cyc)
                 p_snaps.append(np.array(obe.particles, dtype=np.float64))
                 resample_idx.append(rng.choices[0].copy())
-        if cyc < 3 or obe.just_resampled and len(w_snaps) < 8 or cyc == n_cycles - 1:
+        if max_weight_snaps is not None:
+            keep = len(w_snaps) < max_weight_snaps - 1 and (cyc == 0 or obe.just_resampled) or cyc == n_cycles - 1
+        else:
+            keep = cyc < 3 or obe.just_resampled and len(w_snaps) < 8 or cyc == n_cycles - 1
+        if keep:
             w_cycles.append(cyc)
             w_snaps.append(np.array(obe.particle_weights, dtype=np.float64))
 
@@ -148,6 +152,17 @@ def run_trajectory(name, model, setting_values, prior, cons, true_pars, sigma_me
     np.savez_compressed(path, **arrays)
     print(f"{name}: {n_cycles} cycles, {int(np.sum(out['resampled']))} resamples, "
           f"{os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def demo_size():
+    """The reference's find_peak demo at its own size (demos/find_peak/sequentialLorentzian.py:
+    200 settings, 50 000 particles, good_setting(pickiness=19), scale=False): large enough for the
+    multi-chunk sweep kernel, the guided CDF search and the pipelined device-generator resample to be
+    pinned to the real reference (indices exact)."""
+    g = np.random.default_rng(20240425)
+    run_trajectory("lorentz3_demo", "lorentzian", (np.linspace(1.5, 4.5, 200),), lorentz_prior(g, 50000), (0.1,),
+                   (3.0, -1000.0, 50000.0), 500.0, 36, 808, ctor=dict(scale=False),
+                   selection="good", pickiness=19, max_particle_snaps=1, max_weight_snaps=3)
 
 
 def lorentz_prior(g, n):
@@ -429,6 +444,6 @@ def sweeper_cases():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["trajectories", "yspace", "units", "full_sweep", "sweeper"]
     steps = dict(trajectories=trajectories, yspace=yspace_utilities, units=unit_cases,
-                 full_sweep=full_sweep_cases, sweeper=sweeper_cases)
+                 full_sweep=full_sweep_cases, sweeper=sweeper_cases, demo_size=demo_size)
     for w in which:
         steps[w]()
