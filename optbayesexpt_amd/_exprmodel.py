@@ -90,7 +90,7 @@ class _ToC(ast.NodeVisitor):
 # is a small compiler pass over the expression rather than a transliteration:
 #   * every node has a level: C (constants only), S (settings), P (parameters, sqrt(w)), SP;
 #   * maximal S-level subtrees are computed once per setting (prep_setting -> xs slots),
-#     maximal C/P-level subtrees once per particle (pack -> pk slots, staged through LDS);
+#     maximal C/P-level subtrees once per particle (pack -> pk slots of the packed record the sweep streams);
 #   * products are distributed / re-associated when that moves work out of the SP level
 #     ((x - x0)/d -> x/d - x0/d;  sw*(b + a*r) -> (sw*a)*r + sw*b);
 #   * divisions by SP-level denominators are batched over the SPT settings a lane owns
