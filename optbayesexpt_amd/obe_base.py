@@ -422,10 +422,10 @@ class OptBayesExpt(ParticlePDF):
         best_idx = np.zeros(1, dtype=np.int64)
         kappa = np.zeros(1)
         s_ptr = _P(self._settings_dev.data_ptr() + 8 * self._s_begin)
+        noise, noise_ld = self._noise_var_device()
         # last, so that the moments kernels and the sweep are enqueued back to back (every idle
         # microsecond before the sweep kernel also costs clock ramp-up inside it)
         mom = self._moments_on_device()
-        noise, noise_ld = self._noise_var_device()
 
         sharded = self._shard is not None     # every sweep of a sharded object gathers: ranks stay in lockstep
         result = {}
