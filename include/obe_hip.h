@@ -349,7 +349,8 @@ int obe_timer_destroy(void* timer);
  * stream and adds the elapsed time to a running total (the events are read after the stream
  * synchronisation the result copy performs anyway).  Returns the total and the number of
  * launches accumulated so far, then: enable > 0 starts a fresh accumulation, enable == 0 stops
- * it, enable < 0 leaves the state alone (read only).  bench.py: roofline.achieved. */
+ * it, enable < 0 leaves the state alone (read only).  One accumulation per process (per loaded
+ * library: a plugin keeps its own), not thread-safe.  bench.py: roofline.achieved. */
 int obe_sweep_timing(int32_t enable, double* h_total_ms, int64_t* h_launches);
 /* Launches only the dominant sweep kernel `iters` times between two events on `stream`
  * and returns the average per-launch duration in ms; iters < 0: -iters isolated launches

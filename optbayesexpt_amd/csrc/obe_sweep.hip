@@ -669,7 +669,7 @@ static void launch_sweep_spt(int spt, unsigned grid, const SweepArgs& a, hipStre
     }
 }
 
-// pack (once per sweep; `repack` = false when the caller knows the packed draws are current)
+// every draw packed once per sweep call
 template <class M>
 static int launch_pack(const SweepArgs& a, hipStream_t st) {
     sweep_pack_kernel<M><<<stream_blocks(a.nd, kBlock), kBlock, 0, st>>>(a);

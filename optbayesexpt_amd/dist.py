@@ -53,6 +53,7 @@ class SettingsShard:
                                    "(or explicit rank/world_size)")
             rank, world_size = dist.get_rank(group), dist.get_world_size(group)
         self.rank, self.world_size = int(rank), int(world_size)
+        self._record_bufs = {}        # device -> (all-gather receive buffer, page-locked host copy)
 
     def bounds(self, n_settings):
         return shard_bounds(n_settings, self.rank, self.world_size)
@@ -84,7 +85,7 @@ class SettingsShard:
         if w == 1:
             return record.cpu().reshape(1, 4)
         dev = self._comm_device(record.device)        # nccl: stay on the GPU; gloo: host tensors
-        bufs = self.__dict__.setdefault("_record_bufs", {})
+        bufs = self._record_bufs
         if dev not in bufs:                           # receive buffer + page-locked landing zone, made once
             host = torch.empty(4 * w, dtype=torch.float64)
             bufs[dev] = (torch.empty(4 * w, dtype=torch.float64, device=dev),
