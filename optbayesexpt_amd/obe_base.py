@@ -418,9 +418,12 @@ class OptBayesExpt(ParticlePDF):
         p, w = self._pw_tensors()
         cost_t, cost_s = self._cost_device()
         n_local = self._s_end - self._s_begin
-        best = np.zeros(1)
-        best_idx = np.zeros(1, dtype=np.int64)
-        kappa = np.zeros(1)
+        res = self.__dict__.get("_sweep_result")
+        if res is None:               # persistent host landing zone of the sweep result, pointers made once
+            best, best_idx, kappa = np.zeros(1), np.zeros(1, dtype=np.int64), np.zeros(1)
+            res = self._sweep_result = (best, best_idx, kappa, _lib.host_ptr(best), _lib.host_ptr(best_idx),
+                                        _lib.host_ptr(kappa))
+        best, best_idx, kappa, p_best, p_best_idx, p_kappa = res
         s_ptr = _P(self._settings_dev.data_ptr() + 8 * self._s_begin)
         noise, noise_ld = self._noise_var_device()
         # last, so that the moments kernels and the sweep are enqueued back to back (every idle
@@ -439,9 +442,9 @@ class OptBayesExpt(ParticlePDF):
                            (_lib.OBE_SWEEP_SHIFTED if shifted else 0) | (_lib.OBE_SWEEP_SAFE if safe else 0),
                            _ptr(noise), noise_ld, None if cost_t is None else _ptr(cost_t), cost_s,
                            _ptr(self._yvar_dev), _ptr(self._utility_dev),
-                           None if sharded else _lib.host_ptr(best),
-                           None if sharded else _lib.host_ptr(best_idx),
-                           None if sharded else _lib.host_ptr(kappa),
+                           None if sharded else p_best,
+                           None if sharded else p_best_idx,
+                           None if sharded else p_kappa,
                            _ptr(self._ws), self._ws_bytes, self._stream())
             if sharded:
                 off = _lib.OBE_WS_RESULT_OFFSET

@@ -50,6 +50,7 @@ class ParticlePDF:
             torch.device("cuda", torch.cuda.current_device())
         if self._device.index is None:
             self._device = torch.device("cuda", torch.cuda.current_device())
+        self._device_index = self._device.index
         # kernels are launched with this object's device current, whatever the caller's is
         self._lib = _lib.DeviceBound(lib, self._device)
 
@@ -155,7 +156,11 @@ class ParticlePDF:
         return np.arange(self.n_particles, dtype="int")
 
     def _stream(self):
-        return _P(torch.cuda.current_stream(self._device).cuda_stream)
+        """The torch current stream of the object's device, as the C ABI wants it."""
+        try:            # the raw query (0.3 us) instead of building a torch.cuda.Stream object (2 us)
+            return _P(torch._C._cuda_getCurrentRawStream(self._device_index))
+        except AttributeError:
+            return _P(torch.cuda.current_stream(self._device).cuda_stream)
 
     def _pw_tensors(self):
         p, w = self._particles.tensor(), self._weights.tensor()
