@@ -228,6 +228,15 @@ def host_ptr(arr):
     return c_void_p(arr.ctypes.data)          # (data_as() costs twice as much: 2.2 vs 1.2 us per call)
 
 
+def pinned_array(n, dtype=np.float64):
+    """A zeroed page-locked host array (NumPy view of a pinned torch tensor, which it keeps alive).
+    The kernels that end a call write their few result scalars straight into such memory; a pageable
+    array works too, through a small device-to-host copy."""
+    import torch
+    t = torch.zeros(n, dtype=torch.from_numpy(np.zeros(0, dtype=dtype)).dtype).pin_memory()
+    return t.numpy()          # the array's base keeps the pinned storage alive
+
+
 def f64(values, n=None):
     """Small host array of float64 for by-value style arguments."""
     a = np.ascontiguousarray(np.asarray(values, dtype=np.float64).reshape(-1))

@@ -38,6 +38,20 @@ int bad_arg(const char* what);
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Device-visible address of page-locked host memory (hipHostMalloc / hipHostRegister: what torch's
+// pin_memory() gives), or nullptr for pageable memory.  A kernel that delivers a few scalars to the
+// host writes them there itself: the blit kernel of a tiny hipMemcpyAsync costs a launch (~5-10 us of
+// latency per result on an otherwise short call).
+inline void* device_view_of_host(const void* h) {
+    if (!h) return nullptr;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, h) != hipSuccess) {
+        (void)hipGetLastError();           // pageable memory is "invalid value" to some runtimes: not an error here
+        return nullptr;
+    }
+    return attr.type == hipMemoryTypeHost ? attr.devicePointer : nullptr;
+}
+
 inline int stream_blocks(int64_t n, int per_block) {
     int64_t b = (n + per_block - 1) / per_block;
     if (b < 1) b = 1;

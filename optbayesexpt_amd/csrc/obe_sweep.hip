@@ -465,11 +465,24 @@ __global__ __launch_bounds__(kBlock) void argmax_kernel(const double* __restrict
     block_argmax(best, bv, bi);
 }
 
+// Where the result goes on the host, as device-visible addresses (page-locked host memory), or all
+// NULL: then read_best() copies it.
+struct HostResult {
+    double* best;
+    int64_t* idx;
+    double* kappa;
+};
+__device__ __forceinline__ void deliver(const HostResult& h, double v, int64_t i, double k) {
+    if (h.best) *h.best = v;
+    if (h.idx) *h.idx = i;
+    if (h.kappa) *h.kappa = k;
+}
+
 // one block: first-max over the block partials -> scalars {value, index (as int64 bits)}
 __global__ __launch_bounds__(kBlock) void argmax_fold(const double* __restrict__ bv, const int64_t* __restrict__ bi,
                                                       int nb, const double* __restrict__ bk,
                                                       double* __restrict__ out_v,
-                                                      int64_t* __restrict__ out_i) {
+                                                      int64_t* __restrict__ out_i, HostResult host) {
     Best best{-INFINITY, INT64_MAX};
     for (int b = threadIdx.x; b < nb; b += kBlock) {
         Best cand{bv[b], bi[b]};
@@ -496,6 +509,7 @@ __global__ __launch_bounds__(kBlock) void argmax_fold(const double* __restrict__
         reinterpret_cast<int64_t*>(out_v)[3] = out_i[0];
         out_v[4] = k;
         out_v[5] = 0.0;
+        deliver(host, out_v[0], out_i[0], k);
     }
 }
 
@@ -508,7 +522,7 @@ template <class M, bool SAFE>
 __global__ __launch_bounds__(kBlock) void sweep_small_kernel(SweepArgs a, UtilArgs ua, double* __restrict__ yvar,
                                                              double* __restrict__ utility,
                                                              double* __restrict__ out_v,
-                                                             int64_t* __restrict__ out_i) {
+                                                             int64_t* __restrict__ out_i, HostResult host) {
     constexpr int NC = M::NC, NXS = M::NXS, NPK = M::NPK;
     constexpr int NPKW = (NPK + 1 + 1) & ~1;
     extern __shared__ __attribute__((aligned(16))) double tile[];
@@ -587,6 +601,7 @@ __global__ __launch_bounds__(kBlock) void sweep_small_kernel(SweepArgs a, UtilAr
         reinterpret_cast<int64_t*>(out_v)[3] = out_i[0];
         out_v[4] = k;
         out_v[5] = 0.0;
+        deliver(host, out_v[0], out_i[0], k);
     }
 }
 
@@ -647,9 +662,21 @@ static int carve_sweep_ws(void* d_ws, int64_t ws_bytes, int64_t part_doubles, in
     return 0;
 }
 
+// the device views of the caller's host outputs if every one that is asked for is page-locked
+static HostResult host_result(double* h_best, int64_t* h_best_idx, double* h_kappa) {
+    HostResult r{static_cast<double*>(device_view_of_host(h_best)), static_cast<int64_t*>(device_view_of_host(h_best_idx)),
+                 static_cast<double*>(device_view_of_host(h_kappa))};
+    if ((h_best && !r.best) || (h_best_idx && !r.idx) || (h_kappa && !r.kappa)) r = HostResult{nullptr, nullptr, nullptr};
+    return r;
+}
+
 static int read_best(const SweepWs& w, double* h_best, int64_t* h_best_idx, hipStream_t st,
-                     double* h_kappa = nullptr) {
+                     double* h_kappa = nullptr, const HostResult& delivered = HostResult{nullptr, nullptr, nullptr}) {
     if (!h_best && !h_best_idx && !h_kappa) return 0;
+    if (delivered.best || delivered.idx || delivered.kappa) {      // the kernel wrote them: only wait for it
+        OBE_HIP_TRY(hipStreamSynchronize(st));
+        return 0;
+    }
     double tmp[9];
     OBE_HIP_TRY(hipMemcpyAsync(tmp, w.out_v, 9 * sizeof(double), hipMemcpyDeviceToHost, st));
     OBE_HIP_TRY(hipStreamSynchronize(st));
@@ -775,6 +802,7 @@ int obe_sweep_utility(const obe_model* m, const double* d_settings, int64_t ld_s
         return rc;
     hipStream_t st = as_stream(stream);
     UtilArgs ua{d_noise_var, noise_ld, d_cost, cost_scalar};
+    const HostResult hr = host_result(h_best, h_best_idx, h_kappa);
     static const bool no_small = getenv("OBE_SWEEP_NO_SMALL") != nullptr;      // test / tuning aid
     if (d_draw_idx && !no_small && n_draws <= kSmallSweepDraws && n_settings * n_draws <= kSmallSweepEvals) {
         int rc = dispatch_model(mm, [&](auto M) -> int {
@@ -785,15 +813,15 @@ int obe_sweep_utility(const obe_model* m, const double* d_settings, int64_t ld_s
             if constexpr (has_safe_eval<Model>::value) safe = shifted & OBE_SWEEP_SAFE;
             if (safe) {
                 if constexpr (has_safe_eval<Model>::value)
-                    sweep_small_kernel<Model, true><<<1, kBlock, lds, st>>>(a, ua, d_yvar, d_utility, w.out_v, w.out_i);
+                    sweep_small_kernel<Model, true><<<1, kBlock, lds, st>>>(a, ua, d_yvar, d_utility, w.out_v, w.out_i, hr);
             } else {
-                sweep_small_kernel<Model, false><<<1, kBlock, lds, st>>>(a, ua, d_yvar, d_utility, w.out_v, w.out_i);
+                sweep_small_kernel<Model, false><<<1, kBlock, lds, st>>>(a, ua, d_yvar, d_utility, w.out_v, w.out_i, hr);
             }
             OBE_CHECK_LAUNCH("sweep_small_kernel");
             return 0;
         });
         if (rc) return rc;
-        return read_best(w, h_best, h_best_idx, st, h_kappa);
+        return read_best(w, h_best, h_best_idx, st, h_kappa, hr);
     }
     const bool timed = g_timing.on && (h_best || h_best_idx || h_kappa);
     if (timed) {
@@ -820,9 +848,9 @@ int obe_sweep_utility(const obe_model* m, const double* d_settings, int64_t ld_s
     sweep_finalize<<<nb, kBlock, 0, st>>>(w.part1, w.part2, plan.nchunks, mm.n_channels, n_settings, d_moments,
                                           d_draw_idx == nullptr, ua, w.cs, d_yvar, d_utility, w.bv, w.bi, w.bk);
     OBE_CHECK_LAUNCH("sweep_finalize");
-    argmax_fold<<<1, kBlock, 0, st>>>(w.bv, w.bi, nb, w.bk, w.out_v, w.out_i);
+    argmax_fold<<<1, kBlock, 0, st>>>(w.bv, w.bi, nb, w.bk, w.out_v, w.out_i, hr);
     OBE_CHECK_LAUNCH("argmax_fold");
-    rc = read_best(w, h_best, h_best_idx, st, h_kappa);
+    rc = read_best(w, h_best, h_best_idx, st, h_kappa, hr);
     if (timed && !rc) {                       // the stream is drained: both events have completed
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, g_timing.e0, g_timing.e1) == hipSuccess) {
@@ -929,9 +957,10 @@ int obe_utility_argmax(const double* d_yvar, int32_t n_channels, int64_t n_setti
     const int nb = stream_blocks(n_settings, kBlock);
     utility_kernel<<<nb, kBlock, 0, st>>>(d_yvar, n_channels, n_settings, ua, d_utility, w.bv, w.bi);
     OBE_CHECK_LAUNCH("utility_kernel");
-    argmax_fold<<<1, kBlock, 0, st>>>(w.bv, w.bi, nb, nullptr, w.out_v, w.out_i);
+    const HostResult hr = host_result(h_best, h_best_idx, nullptr);
+    argmax_fold<<<1, kBlock, 0, st>>>(w.bv, w.bi, nb, nullptr, w.out_v, w.out_i, hr);
     OBE_CHECK_LAUNCH("argmax_fold");
-    return read_best(w, h_best, h_best_idx, st);
+    return read_best(w, h_best, h_best_idx, st, nullptr, hr);
 }
 
 int obe_argmax(const double* d_v, int64_t n, double* h_best, int64_t* h_best_idx, void* d_ws, int64_t ws_bytes,
@@ -943,9 +972,10 @@ int obe_argmax(const double* d_v, int64_t n, double* h_best, int64_t* h_best_idx
     const int nb = stream_blocks(n, kBlock);
     argmax_kernel<<<nb, kBlock, 0, st>>>(d_v, n, w.bv, w.bi);
     OBE_CHECK_LAUNCH("argmax_kernel");
-    argmax_fold<<<1, kBlock, 0, st>>>(w.bv, w.bi, nb, nullptr, w.out_v, w.out_i);
+    const HostResult hr = host_result(h_best, h_best_idx, nullptr);
+    argmax_fold<<<1, kBlock, 0, st>>>(w.bv, w.bi, nb, nullptr, w.out_v, w.out_i, hr);
     OBE_CHECK_LAUNCH("argmax_fold");
-    return read_best(w, h_best, h_best_idx, st);
+    return read_best(w, h_best, h_best_idx, st, nullptr, hr);
 }
 
 }  // extern "C"

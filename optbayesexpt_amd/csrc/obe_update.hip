@@ -164,8 +164,10 @@ __global__ __launch_bounds__(kBlock) void normalize_kernel(const double* __restr
 }
 
 // pass C: scalars[0] = sum t, scalars[1] = sum w'^2
+// (host_out: the device view of the caller's page-locked h_out, or NULL)
 __global__ __launch_bounds__(kBlock) void fold2_kernel(const double* __restrict__ pa, const double* __restrict__ pb,
-                                                       int n_partials, double* __restrict__ scalars) {
+                                                       int n_partials, double* __restrict__ scalars,
+                                                       double* __restrict__ host_out) {
     __shared__ double red[kBlock / kWave];
     const double a = block_sum_array(pa, n_partials, red);
     __syncthreads();
@@ -173,7 +175,23 @@ __global__ __launch_bounds__(kBlock) void fold2_kernel(const double* __restrict_
     if (threadIdx.x == 0) {
         scalars[0] = a;
         scalars[1] = b;
+        if (host_out) {
+            host_out[0] = a;
+            host_out[1] = b;
+        }
     }
+}
+
+// fold + delivery of {sum t, sum w'^2} to h_out: written by the kernel itself when h_out is page-locked
+static int fold2_to_host(const double* pa, const double* pb, int nb, double* scalars, double* h_out, hipStream_t st) {
+    double* hv = static_cast<double*>(device_view_of_host(h_out));
+    fold2_kernel<<<1, kBlock, 0, st>>>(pa, pb, nb, scalars, hv);
+    OBE_CHECK_LAUNCH("fold2_kernel");
+    if (h_out) {
+        if (!hv) OBE_HIP_TRY(hipMemcpyAsync(h_out, scalars, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+        OBE_HIP_TRY(hipStreamSynchronize(st));
+    }
+    return 0;
 }
 
 // last launch of a sweep batch: fold the final point's partials and test it (unless an earlier
@@ -374,13 +392,7 @@ static int update_blocks(int64_t n) {
 static int finish_update(const UpdateWs& w, int nb, int64_t n, double* d_weights, double* h_out, hipStream_t st) {
     normalize_kernel<<<nb, kBlock, 0, st>>>(w.pa, nb, n, d_weights, w.pb, nullptr);
     OBE_CHECK_LAUNCH("normalize_kernel");
-    fold2_kernel<<<1, kBlock, 0, st>>>(w.pa, w.pb, nb, w.scalars);
-    OBE_CHECK_LAUNCH("fold2_kernel");
-    if (h_out) {
-        OBE_HIP_TRY(hipMemcpyAsync(h_out, w.scalars, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
-        OBE_HIP_TRY(hipStreamSynchronize(st));
-    }
-    return 0;
+    return fold2_to_host(w.pa, w.pb, nb, w.scalars, h_out, st);
 }
 
 }  // namespace obe
@@ -515,11 +527,7 @@ int obe_weight_sums(const double* d_weights, int64_t n_particles, void* d_ws, in
     const int nb = stream_blocks(n_particles, kBlock);
     weight_sums_kernel<<<nb, kBlock, 0, st>>>(d_weights, n_particles, w.pa, w.pb);
     OBE_CHECK_LAUNCH("weight_sums_kernel");
-    fold2_kernel<<<1, kBlock, 0, st>>>(w.pa, w.pb, nb, w.scalars);
-    OBE_CHECK_LAUNCH("fold2_kernel");
-    OBE_HIP_TRY(hipMemcpyAsync(h_out, w.scalars, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
-    OBE_HIP_TRY(hipStreamSynchronize(st));
-    return 0;
+    return fold2_to_host(w.pa, w.pb, nb, w.scalars, h_out, st);
 }
 
 int obe_eval_over_particles(const obe_model* m, const double* d_particles, int64_t ld_p, int64_t n_particles,
@@ -570,7 +578,7 @@ int obe_mask_nonpositive(const double* d_particles, int64_t ld_p, int64_t n_part
     const int nb = stream_blocks(n_particles, kBlock);
     mask_kernel<<<nb, kBlock, 0, st>>>(ra, d_particles, ld_p, n_particles, d_weights, w.pa, w.pb);
     OBE_CHECK_LAUNCH("mask_kernel");
-    fold2_kernel<<<1, kBlock, 0, st>>>(w.pa, w.pb, nb, w.scalars);
+    fold2_kernel<<<1, kBlock, 0, st>>>(w.pa, w.pb, nb, w.scalars, nullptr);
     OBE_CHECK_LAUNCH("fold2_kernel");
     mask_renorm_kernel<<<nb, kBlock, 0, st>>>(w.scalars, n_particles, d_weights);
     OBE_CHECK_LAUNCH("mask_renorm_kernel");

@@ -420,7 +420,7 @@ class OptBayesExpt(ParticlePDF):
         n_local = self._s_end - self._s_begin
         res = self.__dict__.get("_sweep_result")
         if res is None:               # persistent host landing zone of the sweep result, pointers made once
-            best, best_idx, kappa = np.zeros(1), np.zeros(1, dtype=np.int64), np.zeros(1)
+            best, best_idx, kappa = _lib.pinned_array(1), _lib.pinned_array(1, np.int64), _lib.pinned_array(1)
             res = self._sweep_result = (best, best_idx, kappa, _lib.host_ptr(best), _lib.host_ptr(best_idx),
                                         _lib.host_ptr(kappa))
         best, best_idx, kappa, p_best, p_best_idx, p_kappa = res

@@ -64,7 +64,7 @@ class ParticlePDF:
         self.just_resampled = False
         #: numpy Generator feeding randdraw() and resample(); reseed by assignment
         self.rng = np.random.default_rng()
-        self._host_out = np.zeros(16)
+        self._host_out = _lib.pinned_array(16)       # page-locked: the folding kernels write their scalars here
 
     # ------------------------------------------------------------------ state
     def _set_cloud(self, samples, weights):
@@ -81,7 +81,7 @@ class ParticlePDF:
         if weights is not None:
             # weights / np.sum(weights) (particlepdf.py:171) as a device pass: uniform
             # weights times the given array, normalised by its sum
-            self._host_out = np.zeros(16)
+            self._host_out = _lib.pinned_array(16)       # page-locked: the folding kernels write their scalars here
             self._weights = Mirror(self._device, host=np.ones(self.n_particles))
             lik = torch.from_numpy(np.array(weights, dtype=np.float64)).to(self._device)
             w = self._weights.tensor()
