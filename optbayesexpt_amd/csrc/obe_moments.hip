@@ -207,27 +207,40 @@ constexpr int kMaxMomentValues = OBE_MAX_DIMS * (OBE_MAX_DIMS + 1) / 2;     // >
 
 // fold + derive in one single-workgroup launch
 // out: [0]=W [1]=W2 [2..) mean [2+D..) m1 [2+2D..) m2 [2+3D..) std
+// (host: the device view of the caller's page-locked h_out, or NULL — then obe_moments copies)
 __global__ __launch_bounds__(kFoldThreads) void fold_derive_pass1(const double* __restrict__ partials, int nb, int d,
-                                                            double* __restrict__ out) {
+                                                            double* __restrict__ out, double* __restrict__ host) {
     __shared__ double raw[kMaxMomentValues];
     fold_values_block(partials, nb, 2 + 2 * d, raw);
     const int i = threadIdx.x;
     if (i == 0) {
         out[0] = raw[0];
         out[1] = raw[1];
+        if (host) {
+            host[0] = raw[0];
+            host[1] = raw[1];
+        }
     }
     if (i < d) {
         const double m1 = raw[2 + i], m2 = raw[2 + d + i];
-        out[2 + i] = m1 / raw[0];             // np.average: sum(x w) / sum(w)
+        const double mean = m1 / raw[0];             // np.average: sum(x w) / sum(w)
+        const double sd = sqrt(m2 - m1 * m1);        // particlepdf.py:211-214
+        out[2 + i] = mean;
         out[2 + d + i] = m1;
         out[2 + 2 * d + i] = m2;
-        out[2 + 3 * d + i] = sqrt(m2 - m1 * m1);   // particlepdf.py:211-214
+        out[2 + 3 * d + i] = sd;
+        if (host) {
+            host[2 + i] = mean;
+            host[2 + d + i] = m1;
+            host[2 + 2 * d + i] = m2;
+            host[2 + 3 * d + i] = sd;
+        }
     }
 }
 
 // cov = S * (1 / (W - W2/W))  (np.cov scales by the reciprocal)
 __global__ __launch_bounds__(kFoldThreads) void fold_derive_pass2(const double* __restrict__ partials, int nb, int d,
-                                                            double* __restrict__ out) {
+                                                            double* __restrict__ out, double* __restrict__ host) {
     __shared__ double raw[kMaxMomentValues];
     fold_values_block(partials, nb, d * (d + 1) / 2, raw);
     const double fact = out[0] - out[1] / out[0];
@@ -241,23 +254,25 @@ __global__ __launch_bounds__(kFoldThreads) void fold_derive_pass2(const double* 
             j = t;
         }
         const int k = i * d - i * (i - 1) / 2 + (j - i);     // index of (i, j), i <= j, in the packed upper triangle
-        cov[e] = raw[k] * scale;
+        const double c = raw[k] * scale;
+        cov[e] = c;
+        if (host) host[2 + 4 * d + e] = c;
     }
 }
 
 template <int D>
 static int launch_moments(const double* x, int64_t ld, int64_t n, const double* w, int want_cov, double* out,
-                          double* partials, double* raw, hipStream_t st) {
+                          double* partials, double* raw, double* host, hipStream_t st) {
     const int nb = static_cast<int>(std::min<int64_t>(kMomBlocks, (n + kBlock - 1) / kBlock));
     constexpr int NV1 = 2 + 2 * D;
     moments_pass1<D><<<nb, kBlock, 0, st>>>(x, ld, n, w, partials);
     OBE_CHECK_LAUNCH("moments_pass1");
-    fold_derive_pass1<<<1, kFoldThreads, 0, st>>>(partials, nb, D, out);
+    fold_derive_pass1<<<1, kFoldThreads, 0, st>>>(partials, nb, D, out, host);
     OBE_CHECK_LAUNCH("fold_derive_pass1");
     if (want_cov) {
         moments_pass2<D><<<nb, kBlock, 0, st>>>(x, ld, n, w, out, partials);
         OBE_CHECK_LAUNCH("moments_pass2");
-        fold_derive_pass2<<<1, kFoldThreads, 0, st>>>(partials, nb, D, out);
+        fold_derive_pass2<<<1, kFoldThreads, 0, st>>>(partials, nb, D, out, host);
         OBE_CHECK_LAUNCH("fold_derive_pass2");
     }
     return 0;
@@ -282,9 +297,10 @@ int obe_moments(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t
     double* partials = static_cast<double*>(d_ws);
     double* raw = partials + (int64_t)kMomBlocks * nv_max;
     hipStream_t st = as_stream(stream);
+    double* hv = static_cast<double*>(device_view_of_host(h_out));     // page-locked h_out: the kernels write it
     int rc = -1;
 #define OBE_MOM_CASE(DD) \
-    case DD: rc = launch_moments<DD>(d_particles, ld_p, n_particles, d_weights, want_cov, d_out, partials, raw, st); break;
+    case DD: rc = launch_moments<DD>(d_particles, ld_p, n_particles, d_weights, want_cov, d_out, partials, raw, hv, st); break;
     switch (n_dims) {
         OBE_MOM_CASE(1) OBE_MOM_CASE(2) OBE_MOM_CASE(3) OBE_MOM_CASE(4) OBE_MOM_CASE(5) OBE_MOM_CASE(6)
         OBE_MOM_CASE(7) OBE_MOM_CASE(8) OBE_MOM_CASE(9) OBE_MOM_CASE(10) OBE_MOM_CASE(11) OBE_MOM_CASE(12)
@@ -294,7 +310,7 @@ int obe_moments(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t
     if (rc) return rc;
     if (h_out) {
         const int64_t len = want_cov ? obe_moments_len(n_dims) : 2 + 4 * (int64_t)n_dims;
-        OBE_HIP_TRY(hipMemcpyAsync(h_out, d_out, len * sizeof(double), hipMemcpyDeviceToHost, st));
+        if (!hv) OBE_HIP_TRY(hipMemcpyAsync(h_out, d_out, len * sizeof(double), hipMemcpyDeviceToHost, st));
         if (!defer_host_sync()) OBE_HIP_TRY(hipStreamSynchronize(st));
     }
     return 0;

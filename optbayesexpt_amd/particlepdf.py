@@ -107,7 +107,7 @@ class ParticlePDF:
         self._ws = torch.empty(nbytes // 8 + 1, dtype=torch.float64, device=self._device)
         self._ws_bytes = self._ws.numel() * 8
         self._moments_dev = torch.zeros(self._lib.moments_len(d), dtype=torch.float64, device=self._device)
-        self._moments_host = np.zeros(self._lib.moments_len(d))
+        self._moments_host = _lib.pinned_array(self._lib.moments_len(d))
         self._mom_host_key = None      # (particles version, weights version, has_cov) of the host copy
         self._mom_dev_key = None       # same, for the device copy
         self._cdf_dev = torch.empty(n, dtype=torch.float64, device=self._device)
