@@ -310,8 +310,11 @@ __global__ __launch_bounds__(kBlock) void mask_kernel(RowsArg ra, const double* 
 }
 
 // renormalise only if anything was zeroed (scalars[1] = count)
+// (host_changed: the device view of the caller's page-locked count, or NULL)
 __global__ __launch_bounds__(kBlock) void mask_renorm_kernel(const double* __restrict__ scalars, int64_t n,
-                                                             double* __restrict__ weights) {
+                                                             double* __restrict__ weights,
+                                                             int64_t* __restrict__ host_changed) {
+    if (host_changed && blockIdx.x == 0 && threadIdx.x == 0) *host_changed = (int64_t)scalars[1];
     if (scalars[1] == 0.0) return;
     const double total = scalars[0];
     for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (int64_t)gridDim.x * kBlock)
@@ -580,13 +583,18 @@ int obe_mask_nonpositive(const double* d_particles, int64_t ld_p, int64_t n_part
     OBE_CHECK_LAUNCH("mask_kernel");
     fold2_kernel<<<1, kBlock, 0, st>>>(w.pa, w.pb, nb, w.scalars, nullptr);
     OBE_CHECK_LAUNCH("fold2_kernel");
-    mask_renorm_kernel<<<nb, kBlock, 0, st>>>(w.scalars, n_particles, d_weights);
+    int64_t* hv = static_cast<int64_t*>(device_view_of_host(h_changed));
+    mask_renorm_kernel<<<nb, kBlock, 0, st>>>(w.scalars, n_particles, d_weights, hv);
     OBE_CHECK_LAUNCH("mask_renorm_kernel");
     if (h_changed) {
-        double sc[2];
-        OBE_HIP_TRY(hipMemcpyAsync(sc, w.scalars, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
-        OBE_HIP_TRY(hipStreamSynchronize(st));
-        *h_changed = (int64_t)sc[1];
+        if (hv) {
+            OBE_HIP_TRY(hipStreamSynchronize(st));
+        } else {
+            double sc[2];
+            OBE_HIP_TRY(hipMemcpyAsync(sc, w.scalars, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+            OBE_HIP_TRY(hipStreamSynchronize(st));
+            *h_changed = (int64_t)sc[1];
+        }
     }
     return 0;
 }

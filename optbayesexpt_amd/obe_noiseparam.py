@@ -52,7 +52,9 @@ class OptBayesExptNoiseParameter(OptBayesExpt):
         renormalise; called by ``pdf_update`` right after a resample."""
         par = self._parameters.tensor()
         w = self._weights.tensor()
-        changed = np.zeros(1, dtype=np.int64)
+        changed = self.__dict__.get("_changed_pinned")
+        if changed is None:
+            changed = self._changed_pinned = _lib.pinned_array(1, np.int64)
         self._lib.call("obe_mask_nonpositive", _ptr(par), par.shape[1], self.n_particles,
                        _lib.host_ptr(self._noise_rows), self.n_channels, _ptr(w), _lib.host_ptr(changed),
                        _ptr(self._ws), self._ws_bytes, self._stream())
