@@ -10,7 +10,9 @@
  *  - All arithmetic is IEEE float64; indices are int64.
  *  - Every pointer named d_* is a DEVICE pointer owned by the caller (the Python
  *    host side allocates them as torch tensors); the library never allocates or
- *    frees device memory.  h_* are HOST pointers.
+ *    frees device memory.  h_* are HOST pointers.  Result scalars (h_best, h_out, ...) may be
+ *    pageable or page-locked: into page-locked memory (hipHostMalloc / hipHostRegister) the last
+ *    kernel of the call writes them itself, otherwise they arrive by a small device-to-host copy.
  *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All
  *    kernels are enqueued on it; functions that return host scalars say so and
  *    synchronise that stream themselves.
