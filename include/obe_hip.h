@@ -190,7 +190,7 @@ int obe_interval_utility(const double* d_cum, int64_t n_settings, const int64_t*
 /* The index part of randdraw() for a small draw (n_draws <= 64; the reference's N_DRAWS = 30,
  * good_setting's single draw): the uniforms travel as kernel arguments, the CDF is rebuilt
  * unless cdf_is_fresh (d_cdf still holds the CDF of d_weights), and for clouds of up to
- * 65 536 particles scan and search are one launch.  Same CDF bits and indices as
+ * 14 336 particles scan and search are one launch (beyond that the three-kernel scan is faster).  Same CDF bits and indices as
  * obe_weight_cdf + obe_cdf_search.  Never synchronises: when the CDF is rebuilt and
  * h_total_pinned != NULL (pinned host memory), sum(w) is copied there asynchronously and is
  * valid after the caller's next synchronisation of the stream. */

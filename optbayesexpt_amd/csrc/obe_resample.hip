@@ -9,6 +9,8 @@
 //          L2-resident probes.
 //   gather new[i,p] = old[i, idx[p]] + z[p,:] . F[i,:]  (+ optional contraction to the
 //          mean): random 8 B reads, coalesced writes.
+#include <cstdlib>
+
 #include "obe_common.h"
 
 namespace obe {
@@ -152,7 +154,11 @@ __global__ __launch_bounds__(kWave) void cdf_search_arg_kernel(const double* __r
 // CDF + search in one launch for clouds of up to kSmallCloud particles: one workgroup walks the
 // 2048-weight tiles with the same tile_scan / tile-offset arithmetic as the three-kernel path
 // (identical CDF bits), then up to 64 threads run the searches.  total_out[0] = sum(w).
-constexpr int64_t kSmallCloud = 65536;
+constexpr int64_t kSmallCloud = 65536;          // what the kernel can hold
+// what it is used for: one workgroup walks a 2048-weight tile in ~2 us, the three-kernel scan costs
+// ~15 us more in launches — measured crossover at ~15 000 particles (cycle of 200 settings x 30 draws:
+// 92.9 vs 101 us at 10 000 particles, 107.8 vs 99.8 us at 20 000, 202 vs 146 us at 50 000)
+constexpr int64_t kSmallCloudDefault = 14336;
 constexpr int kSmallTiles = static_cast<int>(kSmallCloud / kScanTile);
 
 __global__ __launch_bounds__(kBlock) void draw_small_kernel(const double* __restrict__ w, int64_t n,
@@ -425,7 +431,8 @@ int obe_draw_indices(const double* d_weights, int64_t n_particles, int32_t stric
         OBE_CHECK_LAUNCH("cdf_search_arg_kernel");
         return 0;
     }
-    if (!strict_order && n_particles <= kSmallCloud) {
+    static const int64_t small_limit = getenv("OBE_SMALL_CLOUD") ? atoll(getenv("OBE_SMALL_CLOUD")) : kSmallCloudDefault;   // tuning aid
+    if (!strict_order && n_particles <= std::min(small_limit, kSmallCloud)) {
         draw_small_kernel<<<1, kBlock, 0, st>>>(d_weights, n_particles, d_cdf, ua, n_draws, d_idx, scalars);
         OBE_CHECK_LAUNCH("draw_small_kernel");
     } else {

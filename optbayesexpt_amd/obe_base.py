@@ -671,16 +671,22 @@ class OptBayesExpt(ParticlePDF):
         else:
             u = torch.from_numpy(np.ascontiguousarray(self.utility(), dtype=np.float64).reshape(-1)).to(self._device)
         n = u.numel()
-        prob = torch.empty(n, dtype=torch.float64, device=self._device)
-        cdf = torch.empty(n, dtype=torch.float64, device=self._device)
+        bufs = self.__dict__.get("_good_bufs")
+        if bufs is None or bufs[0].numel() != n:
+            # scratch of the selection, made once; the chosen index lands in page-locked host memory,
+            # which the search kernel writes through its device address (no copy back)
+            bufs = self._good_bufs = (torch.empty(n, dtype=torch.float64, device=self._device),
+                                      torch.empty(n, dtype=torch.float64, device=self._device),
+                                      _lib.pinned_array(1, np.int64))
+        prob, cdf, idx_host = bufs
         self._lib.call("obe_power_normalize", _ptr(u), n, float(pickiness), _ptr(prob), _ptr(self._ws),
                        self._ws_bytes, self._stream())
         uni = np.atleast_1d(self.rng.random())
-        idx = torch.empty(1, dtype=torch.int64, device=self._device)
         # CDF of the selection probabilities + the search for one uniform (passed by value)
-        self._lib.call("obe_draw_indices", _ptr(prob), n, 0, 0, _ptr(cdf), _lib.host_ptr(uni), 1, _ptr(idx), None,
-                       _ptr(self._ws), self._ws_bytes, self._stream())
-        goodindex = int(idx.cpu()[0])
+        self._lib.call("obe_draw_indices", _ptr(prob), n, 0, 0, _ptr(cdf), _lib.host_ptr(uni), 1,
+                       _lib.host_ptr(idx_host), None, _ptr(self._ws), self._ws_bytes, self._stream())
+        torch.cuda.current_stream(self._device).synchronize()
+        goodindex = int(idx_host[0])
         self.last_setting_index = goodindex
         return tuple(self.allsettings[:, goodindex])
 
