@@ -432,6 +432,12 @@ class OptBayesExpt(ParticlePDF):
 
         sharded = self._shard is not None     # every sweep of a sharded object gathers: ranks stay in lockstep
         result = {}
+        # Nobody waits for this sweep: its caller wants the utility on the device (good_setting,
+        # utility_variance), a draws-mode sweep is always shifted (kappa decides nothing) and the model's
+        # fast form cannot leave its range.  Then the launch returns no host result and does not
+        # synchronise; the deferred check of sum(w) happens at the caller's own synchronisation.
+        lazy = (not want_best and not full and not sharded
+                and not getattr(self._device_model, "safe_sweep", False))
 
         def launch(shifted, safe=False):
             # sharded: no host read here — the 32-byte result record is all-gathered from
@@ -442,11 +448,14 @@ class OptBayesExpt(ParticlePDF):
                            (_lib.OBE_SWEEP_SHIFTED if shifted else 0) | (_lib.OBE_SWEEP_SAFE if safe else 0),
                            _ptr(noise), noise_ld, None if cost_t is None else _ptr(cost_t), cost_s,
                            _ptr(self._yvar_dev), _ptr(self._utility_dev),
-                           None if sharded else p_best,
-                           None if sharded else p_best_idx,
-                           None if sharded else p_kappa,
+                           None if sharded or lazy else p_best,
+                           None if sharded or lazy else p_best_idx,
+                           None if sharded or lazy else p_kappa,
                            _ptr(self._ws), self._ws_bytes, self._stream())
-            if sharded:
+            if lazy:
+                result["best"] = None
+                kappa[0] = 0.0
+            elif sharded:
                 off = _lib.OBE_WS_RESULT_OFFSET
                 val, gidx, k = self._shard.combine_records(self._ws[off:off + 4], self._n_settings)
                 result["best"] = (val, gidx)
@@ -465,6 +474,10 @@ class OptBayesExpt(ParticlePDF):
         mode = self.tuning_parameters.get("sweep_shift", "auto")
         shifted = (not full) or mode == "always" or (mode == "auto" and not self._sweep_unshifted)
         safe = False
+        if lazy:
+            launch(True)
+            self.last_sweep = dict(shifted=True, kappa=float("nan"), safe=False)     # kappa was not read back
+            return None
         if self._sweep_safe_streak < self.SAFE_STREAK:
             launch(shifted)
             self._check_pending_total()
@@ -635,7 +648,9 @@ class OptBayesExpt(ParticlePDF):
     def _gather_settings(self, local):
         """Host (rows, N_s) array from this rank's (rows, n_local) device slice."""
         if self._shard is None:
-            return local.cpu().numpy()
+            host = local.cpu().numpy()
+            self._check_pending_total()       # (the copy synchronised: a deferred check of sum(w) can run)
+            return host
         return self._shard.gather_rows(local, self._n_settings)
 
     # --------------------------------------------------------------- selection
@@ -686,6 +701,7 @@ class OptBayesExpt(ParticlePDF):
         self._lib.call("obe_draw_indices", _ptr(prob), n, 0, 0, _ptr(cdf), _lib.host_ptr(uni), 1,
                        _lib.host_ptr(idx_host), None, _ptr(self._ws), self._ws_bytes, self._stream())
         torch.cuda.current_stream(self._device).synchronize()
+        self._check_pending_total()
         goodindex = int(idx_host[0])
         self.last_setting_index = goodindex
         return tuple(self.allsettings[:, goodindex])
