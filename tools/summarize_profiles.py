@@ -7,11 +7,14 @@ import sqlite3
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "prof")
+SRC = os.path.join(ROOT, "gpurun_out", "prof")       # (c3; other configs: gpurun_out/prof_<cfg>, set below)
 DST = os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 cfg = sys.argv[2] if len(sys.argv) > 2 else "c3"
-n_p, n_s, d = (1048576, 65536, 3) if cfg == "c3" else (262144, 4096, 3)
+n_p, n_s, d = {"c3": (1048576, 65536, 3), "c2": (262144, 4096, 3), "c5": (524288, 16384, 10)}[cfg]
+if cfg != "c3":
+    SRC = os.path.join(ROOT, "gpurun_out", f"prof_{cfg}")
+n_read = d + 1 if cfg != "c5" else 10 + 1        # rows pass A of the update reads (c5: the noise row is one of the 10)
 
 
 def short(name):
@@ -59,7 +62,7 @@ upd = [k for k in summary["kernels"] if "update_model_kernel" in k]
 corr = None
 if upd:
     u = summary["kernels"][upd[0]]
-    known_read = 8 * (d + 1) * n_p
+    known_read = 8 * n_read * n_p
     known_write = 8 * n_p
     corr = {"kernel": upd[0], "known_read_bytes": known_read, "known_write_bytes": known_write,
             # (min over dispatches: bench.py also runs this kernel on a 16 x tiled cloud)
@@ -80,7 +83,7 @@ if sw and corr:
     summary["sweep_kernel_read_bytes"], summary["sweep_kernel_written_bytes"] = rd, wr
     summary["sweep_kernel_note"] = ("FETCH (scalar loads, factor 1.0) + calibrated WRITE per launch; compulsory bytes are "
                                     f"{8 * (d + 1) * n_p + 16 * n_s} (cloud + settings + utility); the reads are the packed "
-                                    "cloud once, the writes are the chunk partials (40 chunks x N_s x 16 B)")
+                                    "cloud once, the writes are the chunk partials (n_chunks x N_s x 16 B)")
 path = os.path.join(DST, f"{tag}_pmc_hbm_{cfg}.json")
 json.dump(summary, open(path, "w"), indent=1)
 print(json.dumps(summary, indent=1)[:4000])
@@ -92,7 +95,7 @@ allcfg[cfg] = {"sweep_kernel_hbm_bytes_per_launch": summary.get("sweep_kernel_hb
 json.dump(allcfg, open(tpath, "w"), indent=1)
 
 # 3. SQ issue counters of the sweep kernel (tools/profile_sq.sh), if collected
-sq_db = os.path.join(ROOT, "gpurun_out", "prof_sq", "sq")
+sq_db = os.path.join(ROOT, "gpurun_out", "prof_sq", "sq") if cfg == "c3" else ""      # (collected for c3 only)
 dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(sq_db) for f in fs if f.endswith(".db")] if os.path.isdir(sq_db) else []
 if dbs:
     c = sqlite3.connect(dbs[0])
