@@ -45,3 +45,6 @@ tag = f"{os.environ.get('OBE_AB_ROOT', os.environ.get('OBE_VARIANT', 'tree'))} {
 b2b = [k1(iters) for _ in range(3)]
 iso = [k1(-iters) for _ in range(3)] if not os.environ.get("OBE_AB_ROOT") else [float("nan")]
 print(f"{tag}: back-to-back {min(b2b):.3f} ms  isolated {min(iso):.3f} ms  (all: {b2b} {iso})")
+if not os.environ.get("OBE_AB_ROOT"):
+    sh = [k1(iters, 1) for _ in range(3)]
+    print(f"{tag}: shifted variant back-to-back {min(sh):.3f} ms")
