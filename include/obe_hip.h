@@ -215,12 +215,16 @@ int obe_gather_columns(const double* d_particles, int64_t ld_p, int32_t n_dims, 
                        double* d_out, int64_t ld_out, void* stream);
 /* resample(): new[i,p] = old[i, idx[p]] + sum_j z[p,j] F[i,j]   (F = u*sqrt(s) of the
  * SVD of (1-a^2) cov, h_factor row-major D*D; z = standard normals (N, D) row-major);
- * if scale: new = new*a + mean[i]*(1-a)   (particlepdf.py:296-305).  Then weights = 1/N. */
+ * if scale: new = new*a + mean[i]*(1-a)   (particlepdf.py:296-305).  Then weights = 1/N.
+ * d_ws (nullable): with 8 * n_dims * n_particles bytes of scratch a large cloud is first copied
+ * to (N, D) order, so that the gather of a particle touches one or two 64-byte sectors instead
+ * of n_dims of them. */
 int obe_resample_particles(const double* d_old, int64_t ld_old, int32_t n_dims, int64_t n_particles,
                            const int64_t* d_idx, const double* d_normals,
                            const double* h_factor, const double* h_mean,
                            double a_param, int32_t scale,
-                           double* d_new, int64_t ld_new, double* d_weights, void* stream);
+                           double* d_new, int64_t ld_new, double* d_weights,
+                           void* d_ws, int64_t ws_bytes, void* stream);
 
 /* ---- K6: OptBayesExptNoiseParameter extras ----
  * enforce_parameter_constraints (obe_noiseparam.py:57-79): zero the weight of every

@@ -291,7 +291,29 @@ struct NudgeArgs {
 // One thread per new particle.  D is a template parameter so that the z row lives in
 // registers, the D x D factor is read as wave-uniform kernel arguments and both loops
 // unroll (the generic runtime-D loop took 343 us at D = 10, N = 524 288).
+// (D, N) SoA -> (N, D) AoS copy of the old cloud, lane-contiguous on both sides (LDS transpose).  The
+// gather of resample_kernel reads D random 8-byte values per particle: from the SoA layout every one
+// of them pulls its own 64-byte sector (8 x the bytes); from the AoS copy a particle is one or two
+// sectors.  Worth the extra pass from D = 2 on.
 template <int D>
+__global__ __launch_bounds__(kBlock) void soa_to_aos_kernel(const double* __restrict__ x, int64_t ld, int64_t n,
+                                                            double* __restrict__ aos) {
+    __shared__ double tile[kBlock * D];
+    for (int64_t p0 = (int64_t)blockIdx.x * kBlock; p0 < n; p0 += (int64_t)gridDim.x * kBlock) {
+        const int64_t p = p0 + threadIdx.x;
+        __syncthreads();
+        if (p < n) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) tile[threadIdx.x * D + i] = x[(int64_t)i * ld + p];
+        }
+        __syncthreads();
+        const int64_t run = (n - p0 < kBlock ? n - p0 : kBlock) * D;
+        for (int64_t e = threadIdx.x; e < run; e += kBlock) aos[p0 * D + e] = tile[e];
+    }
+}
+
+// AOS: `old` is the (N, D) copy made by soa_to_aos_kernel (ld_old unused)
+template <int D, bool AOS>
 __global__ __launch_bounds__(kBlock) void resample_kernel(NudgeArgs na, const double* __restrict__ old, int64_t ld_old,
                                                           int64_t n, const int64_t* __restrict__ idx,
                                                           const double* __restrict__ z, double* __restrict__ out,
@@ -312,7 +334,8 @@ __global__ __launch_bounds__(kBlock) void resample_kernel(NudgeArgs na, const do
 #pragma unroll
         for (int j = 0; j < D; ++j) zr[j] = zs[threadIdx.x * D + j];
 #pragma unroll
-        for (int i = 0; i < D; ++i) x0[i] = old[(int64_t)i * ld_old + src];      // D independent gathers in flight
+        for (int i = 0; i < D; ++i)                                              // D independent gathers in flight
+            x0[i] = AOS ? old[src * D + i] : old[(int64_t)i * ld_old + src];
 #pragma unroll
         for (int i = 0; i < D; ++i) {
             // (z @ F.T)[p, i]: FMA chain from zero in j order — bit-identical to the
@@ -334,10 +357,18 @@ __global__ __launch_bounds__(kBlock) void resample_kernel(NudgeArgs na, const do
 
 template <int D>
 static int launch_resample(const NudgeArgs& na, const double* d_old, int64_t ld_old, int64_t n, const int64_t* d_idx,
-                           const double* d_normals, double* d_new, int64_t ld_new, double* d_weights,
-                           hipStream_t st) {
-    resample_kernel<D><<<stream_blocks(n, kBlock), kBlock, 0, st>>>(na, d_old, ld_old, n, d_idx, d_normals, d_new,
-                                                                    ld_new, d_weights);
+                           const double* d_normals, double* d_new, int64_t ld_new, double* d_weights, void* d_ws,
+                           int64_t ws_bytes, hipStream_t st) {
+    const int blocks = stream_blocks(n, kBlock);
+    if (D >= 2 && n >= 65536 && d_ws && ws_bytes >= (int64_t)sizeof(double) * D * n) {
+        double* aos = static_cast<double*>(d_ws);
+        soa_to_aos_kernel<D><<<blocks, kBlock, 0, st>>>(d_old, ld_old, n, aos);
+        OBE_CHECK_LAUNCH("soa_to_aos_kernel");
+        resample_kernel<D, true><<<blocks, kBlock, 0, st>>>(na, aos, 0, n, d_idx, d_normals, d_new, ld_new, d_weights);
+    } else {
+        resample_kernel<D, false><<<blocks, kBlock, 0, st>>>(na, d_old, ld_old, n, d_idx, d_normals, d_new, ld_new,
+                                                             d_weights);
+    }
     OBE_CHECK_LAUNCH("resample_kernel");
     return 0;
 }
@@ -499,7 +530,7 @@ int obe_gather_columns(const double* d_particles, int64_t ld_p, int32_t n_dims, 
 int obe_resample_particles(const double* d_old, int64_t ld_old, int32_t n_dims, int64_t n_particles,
                            const int64_t* d_idx, const double* d_normals, const double* h_factor,
                            const double* h_mean, double a_param, int32_t scale, double* d_new, int64_t ld_new,
-                           double* d_weights, void* stream) {
+                           double* d_weights, void* d_ws, int64_t ws_bytes, void* stream) {
     if (!d_old || !d_idx || !d_normals || !h_factor || !h_mean || !d_new || !d_weights || n_particles <= 0)
         return bad_arg("obe_resample_particles: bad pointer/size");
     if (n_dims < 1 || n_dims > OBE_MAX_DIMS) return bad_arg("obe_resample_particles: n_dims must be 1..16");
@@ -514,7 +545,8 @@ int obe_resample_particles(const double* d_old, int64_t ld_old, int32_t n_dims, 
     for (int i = 0; i < n_dims; ++i) na.mean[i] = h_mean[i];
     hipStream_t st = as_stream(stream);
 #define OBE_RS_CASE(DD) \
-    case DD: return launch_resample<DD>(na, d_old, ld_old, n_particles, d_idx, d_normals, d_new, ld_new, d_weights, st);
+    case DD: return launch_resample<DD>(na, d_old, ld_old, n_particles, d_idx, d_normals, d_new, ld_new, d_weights, \
+                                        d_ws, ws_bytes, st);
     switch (n_dims) {
         OBE_RS_CASE(1) OBE_RS_CASE(2) OBE_RS_CASE(3) OBE_RS_CASE(4) OBE_RS_CASE(5) OBE_RS_CASE(6) OBE_RS_CASE(7)
         OBE_RS_CASE(8) OBE_RS_CASE(9) OBE_RS_CASE(10) OBE_RS_CASE(11) OBE_RS_CASE(12) OBE_RS_CASE(13)

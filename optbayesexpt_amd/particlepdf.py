@@ -424,7 +424,8 @@ class ParticlePDF:
         w = self._weights.tensor()
         self._lib.call("obe_resample_particles", _ptr(old), old.shape[1], d, n, _ptr(idx), _ptr(z_dev),
                        _lib.host_ptr(factor), _lib.host_ptr(mean), float(self.tuning_parameters["a_param"]),
-                       1 if self.tuning_parameters["scale"] else 0, _ptr(new), n, _ptr(w), self._stream())
+                       1 if self.tuning_parameters["scale"] else 0, _ptr(new), n, _ptr(w), _ptr(self._ws),
+                       self._ws_bytes, self._stream())
         self._particles = Mirror(self._device, tensor=new)
         self._weights.mark_device_written()
         self.last_resample_indices_device = idx
