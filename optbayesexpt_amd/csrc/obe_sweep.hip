@@ -112,6 +112,7 @@ struct SweepArgs {
     int64_t chunk;
     int tiles_x, nchunks;      // logical grid: setting tiles x particle chunks
     int one;                   // 1 (a run-time constant the prefetch address is built from)
+    int xcd_map;               // chunks in whole groups of 8: block -> (tile, chunk) follows the XCD round robin
     double* packed;            // (nd, packed_width): written by sweep_pack_kernel, read by sweep_kernel
     double* part1;
     double* part2;
@@ -172,9 +173,17 @@ __global__ __launch_bounds__(kBlock) OBE_SWEEP_OCCUPANCY void sweep_kernel(Sweep
     // XCD b % 8 (observed placement; only speed depends on it): give XCD x the chunks
     // {x, x+8, ...}, so each 4 MiB L2 streams 1/8 of the cloud instead of all of it
     // (rocprofv3 FETCH_SIZE before: 8 x the cloud per launch).
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int chunk_id = (slot / a.tiles_x) * 8 + xcd;
-    const int tile_x = slot % a.tiles_x;
+    // (Only when the chunks come in whole groups of 8; a sweep of few draws has fewer chunks than
+    // XCDs, and padding the map would leave most of its workgroups — and XCDs — without work.)
+    int chunk_id, tile_x;
+    if (a.xcd_map) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        chunk_id = (slot / a.tiles_x) * 8 + xcd;
+        tile_x = slot % a.tiles_x;
+    } else {
+        chunk_id = blockIdx.x / a.tiles_x;
+        tile_x = blockIdx.x % a.tiles_x;
+    }
     if (chunk_id >= a.nchunks) return;
     const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
 
@@ -709,7 +718,8 @@ static int launch_sweep(const SweepPlan& p, SweepArgs& a, int flags, hipStream_t
     a.tiles_x = p.tiles_x;
     a.nchunks = p.nchunks;
     a.one = 1;
-    const unsigned grid = (unsigned)p.tiles_x * (unsigned)((p.nchunks + 7) / 8 * 8);
+    a.xcd_map = p.nchunks % 8 == 0;
+    const unsigned grid = (unsigned)p.tiles_x * (unsigned)p.nchunks;
     const bool shifted = flags & OBE_SWEEP_SHIFTED;
     bool safe = false;
     if constexpr (has_safe_eval<M>::value) safe = flags & OBE_SWEEP_SAFE;
