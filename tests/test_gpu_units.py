@@ -656,6 +656,37 @@ def test_pipelined_resample_is_the_step_by_step_resample(obe, d, scale):
     assert pdf.rng.bit_generator.state == before
 
 
+@pytest.mark.parametrize("d", [1, 3, 10])
+def test_resample_gather_layouts_agree(hip, d):
+    """obe_resample_particles gathers from an (N, D) copy of the old cloud when it is given scratch
+    for it, and from the (D, N) rows directly otherwise: the same numbers either way, and equal to
+    old[:, idx] + z @ F.T computed on the host."""
+    import torch
+    from optbayesexpt_amd import _lib
+    from optbayesexpt_amd.particlepdf import _ptr
+    g = np.random.default_rng(60 + d)
+    n = 70001
+    old = g.normal(0.0, 1.0, (d, n)) * np.arange(1, d + 1)[:, None]
+    idx = g.integers(0, n, n)
+    z = g.standard_normal((n, d))
+    f = g.normal(0.0, 0.1, (d, d))
+    mean = old.mean(axis=1)
+    od, zd, ix = torch.from_numpy(old).cuda(), torch.from_numpy(z).cuda(), torch.from_numpy(idx).cuda()
+    ws = torch.empty(d * n + 64, dtype=torch.float64, device="cuda")
+    out = {}
+    for with_ws in (False, True):
+        new = torch.empty((d, n), dtype=torch.float64, device="cuda")
+        w = torch.empty(n, dtype=torch.float64, device="cuda")
+        hip.call("obe_resample_particles", _ptr(od), n, d, n, _ptr(ix), _ptr(zd), _lib.host_ptr(np.ascontiguousarray(f)),
+                 _lib.host_ptr(mean), 0.98, 1, _ptr(new), n, _ptr(w), _ptr(ws) if with_ws else None,
+                 ws.numel() * 8 if with_ws else 0, None)
+        out[with_ws] = (new.cpu().numpy(), w.cpu().numpy())
+    assert_array_equal(out[True][0], out[False][0])
+    assert_array_equal(out[True][1], np.full(n, 1.0 / n))
+    ref = (old[:, idx] + (z @ f.T).T) * 0.98 + (mean * (1 - 0.98))[:, None]
+    assert_allclose(out[True][0], ref, rtol=1e-13, atol=1e-13)
+
+
 def test_sweep_timing_counts_the_launches_of_real_cycles(obe):
     """obe_sweep_timing (bench.py's roofline leg): events around every sweep-kernel launch that
     returns its result to the host."""
