@@ -43,6 +43,9 @@ FLOP_PER_EVAL = {"lorentzian": 10, "lorentzian7": 46}
 # FP64 VALU issue slots per evaluation in the kernel's pair loop, counted in the gfx950 ISA
 # (tools/count_isa.py; v_rcp_f64 = 4 slots): (unshifted, shifted)
 ISSUE_SLOTS_PER_EVAL = {"lorentzian": (7.375, 8.375), "lorentzian7": (35.0, 36.0)}   # 7 peaks: 34.75 FP64 + 0.25 v_cndmask
+# the form a sweep falls back to when the fast one leaves its range (last_sweep["safe"]): 7 peaks one by
+# one, two particles per reciprocal, always shifted
+ISSUE_SLOTS_SAFE_FORM = {"lorentzian7": 40.6}
 VALU_ISSUE_PEAK = 256 * 4 * 16 * 2.4e9                   # lane-instructions/s: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz
 
 CONFIGS = {
@@ -272,8 +275,10 @@ def main():
     stream = obe._stream()
     s_ptr = ctypes.c_void_p(obe._settings_dev.data_ptr() + 8 * obe._s_begin)
     shifted = bool(obe.last_sweep["shifted"])           # the variant the timed cycles ended on
+    safe_form = bool(obe.last_sweep.get("safe"))        # ... and the form (fast, or the model's in-range twin)
+    flags = (_lib.OBE_SWEEP_SHIFTED if shifted else 0) | (_lib.OBE_SWEEP_SAFE if safe_form else 0)
     obe._mlib.call("obe_sweep_kernel_time", obe._model_struct, s_ptr, ns, n_local, _ptr(p), p.shape[1], n_p,
-             _ptr(w), _ptr(mom), 1 if shifted else 0, _ptr(obe._ws), obe._ws_bytes, 5, ctypes.byref(ms), stream)
+             _ptr(w), _ptr(mom), flags, _ptr(obe._ws), obe._ws_bytes, 5, ctypes.byref(ms), stream)
     k1_back_to_back_ms = ms.value
     # the figure the roofline uses: the average over the launches of the timed cycles themselves
     # (full-sweep configs; c1's reference-semantics sweep is a one-workgroup kernel timed back to back)
@@ -303,13 +308,14 @@ def main():
                                   "steps, on the launch stream" if in_cycle else
                                   "5 back-to-back launches between two HIP events on the launch stream"),
                 "launch_ms_back_to_back": k1_back_to_back_ms,
-                "variant": "shifted" if shifted else "unshifted",
+                "variant": "shifted" if shifted else "unshifted", "form": "safe" if safe_form else "fast",
                 "kappa": obe.last_sweep["kappa"], "traffic": traffic,
                 "valu_issue": (lambda slots: {
                     "slots_per_eval": slots, "achieved": slots * n_local * n_p / k1_s, "peak": VALU_ISSUE_PEAK,
                     "unit": "FP64 lane-instructions/s", "frac": slots * n_local * n_p / k1_s / VALU_ISSUE_PEAK,
                     "note": "the flop roofline prices every slot as an FMA; the kernel's mix is ~half mul/add"})(
-                        ISSUE_SLOTS_PER_EVAL[model][1 if shifted else 0]),
+                        ISSUE_SLOTS_SAFE_FORM.get(model, ISSUE_SLOTS_PER_EVAL[model][1]) if safe_form
+                        else ISSUE_SLOTS_PER_EVAL[model][1 if shifted else 0]),
                 "hbm_algorithmic": {"bytes": k1_bytes, "achieved": k1_bytes / k1_s / 1e9, "peak": HBM_PEAK_GBS,
                                     "unit": "GB/s", "frac": k1_bytes / k1_s / 1e9 / HBM_PEAK_GBS,
                                     "note": "compute-bound kernel: ~1e4 flop per compulsory byte"}}

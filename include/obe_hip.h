@@ -82,6 +82,11 @@ const char* obe_last_error(void);
  * copy itself blocks).  resample() uses it to keep the device busy while the host factorises the
  * covariance.  Returns the previous state. */
 int obe_defer_host_sync(int32_t on);
+/* The address under which kernels of the current device reach a page-locked host buffer
+ * (hipHostMalloc / hipHostRegister; fails for pageable memory).  A `d_*` output argument that is
+ * only a few values — the index of obe_draw_indices for good_setting() — may be given as this
+ * address: the kernel then delivers the result to the host itself, with no copy back. */
+int obe_host_device_pointer(const void* h_pinned, void** d_out);
 /* Name, CU count and memory of the current device; returns 0 if a gfx950 device is current. */
 int obe_device_info(char* name, int name_len, int* n_cu, int64_t* hbm_bytes);
 
@@ -278,6 +283,10 @@ int obe_power_normalize(const double* d_u, int64_t n, double exponent, double* d
  * reciprocal per element, implies the shift).  Built-in models ignore OBE_SWEEP_SAFE. */
 #define OBE_SWEEP_SHIFTED 1
 #define OBE_SWEEP_SAFE 2
+/* Settings one lane of the sweep kernel owns for a grid of n_settings (1, 2, 4 or 8): the number
+ * of denominators a model's fast form inverts together, which a caller that predicts whether a
+ * settings grid stays inside that form's range needs (optbayesexpt_amd/models.py: range_hint). */
+int obe_sweep_settings_per_lane(int64_t n_settings);
 int obe_sweep_utility(const obe_model* m,
                       const double* d_settings, int64_t ld_s, int64_t n_settings,
                       const double* d_particles, int64_t ld_p, int64_t n_particles,

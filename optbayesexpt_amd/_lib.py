@@ -101,6 +101,8 @@ _SIGNATURES = {
     "obe_timer_start": (c_int, [_P, _P]),
     "obe_timer_stop": (c_int, [_P, _P, ctypes.POINTER(ctypes.c_float)]),
     "obe_timer_destroy": (c_int, [_P]),
+    "obe_sweep_settings_per_lane": (c_int, [c_int64]),
+    "obe_host_device_pointer": (c_int, [_P, ctypes.POINTER(c_void_p)]),
     "obe_sweep_timing": (c_int, [c_int32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64)]),
     "obe_sweep_kernel_time": (c_int, [ctypes.POINTER(ObeModelStruct), _P, c_int64, c_int64, _P, c_int64, c_int64,
                                       _P, _P, c_int32, _P, c_int64, c_int32, ctypes.POINTER(ctypes.c_float), _P]),
@@ -108,7 +110,7 @@ _SIGNATURES = {
 
 
 # entry points whose code depends on the model: a plugin library serves these
-MODEL_ENTRY_POINTS = ("obe_model_validate", "obe_workspace_bytes", "obe_bayes_update_model", "obe_bayes_update_sweep",
+MODEL_ENTRY_POINTS = ("obe_model_validate", "obe_workspace_bytes", "obe_sweep_settings_per_lane", "obe_bayes_update_model", "obe_bayes_update_sweep",
                       "obe_eval_over_particles",
                       "obe_eval_over_settings", "obe_sweep_utility", "obe_sweep_kernel_time", "obe_sweep_timing",
                       "obe_eval_draws")
@@ -117,7 +119,7 @@ MODEL_ENTRY_POINTS = ("obe_model_validate", "obe_workspace_bytes", "obe_bayes_up
 class HipLib:
     """Loaded library with typed entry points; ``call(name, *args)`` raises on error."""
 
-    def __init__(self, path=LIB_PATH, plugin=False):
+    def __init__(self, path=LIB_PATH, plugin=False, allow_variant=False):
         if not os.path.exists(path):
             raise ImportError(
                 f"{path} not found: the HIP library has not been built.  Run "
@@ -138,6 +140,11 @@ class HipLib:
             raise ImportError(f"libobe_hip ABI {abi} does not match this package (1)")
         from . import build
         built_from = self.cdll.obe_source_fingerprint().decode()
+        #: extra compiler flags of a tools/build_variant.py library ("" for the product build); such a
+        #: library is only accepted when the caller asks for it by path with allow_variant=True
+        self.variant_flags = built_from.partition("+")[2]
+        if allow_variant:
+            built_from = built_from.partition("+")[0]
         if built_from != build._source_fingerprint():
             raise ImportError(f"{path} was built from other kernel sources ({built_from}) than the ones next to it "
                               f"({build._source_fingerprint()}): run `python -m optbayesexpt_amd.build`")
@@ -235,6 +242,14 @@ def pinned_array(n, dtype=np.float64):
     import torch
     t = torch.zeros(n, dtype=torch.from_numpy(np.zeros(0, dtype=dtype)).dtype).pin_memory()
     return t.numpy()          # the array's base keeps the pinned storage alive
+
+
+def device_ptr_of_pinned(lib, arr):
+    """The address kernels use for a ``pinned_array`` (obe_host_device_pointer): what to pass where
+    the C ABI takes a *device* pointer and the result should land in host memory directly."""
+    d = c_void_p()
+    lib.call("obe_host_device_pointer", host_ptr(arr), ctypes.byref(d))
+    return c_void_p(d.value)
 
 
 def f64(values, n=None):

@@ -70,6 +70,14 @@ int obe_model_validate(obe_model* m) {
     return 0;
 }
 
+int obe_host_device_pointer(const void* h_pinned, void** d_out) {
+    if (!h_pinned || !d_out) return bad_arg("obe_host_device_pointer: null pointer");
+    void* d = device_view_of_host(h_pinned);
+    if (!d) return bad_arg("obe_host_device_pointer: not page-locked host memory");
+    *d_out = d;
+    return 0;
+}
+
 int obe_device_info(char* name, int name_len, int* n_cu, int64_t* hbm_bytes) {
     int dev = 0;
     OBE_HIP_TRY(hipGetDevice(&dev));

@@ -450,8 +450,11 @@ struct Lorentz {
     }
     // Two particles at once: their 2*SPT/2 pair products share ONE reciprocal, and each
     // particle's amplitude enters the inversion tree at its root (2 multiplies per 16 evaluations).
-    // (Peak-by-peak models only: a combined fraction already spans q^(8K) per particle.)
+    // The fast form of the peak-by-peak models (a combined fraction already spans q^(8K) per
+    // particle) and, for K >= 3, the form the SAFE repeat streams its particles through: the tree
+    // spans q^16 per peak whatever K is, in range for |x - x0|/d up to ~1e9.
     static constexpr bool kHasPairEval = !kCombinePeaks;
+    static constexpr bool kSafePairEval = kCombinePeaks;
     template <int SPT>
     __device__ __forceinline__ static void sweep_eval_pair(const double (&xs)[SPT][NXS], const double* pa,
                                                            const double* pb, double (&va)[SPT][NC],
@@ -703,6 +706,11 @@ template <class M, class = void>
 struct has_pair_eval { static constexpr bool value = false; };
 template <class M>
 struct has_pair_eval<M, std::enable_if_t<M::kHasPairEval>> { static constexpr bool value = true; };
+// models whose SAFE sweep may run its particles two at a time through sweep_eval_pair()
+template <class M, class = void>
+struct safe_pair_eval { static constexpr bool value = false; };
+template <class M>
+struct safe_pair_eval<M, std::enable_if_t<M::kSafePairEval>> { static constexpr bool value = true; };
 // models whose sweep_eval() may poison out-of-range batches bring a branchy, always-IEEE twin
 template <class M, class = void>
 struct has_safe_eval { static constexpr bool value = false; };

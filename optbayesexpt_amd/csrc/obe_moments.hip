@@ -99,8 +99,9 @@ __global__ __launch_bounds__(kBlock) void moments_pass1(const double* __restrict
     double v[2 + 2 * D];
 #pragma unroll
     for (int k = 0; k < 2 + 2 * D; ++k) v[k] = 0.0;
-    // two particles per trip: their (D + 1) loads each are in flight together (same order of additions
-    // per accumulator as one at a time)
+    // OBE_MOM_UNROLL particles per trip (a compile-time tuning aid, 1 in the product build: with 256
+    // workgroups of waves already keeping (D + 1) loads each in flight, two per trip measured no
+    // faster); any value adds in the same order per accumulator as one at a time
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += OBE_MOM_UNROLL * stride) {
         double wp[OBE_MOM_UNROLL], xi[OBE_MOM_UNROLL][D];

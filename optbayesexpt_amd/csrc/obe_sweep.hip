@@ -63,6 +63,7 @@ struct SweepPlan {
     int tiles_x;       // setting tiles of 64 * spt
     int nchunks;       // particle chunks
     int64_t chunk;     // draws per chunk
+    int nchunks_bound; // >= nchunks of this plan and of every plan with fewer draws (workspace sizing)
 };
 
 // Tuned on MI355X at 65 536 x 1 048 576 (tools/exp_sweep_launch.sh): 8 settings per lane (one
@@ -83,6 +84,9 @@ static SweepPlan plan_sweep(int64_t ns, int64_t nd) {
     if (want > 8) want = (want + 7) / 8 * 8;          // whole groups of 8 chunks: one per XCD
     const int64_t cap = std::max<int64_t>(1, std::min<int64_t>(kMaxChunks, nd / 256));   // >= 64 draws per wave
     p.nchunks = static_cast<int>(std::max<int64_t>(1, std::min(want, cap)));
+    // want and cap never decrease with nd, and rounding the chunk up to whole waves below can only
+    // lower the count again: this value bounds the chunks of every sweep of <= nd draws
+    p.nchunks_bound = p.nchunks;
     p.chunk = (nd + p.nchunks - 1) / p.nchunks;
     p.chunk = (p.chunk + 63) / 64 * 64;
     p.nchunks = static_cast<int>((nd + p.chunk - 1) / p.chunk);
@@ -91,7 +95,9 @@ static SweepPlan plan_sweep(int64_t ns, int64_t nd) {
 
 static int64_t sweep_ws_doubles(int64_t ns, int64_t nd, int nc, int packed_w) {
     const SweepPlan p = plan_sweep(ns, nd);
-    return 2 * (int64_t)p.nchunks * nc * ns      // partial S1, S2
+    // (sized by the monotone bound: the chunk count itself is not monotone in nd after the rounding
+    // of the chunk length, and a sweep of N_DRAWS < n_particles draws runs in the same workspace)
+    return 2 * (int64_t)p.nchunks_bound * nc * ns  // partial S1, S2
            + (int64_t)nc * ns                      // per-setting shift
            + 3 * argmax_slots(ns) + 16             // argmax / kappa partials + scalars
            + nd * packed_w + 8;                    // packed draws
@@ -164,7 +170,7 @@ __device__ __forceinline__ int64_t wave_uniform(int64_t v) {
 template <class M, int SPT, bool SHIFT, bool SAFE = false>
 __global__ __launch_bounds__(kBlock) OBE_SWEEP_OCCUPANCY void sweep_kernel(SweepArgs a) {
     constexpr int NC = M::NC, NXS = M::NXS, NPK = M::NPK, NPKW = packed_width<M>();
-    constexpr bool PAIRS = has_pair_eval<M>::value && SPT >= 2 && !SAFE;
+    constexpr bool PAIRS = SPT >= 2 && (SAFE ? safe_pair_eval<M>::value : has_pair_eval<M>::value);
     // particles per prefetched group: two groups of packed particles live in SGPRs (~100 per wave)
     constexpr int G = PAIRS ? (NPKW <= 4 ? 4 : 2) : (NPKW <= 4 ? 4 : (NPKW <= 8 ? 2 : 1));
     __shared__ double red[kSweepWaves][NC][2][kWave];
@@ -777,6 +783,8 @@ static int prepare_sweep(const obe_model* m, obe_model& mm, const double* d_sett
 using namespace obe;
 
 extern "C" {
+
+int obe_sweep_settings_per_lane(int64_t n_settings) { return plan_sweep(n_settings < 1 ? 1 : n_settings, 1).spt; }
 
 int64_t obe_workspace_bytes(int64_t n_particles, int64_t n_settings, int32_t n_channels, int32_t n_dims) {
     if (n_particles < 1) n_particles = 1;

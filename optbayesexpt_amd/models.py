@@ -37,7 +37,13 @@ class DeviceModel:
     """
 
     def __init__(self, name, model_id, aux, n_read, n_setdims, n_channels, n_consts, numpy_form,
-                 plugin_path=None, safe_sweep=None):
+                 plugin_path=None, safe_sweep=None, range_hint=None):
+        #: optional ``range_hint(settings (S, n), particles (D, N), cons, settings_per_lane)`` ->
+        #: True / False: a cheap host-side *prediction* of whether the fast sweep form stays inside
+        #: its exact range on this grid and cloud.  False makes the first sweep start with the safe
+        #: form instead of discovering it by a poisoned fast attempt; the kernel's own range check
+        #: stays the guarantee either way.
+        self.range_hint = range_hint
         #: path of the per-model plugin library (expression models), else None
         self.plugin_path = plugin_path
         #: the model's fast sweep form poisons batches that leave their exact range and has an
@@ -93,10 +99,24 @@ def lorentzian(n_peaks=1):
         for k in range(n_peaks):
             y = y + a / (((x - pars[k]) / d) ** 2 + 1)
         return y
+
+    def in_range(settings, particles, cons, settings_per_lane):
+        # the combined form inverts the denominators of a lane's settings together: a tree over
+        # prod_k q_k of each, q_k = 1 + ((x - x0_k)/d)^2, range-checked at 1e250 in the kernel
+        # (csrc/obe_models.h: batch_div_ge1); bound every q by the extremes of grid and cloud
+        x, d = np.asarray(settings[0], dtype=np.float64), abs(float(cons[0]))
+        x_lo, x_hi = float(np.min(x)), float(np.max(x))
+        with np.errstate(all="ignore"):
+            decades = 0.0
+            for k in range(n_peaks):
+                lo, hi = float(np.min(particles[k])), float(np.max(particles[k]))
+                t = max(abs(x_hi - lo), abs(x_lo - lo), abs(x_hi - hi), abs(x_lo - hi)) / d
+                decades += np.log10(1.0 + t * t)
+            return bool(settings_per_lane * decades < 245.0)
     # 3 and more peaks: the sweep combines the peaks of an evaluation into one fraction, range-checked,
     # with the peak-by-peak form as its safe twin (csrc/obe_models.h, Lorentz<K>::kCombinePeaks)
     return DeviceModel(f"lorentzian[{n_peaks}]", MODEL_LORENTZ, n_peaks, n_peaks + 2, 1, 1, 1, form,
-                       safe_sweep=n_peaks >= 3)
+                       safe_sweep=n_peaks >= 3, range_hint=in_range if n_peaks >= 3 else None)
 
 
 def line_ab():

@@ -94,6 +94,10 @@ class OptBayesExpt(ParticlePDF):
     #: after this many consecutive sweeps that had to be repeated with the model's safe twin, the fast
     #: attempt is skipped (the range violation is a property of the settings grid)
     SAFE_STREAK = 3
+    #: ... and tried again once every this many sweeps: a posterior that has narrowed, or a cloud
+    #: that was replaced, may be back inside the fast form's range (costs one discarded fast sweep
+    #: per SAFE_RETRY sweeps while it is not)
+    SAFE_RETRY = 64
 
     def __init__(self, measurement_model, setting_values, parameter_samples,
                  constants, n_draws=DEFAULT_N_DRAWS, choke=None,
@@ -152,6 +156,8 @@ class OptBayesExpt(ParticlePDF):
         # settings on the device; a shard sweeps only [s_begin, s_end)
         self._shard = settings_shard
         self._sweep_safe_streak = 0           # consecutive sweeps that had to be repeated with the safe twin
+        self._sweep_safe_run = 0              # sweeps since the fast form was last tried (while pinned to the twin)
+        self._range_hint_key = None           # particles version the model's range_hint last looked at
         if settings_shard is not None:
             self._s_begin, self._s_end = settings_shard.bounds(self._n_settings)
         else:
@@ -474,6 +480,11 @@ class OptBayesExpt(ParticlePDF):
         mode = self.tuning_parameters.get("sweep_shift", "auto")
         shifted = (not full) or mode == "always" or (mode == "auto" and not self._sweep_unshifted)
         safe = False
+        self._apply_range_hint()
+        if self._sweep_safe_streak >= self.SAFE_STREAK:
+            self._sweep_safe_run += 1
+            if self._sweep_safe_run >= self.SAFE_RETRY:     # one fast attempt; a failure pins it again at once
+                self._sweep_safe_streak, self._sweep_safe_run = self.SAFE_STREAK - 1, 0
         if lazy:
             launch(True)
             self.last_sweep = dict(shifted=True, kappa=float("nan"), safe=False)     # kappa was not read back
@@ -508,6 +519,27 @@ class OptBayesExpt(ParticlePDF):
         if want_best:
             return result["best"]
         return None
+
+    def _apply_range_hint(self):
+        """Models with a ``range_hint`` (models.py) predict from the settings grid and the extremes
+        of a cloud the host holds (the prior, set_pdf, user-written particles) whether their fast
+        sweep form stays in range: if not, the sweep starts with the safe form instead of finding
+        out by a poisoned fast attempt (the kernel's range check remains the guarantee; a wrong
+        'in range' costs one repeated sweep, a wrong 'out of range' is retried after SAFE_RETRY)."""
+        hint = getattr(self._device_model, "range_hint", None)
+        pm = self._particles
+        if hint is None or not pm._host_valid or self._range_hint_key == pm.version:
+            return
+        self._range_hint_key = pm.version
+        n_local = self._s_end - self._s_begin
+        if n_local <= 0:
+            return
+        spt = int(self._mlib.cdll.obe_sweep_settings_per_lane(n_local))
+        ok = hint(self.allsettings[:, self._s_begin:self._s_end], pm._host, self.cons, spt)
+        if ok is False:
+            self._sweep_safe_streak, self._sweep_safe_run = self.SAFE_STREAK, 0
+        elif ok is True and self._sweep_safe_streak >= self.SAFE_STREAK:
+            self._sweep_safe_streak = self.SAFE_STREAK - 1      # a new cloud in range: try the fast form again
 
     def yvar_from_parameter_draws(self):
         """Variance of the model output over parameter draws, per setting: (C, N_s)
@@ -690,16 +722,18 @@ class OptBayesExpt(ParticlePDF):
         if bufs is None or bufs[0].numel() != n:
             # scratch of the selection, made once; the chosen index lands in page-locked host memory,
             # which the search kernel writes through its device address (no copy back)
+            # (through the address the device sees it under: obe_host_device_pointer)
+            idx_host = _lib.pinned_array(1, np.int64)
             bufs = self._good_bufs = (torch.empty(n, dtype=torch.float64, device=self._device),
                                       torch.empty(n, dtype=torch.float64, device=self._device),
-                                      _lib.pinned_array(1, np.int64))
-        prob, cdf, idx_host = bufs
+                                      idx_host, _lib.device_ptr_of_pinned(self._lib, idx_host))
+        prob, cdf, idx_host, idx_dev = bufs
         self._lib.call("obe_power_normalize", _ptr(u), n, float(pickiness), _ptr(prob), _ptr(self._ws),
                        self._ws_bytes, self._stream())
         uni = np.atleast_1d(self.rng.random())
         # CDF of the selection probabilities + the search for one uniform (passed by value)
         self._lib.call("obe_draw_indices", _ptr(prob), n, 0, 0, _ptr(cdf), _lib.host_ptr(uni), 1,
-                       _lib.host_ptr(idx_host), None, _ptr(self._ws), self._ws_bytes, self._stream())
+                       idx_dev, None, _ptr(self._ws), self._ws_bytes, self._stream())
         torch.cuda.current_stream(self._device).synchronize()
         self._check_pending_total()
         goodindex = int(idx_host[0])

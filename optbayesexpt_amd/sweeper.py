@@ -182,7 +182,9 @@ class OptBayesExptSweeper(OptBayesExptNoiseParameter):
 
     def sweep_utility(self):
         """Utility of every (start, stop) pair, (n_pairs,) (obe_sweeper.py:122-149)."""
-        return self._sweep_utility_device().cpu().numpy()
+        host = self._sweep_utility_device().cpu().numpy()
+        self._check_pending_total()      # the copy synchronised: a lazy draws-mode sweep's check of sum(w)
+        return host
 
     # ------------------------------------------------------------------ selection
     def opt_setting(self):
@@ -192,6 +194,7 @@ class OptBayesExptSweeper(OptBayesExptNoiseParameter):
         best_idx = np.zeros(1, dtype=np.int64)
         self._lib.call("obe_argmax", _ptr(u), u.numel(), _lib.host_ptr(best), _lib.host_ptr(best_idx),
                        _ptr(self._pair_ws), self._pair_ws.numel() * 8, self._stream())
+        self._check_pending_total()      # (obe_argmax waited for its host results)
         index = int(best_idx[0])
         self.last_setting_index = index
         return self.start_stop_indices[index]
@@ -212,6 +215,7 @@ class OptBayesExptSweeper(OptBayesExptNoiseParameter):
         self._lib.call("obe_draw_indices", _ptr(prob), n, 0, 0, _ptr(cdf), _lib.host_ptr(uni), 1, _ptr(idx), None,
                        _ptr(ws), wsb, self._stream())
         index = int(idx.cpu()[0])
+        self._check_pending_total()      # (the copy synchronised)
         self.last_setting_index = index
         return self.start_stop_indices[index]
 

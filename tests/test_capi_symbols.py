@@ -74,6 +74,19 @@ def test_workspace_and_moment_sizes(lib):
     assert lib.workspace_bytes(1 << 20, 65536, 2, 3) > big
 
 
+def test_workspace_covers_every_smaller_draw_count(lib):
+    """A sweep of N_DRAWS <= n draws runs in the workspace sized for n (the public N_DRAWS attribute
+    can be set to anything): the size must not shrink when the draw count grows, although the
+    number of particle chunks of the plan is not monotone (the chunk length is rounded up to whole
+    waves after the count is chosen)."""
+    g = np.random.default_rng(12)
+    for _ in range(4000):
+        n = int(g.integers(300, 3_000_000))
+        ns = int(g.integers(1, 70_000))
+        nd = int(g.integers(max(1, n // 3), n + 1))
+        assert lib.workspace_bytes(nd, ns, 1, 3) <= lib.workspace_bytes(n, ns, 1, 3), (n, ns, nd)
+
+
 def test_argument_errors_are_reported_not_crashed(lib):
     """NULL pointers / bad sizes come back as status -1 with a message (no launch)."""
     out = np.zeros(4)

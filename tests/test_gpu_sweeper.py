@@ -216,3 +216,27 @@ def test_server_command_surface_is_json_serialisable(hip):
     # 'newrun' builds a fresh engine from the stored constructor arguments (obe_server.py:72-94)
     engine2 = obe.OptBayesExpt(obe.models.lorentzian(), sets, prior, (0.1,), scale=False)
     assert_allclose(engine2.particle_weights, 1.0 / n)
+
+
+@pytest.mark.parametrize("call", ["opt_setting", "good_setting", "sweep_utility"])
+def test_sweeper_validates_the_weights_of_its_draws(hip, call):
+    """A draws-mode sweep nobody waits for defers numpy's validation of p (Generator.choice inside
+    randdraw, particlepdf.py:330) to the caller's own synchronisation; the sweeper's selection
+    methods are such callers: un-normalised weights raise ValueError from them and the generator
+    is back where it was before the draw (numpy validates before it consumes uniforms)."""
+    import optbayesexpt_amd as obe
+    fx = _replay.load_traj("sweeper_opt")
+    o = make(obe, fx)
+    o.rng = np.random.default_rng(11)
+    getattr(o, call)()                                   # a valid cycle first
+    o.particle_weights = np.array(o.particle_weights) * 1.01
+    before = o.rng.bit_generator.state
+    with pytest.raises(ValueError):
+        getattr(o, call)()
+    assert o.rng.bit_generator.state == before
+    w = np.array(o.particle_weights) / 1.01
+    w[3] = np.nan
+    o.particle_weights = w
+    with pytest.raises(ValueError):
+        getattr(o, call)()
+    assert o.rng.bit_generator.state == before

@@ -1046,13 +1046,34 @@ def test_multi_peak_lorentzian_sweep_forms(obe, k):
                 assert not o.last_sweep["safe"], (k, ns, d, o.last_sweep)
             assert_allclose(got, ref, rtol=2e-10, atol=1e-10 * ref.max(), err_msg=f"K={k} ns={ns} d={d}")
     if k >= 3:
-        # a grid that always leaves the range: after SAFE_STREAK repeats the fast attempt is skipped
+        # a grid that always leaves the range: the model's range hint (grid and cloud extremes, on
+        # the host) starts the very first sweep with the safe form ...
         sv = (np.linspace(1.5, 4.5, 4100),)
         o = obe.OptBayesExpt(obe.models.lorentzian(k), sv, prior.copy(), (1e-7,), utility_method="variance_full",
                              auto_resample=False, default_noise_std=500.0)
+        ref = oracle.yvar_full_sweep(fn, oracle.flatten_settings(sv), prior, np.full(n, 1.0 / n), (1e-7,))
+        got = o.yvar_from_parameter_draws()
+        assert o.last_sweep["safe"] and o._sweep_safe_streak == o.SAFE_STREAK and o._sweep_safe_run == 1
+        assert_allclose(got, ref, rtol=2e-10, atol=1e-10 * ref.max())
+        # ... and without the hint the sweep finds out by itself: after SAFE_STREAK repeats the fast
+        # attempt is skipped, and tried again once every SAFE_RETRY sweeps
         o.particle_weights = w
         ref = oracle.yvar_full_sweep(fn, oracle.flatten_settings(sv), prior, w, (1e-7,))
+        o._sweep_safe_streak = o._sweep_safe_run = 0
+        o.SAFE_RETRY = 4
         for rep in range(o.SAFE_STREAK + 2):
             got = o.yvar_from_parameter_draws()
             assert o.last_sweep["safe"] and o._sweep_safe_streak == min(rep + 1, o.SAFE_STREAK)
             assert_allclose(got, ref, rtol=2e-10, atol=1e-10 * ref.max())
+        assert o._sweep_safe_run == 2
+        o.yvar_from_parameter_draws()
+        assert o._sweep_safe_run == 3 and o.last_sweep["safe"]
+        o.yvar_from_parameter_draws()              # the retry: one fast attempt, poisoned again, pinned again
+        assert o._sweep_safe_run == 0 and o._sweep_safe_streak == o.SAFE_STREAK and o.last_sweep["safe"]
+        # a cloud back inside the range (set by the host): the hint re-arms the fast form at once
+        o2 = obe.OptBayesExpt(obe.models.lorentzian(k), sv, prior.copy(), (0.1,), utility_method="variance_full",
+                              auto_resample=False, default_noise_std=500.0)
+        o2._sweep_safe_streak = o2.SAFE_STREAK       # as if pinned by an earlier, wider cloud
+        o2.particles = prior.copy()
+        o2.yvar_from_parameter_draws()
+        assert not o2.last_sweep["safe"] and o2._sweep_safe_streak == 0

@@ -12,7 +12,10 @@ out = os.path.join(ROOT, "tools", "_variants")
 obj = os.path.join(out, "obj_" + name)
 os.makedirs(obj, exist_ok=True)
 stamp = os.path.join(obj, "obe_fingerprint.h")
-open(stamp, "w").write(f'#define OBE_SOURCE_FINGERPRINT "{b._source_fingerprint()}"\n')
+# the extra flags are part of the stamp: a variant can never pass for the product library
+# (the loader compares obe_source_fingerprint() with the hash of the sources alone)
+flag_tag = "+" + "".join(c if c.isalnum() or c in "-_=" else "_" for c in " ".join(extra)) if extra else ""
+open(stamp, "w").write(f'#define OBE_SOURCE_FINGERPRINT "{b._source_fingerprint()}{flag_tag}"\n')
 
 
 def one(src):

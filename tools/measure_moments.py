@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 import torch
 from optbayesexpt_amd import _lib
 if os.environ.get("OBE_VARIANT"):
-    _lib._LIB = _lib.HipLib(os.path.join(ROOT, "tools", "_variants", f"libobe_hip_{os.environ['OBE_VARIANT']}.so"))
+    _lib._LIB = _lib.HipLib(os.path.join(ROOT, "tools", "_variants", f"libobe_hip_{os.environ['OBE_VARIANT']}.so"), allow_variant=True)
 lib = _lib.load()
 P = ctypes.c_void_p
 g = torch.Generator(device="cuda").manual_seed(1)

@@ -13,7 +13,7 @@ import torch
 import bench
 if os.environ.get("OBE_VARIANT"):      # a library built by tools/build_variant.py instead of the product one
     from optbayesexpt_amd import _lib as _l
-    _l._LIB = _l.HipLib(os.path.join(ROOT, "tools", "_variants", f"libobe_hip_{os.environ['OBE_VARIANT']}.so"))
+    _l._LIB = _l.HipLib(os.path.join(ROOT, "tools", "_variants", f"libobe_hip_{os.environ['OBE_VARIANT']}.so"), allow_variant=True)
 from optbayesexpt_amd.particlepdf import _ptr
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
