@@ -224,15 +224,16 @@ def test_long_full_sweep_trajectory_matches_oracle(obe):
     assert a.rng.bit_generator.state == b.rng.bit_generator.state      # the streams stayed in step
 
 
-def test_large_cloud_16m_particles_every_kernel_against_numpy():
-    """tools/large_cloud.py at 2**24 particles (16x the BASELINE cloud; the tool has been run at
-    2**26 and 2**28, profiles/r03_large_cloud_*.txt): sweep, update, moments, resample indices
+def test_large_cloud_4m_particles_every_kernel_against_numpy():
+    """tools/large_cloud.py at 2**22 particles (4x the BASELINE cloud, sized for the suite's time budget:
+    the host-side NumPy checks dominate; the tool has been run at 2**24, 2**26 and 2**28,
+    profiles/r03_large_cloud_*.txt): sweep, update, moments, resample indices
     (against np.cumsum in float64 and in extended precision) and the moved particles, each checked
     against NumPy on the host — 64-bit indexing and grid caps in every kernel."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "large_cloud.py"), "24", "1024"],
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "large_cloud.py"), "22", "1024"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "LARGE CLOUD OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

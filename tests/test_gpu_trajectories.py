@@ -191,3 +191,48 @@ def test_reference_inference_experiment(hip):
                                                      np.asarray(o.particle_weights), 1.0)))
     assert verdicts[0] == verdicts[1]
     assert 0.8 * n_runs <= sum(verdicts[0]) <= n_runs
+
+
+@pytest.mark.parametrize("selection,device_rng", [("good", True), ("optimal", False)])
+def test_long_run_stays_in_lock_step_with_the_oracle(hip, selection, device_rng):
+    """1200 cycles of the find_peak demo loop (good_setting(pickiness=19) / opt_setting +
+    pdf_update + std, 30 weighted draws, ~10 resamples; demos/find_peak/sequentialLorentzian.py:
+    129-150) on the device and in the oracle class, same seeds: the same setting index and the
+    same resample decision in EVERY cycle, and the posterior moments still agree to 1e-9 at the
+    end — rounding differences do not accumulate into a different experiment."""
+    import warnings
+    import optbayesexpt_amd as obe
+    import oracle
+    from oracle import models as omodels
+    g = np.random.default_rng(31)
+    n, ns, cycles = 20000, 201, 1200
+    prior = np.array([g.uniform(2, 4, n), g.uniform(-2000, -400, n), g.normal(50000, 1000, n)])
+    sv = (np.linspace(1.5, 4.5, ns),)
+    true, cons, sigma = (3.05, -1000.0, 50000.0), (0.1,), 500.0
+    a = obe.OptBayesExpt(obe.models.lorentzian(), sv, prior.copy(), cons, scale=False)
+    b = oracle.OracleOptBayesExpt(omodels.lorentzian, sv, prior.copy(), cons, scale=False)
+    a.tuning_parameters["device_rng"] = device_rng
+    a.rng, b.rng = np.random.default_rng(8), np.random.default_rng(8)
+    sim = np.random.default_rng(9)
+    resamples = 0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        for c in range(cycles):
+            if selection == "good":
+                xa, xb = a.good_setting(pickiness=19), b.good_setting(pickiness=19)
+            else:
+                xa, xb = a.opt_setting(), b.opt_setting()
+            assert a.last_setting_index == b.last_setting_index, f"cycle {c}: settings differ"
+            y = float(omodels.lorentzian(xb, true, cons)) + sigma * sim.standard_normal()
+            a.pdf_update((xa, y, sigma))
+            b.pdf_update((xb, y, sigma))
+            assert bool(a.just_resampled) == bool(b.just_resampled), f"cycle {c}: resample decisions differ"
+            resamples += bool(b.just_resampled)
+            sa, sb = a.std(), b.std()
+            if c % 100 == 99:
+                np.testing.assert_allclose(sa, sb, rtol=1e-7, err_msg=f"cycle {c}")
+    assert resamples >= 5
+    assert a.rng.bit_generator.state == b.rng.bit_generator.state
+    np.testing.assert_allclose(a.mean(), b.mean(), rtol=1e-9)
+    np.testing.assert_allclose(a.covariance(), b.covariance(), rtol=1e-7, atol=1e-9 * np.abs(b.covariance()).max())
+    np.testing.assert_allclose(a.particle_weights, b.particle_weights, rtol=1e-8, atol=1e-12 * b.particle_weights.max())
