@@ -113,6 +113,19 @@ int obe_bayes_update_model(const obe_model* m,
                            int32_t n_lik_channels, double choke,
                            void* d_ws, int64_t ws_bytes, double* h_out, void* stream);
 
+/* obe_bayes_update_model followed by the first pass of obe_moments on the updated weights, with the
+ * normalisation and the moment sums fused into one pass over the cloud (pdf_update() of
+ * obe_base.py:340-399 + mean()/std() of particlepdf.py:173-214, which every caller's cycle asks for
+ * next, and the sweep's per-setting shift).  d_moments receives the K3 block without the covariance
+ * (layout of obe_moments, bit-identical to calling it afterwards); h_out (nullable; sync) receives
+ * [0] = sum t, [1] = sum w'^2, [2 .. 2 + 2 + 4 n_params) = that block.  n_dims = m->n_params. */
+int obe_bayes_update_model_moments(const obe_model* m,
+                                   const double* d_particles, int64_t ld_p, int64_t n_particles,
+                                   double* d_weights,
+                                   const double* h_setting, const double* h_y_meas,
+                                   const double* h_sigma, const int32_t* h_noise_rows,
+                                   int32_t n_lik_channels, double choke, double* d_moments,
+                                   void* d_ws, int64_t ws_bytes, double* h_out, void* stream);
 /* A whole sweep of measurements (demos/sweeper/obe_sweeper.py:86-100: one pdf_update per point,
  * each followed by the resample test of particlepdf.py:236-258) enqueued back to back, no
  * host round trip between the points.  h_settings (n_points, OBE_MAX_SETDIMS) and h_y_meas

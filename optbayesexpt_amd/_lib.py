@@ -56,6 +56,8 @@ _SIGNATURES = {
     "obe_workspace_bytes": (c_int64, [c_int64, c_int64, c_int32, c_int32]),
     "obe_bayes_update_model": (c_int, [ctypes.POINTER(ObeModelStruct), _P, c_int64, c_int64, _P, _P, _P, _P, _P,
                                        c_int32, c_double, _P, c_int64, _P, _P]),
+    "obe_bayes_update_model_moments": (c_int, [ctypes.POINTER(ObeModelStruct), _P, c_int64, c_int64, _P, _P, _P, _P, _P,
+                                               c_int32, c_double, _P, _P, c_int64, _P, _P]),
     "obe_bayes_update_sweep": (c_int, [ctypes.POINTER(ObeModelStruct), _P, c_int64, c_int64, _P, _P, _P, _P, _P,
                                        c_int32, c_double, c_int64, c_int32, c_double, _P, c_int64, _P, _P]),
     "obe_bayes_update_y": (c_int, [_P, c_int64, c_int32, _P, c_int64, c_int64, _P, _P, _P, _P, c_int32,
@@ -110,7 +112,8 @@ _SIGNATURES = {
 
 
 # entry points whose code depends on the model: a plugin library serves these
-MODEL_ENTRY_POINTS = ("obe_model_validate", "obe_workspace_bytes", "obe_sweep_settings_per_lane", "obe_bayes_update_model", "obe_bayes_update_sweep",
+MODEL_ENTRY_POINTS = ("obe_model_validate", "obe_workspace_bytes", "obe_sweep_settings_per_lane", "obe_bayes_update_model",
+                      "obe_bayes_update_model_moments", "obe_bayes_update_sweep",
                       "obe_eval_over_particles",
                       "obe_eval_over_settings", "obe_sweep_utility", "obe_sweep_kernel_time", "obe_sweep_timing",
                       "obe_eval_draws")

@@ -1,0 +1,176 @@
+// K3 building blocks shared by the moment kernels (obe_moments.hip) and the Bayes update that
+// produces the first moments of its posterior in the same pass (obe_update.hip): block partial
+// sums by wave reduce-scatter, the single-workgroup fold, and the per-particle accumulation and
+// the derivation of mean / std — one definition each, so that both routes give the same bits.
+#pragma once
+
+#include <algorithm>
+
+#include "obe_common.h"
+
+namespace obe {
+
+#ifndef OBE_MOM_BLOCKS
+#define OBE_MOM_BLOCKS 256
+#endif
+// grid cap for the moment passes: one workgroup per CU.  The streaming itself is as fast with 1024
+// (12-15 us at D = 10, 524 288 particles either way), but every workgroup ends with a block
+// reduction of up to 136 values and leaves a row of partials for the single-workgroup fold.
+constexpr int kMomBlocks = OBE_MOM_BLOCKS;
+#ifndef OBE_MOM_UNROLL
+#define OBE_MOM_UNROLL 1
+#endif
+
+// Wave-wide sums of C values (C a power of two <= 64) by reduce-scatter: at every level of the
+// butterfly a lane hands half of its values to its partner and adds the partner's copies of the half
+// it keeps, so the tree over the 64 lanes costs C - 1 exchanges (+ one per remaining level once a
+// single value is left) instead of 6 C.  The pairing (lane ^ 32, ^ 16, ...) and hence the association
+// of every sum is that of wave_sum(): bit-identical totals.  Afterwards v[0] of lane L holds the total
+// of value  reduce_scatter_index<C>(L).
+template <int C, int O>
+__device__ __forceinline__ void wave_reduce_scatter(double* v, int lane) {
+    if constexpr (O >= 1) {
+        if constexpr (C > 1) {
+            const bool upper = (lane & O) != 0;
+#pragma unroll
+            for (int i = 0; i < C / 2; ++i) {
+                const double send = upper ? v[i] : v[i + C / 2];
+                const double keep = upper ? v[i + C / 2] : v[i];
+                v[i] = keep + __shfl_xor(send, O, kWave);
+            }
+            wave_reduce_scatter<C / 2, O / 2>(v, lane);
+        } else {
+            v[0] = v[0] + __shfl_xor(v[0], O, kWave);
+            wave_reduce_scatter<1, O / 2>(v, lane);
+        }
+    }
+}
+template <int C>
+__device__ __forceinline__ int reduce_scatter_index(int lane) {
+    int idx = 0, c = C;
+    for (int o = kWave / 2; o >= 1 && c > 1; o >>= 1) {
+        c >>= 1;
+        if (lane & o) idx += c;
+    }
+    return idx;
+}
+constexpr int pow2_ceil(int n) { return n <= 1 ? 1 : 2 * pow2_ceil((n + 1) / 2); }
+
+// The NV block sums with ONE barrier: every wavefront reduces its values (in groups of up to 64, by
+// reduce-scatter) and parks the totals in LDS, then thread k adds the wave sums of value k in wave
+// order — the same arithmetic as NV calls of block_sum (shuffle tree, then the waves in order).
+// (NV separate shuffle trees cost ~13 000 cycles per wave at NV = 55: the epilogue, not the
+// streaming, set the duration of the covariance pass.)
+template <int NV, int G0>
+__device__ __forceinline__ void reduce_value_groups(const double (&v)[NV], double* __restrict__ red_row, int lane) {
+    if constexpr (G0 < NV) {
+        constexpr int CNT = NV - G0 < kWave ? NV - G0 : kWave;      // values in this group
+        constexpr int C = pow2_ceil(CNT);
+        double t[C];
+#pragma unroll
+        for (int i = 0; i < C; ++i) t[i] = i < CNT ? v[G0 + (i < CNT ? i : 0)] : 0.0;
+        wave_reduce_scatter<C, kWave / 2>(t, lane);
+        const int idx = reduce_scatter_index<C>(lane);
+        if ((lane & (kWave / C - 1)) == 0 && idx < CNT) red_row[G0 + idx] = t[0];      // one lane per value
+        reduce_value_groups<NV, G0 + kWave>(v, red_row, lane);
+    }
+}
+
+template <int NV>
+__device__ __forceinline__ void store_block_partials(double (&v)[NV], double* __restrict__ partials) {
+    constexpr int NW = kBlock / kWave;
+    __shared__ double red[NW][NV];
+    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+    reduce_value_groups<NV, 0>(v, red[wid], lane);
+    __syncthreads();
+    for (int k = threadIdx.x; k < NV; k += kBlock) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) s += red[i][k];
+        partials[(int64_t)blockIdx.x * NV + k] = s;
+    }
+}
+
+// One particle's contribution to  [0] sum w, [1] sum w*w, [2+i] sum x_i*w, [2+D+i] sum (x_i*x_i)*w
+template <int D>
+__device__ __forceinline__ void accumulate_first_moments(double (&v)[2 + 2 * D], double wp, const double (&xi)[D]) {
+    v[0] += wp;
+    v[1] += wp * wp;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        v[2 + i] += xi[i] * wp;
+        v[2 + D + i] += (xi[i] * xi[i]) * wp;
+    }
+}
+
+// raw[k] = sum_b partials[b*nv + k]: one wavefront per value (strided partial sums, then the
+// shuffle tree: a fixed order).  One workgroup of 16 waves; a wave takes four values at a time and
+// issues their loads together — the partials come straight from HBM / another XCD's L2, and a wave
+// that walked its values one after the other spent ~1.5 us of latency on each (19 us for the 55
+// values of a 10-parameter covariance).  `vals` in LDS.
+constexpr int kFoldThreads = 1024;
+constexpr int kFoldBatch = 4;
+__device__ __forceinline__ void fold_values_block(const double* __restrict__ partials, int nb, int nv,
+                                                  double* __restrict__ vals) {
+    constexpr int NW = kFoldThreads / kWave;
+    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+    for (int k0 = wid; k0 < nv; k0 += NW * kFoldBatch) {
+        double s[kFoldBatch];
+#pragma unroll
+        for (int u = 0; u < kFoldBatch; ++u) s[u] = 0.0;
+        for (int b = lane; b < nb; b += kWave) {
+#pragma unroll
+            for (int u = 0; u < kFoldBatch; ++u) {
+                const int k = k0 + u * NW;
+                if (k < nv) s[u] += partials[(int64_t)b * nv + k];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kFoldBatch; ++u) s[u] = wave_sum(s[u]);
+#pragma unroll
+        for (int u = 0; u < kFoldBatch; ++u) {
+            const int k = k0 + u * NW;
+            if (lane == 0 && k < nv) vals[k] = s[u];
+        }
+    }
+    __syncthreads();
+}
+
+constexpr int kMaxMomentValues = OBE_MAX_DIMS * (OBE_MAX_DIMS + 1) / 2;     // >= 2 + 2 D
+
+// Thread i < d: mean, m1, m2, std of parameter i from the folded sums raw[] (2 + 2 d values), into the
+// K3 block `out` ([0]=W [1]=W2 [2..) mean [2+D..) m1 [2+2D..) m2 [2+3D..) std) and, if not NULL, `host`
+// (the device view of the caller's page-locked copy).  Thread 0 also stores W and W2.
+__device__ __forceinline__ void derive_first_moments(const double* raw, int d, double* __restrict__ out,
+                                                     double* __restrict__ host) {
+    const int i = threadIdx.x;
+    if (i == 0) {
+        out[0] = raw[0];
+        out[1] = raw[1];
+        if (host) {
+            host[0] = raw[0];
+            host[1] = raw[1];
+        }
+    }
+    if (i < d) {
+        const double m1 = raw[2 + i], m2 = raw[2 + d + i];
+        const double mean = m1 / raw[0];             // np.average: sum(x w) / sum(w)
+        const double sd = sqrt(m2 - m1 * m1);        // particlepdf.py:211-214
+        out[2 + i] = mean;
+        out[2 + d + i] = m1;
+        out[2 + 2 * d + i] = m2;
+        out[2 + 3 * d + i] = sd;
+        if (host) {
+            host[2 + i] = mean;
+            host[2 + d + i] = m1;
+            host[2 + 2 * d + i] = m2;
+            host[2 + 3 * d + i] = sd;
+        }
+    }
+}
+
+inline int moment_blocks(int64_t n) {
+    return static_cast<int>(std::min<int64_t>(kMomBlocks, (n + kBlock - 1) / kBlock));
+}
+
+}  // namespace obe

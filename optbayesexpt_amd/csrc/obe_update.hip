@@ -18,6 +18,7 @@
 
 #include "obe_common.h"
 #include "obe_models.h"
+#include "obe_moments.h"
 
 namespace obe {
 
@@ -161,6 +162,61 @@ __global__ __launch_bounds__(kBlock) void normalize_kernel(const double* __restr
     }
     const double s = block_sum(acc, red);
     if (threadIdx.x == 0) partials_out[blockIdx.x] = s;
+}
+
+// pass B fused with K3's first pass (obe_bayes_update_model_moments): normalise by the re-folded
+// total and, in the same sweep over the cloud, accumulate the first moments of the NEW weights.
+// Grid, per-particle arithmetic and block reductions are those of moments_pass1, so the moments
+// are bit-identical to obe_moments() called on the updated weights; the weights themselves are
+// the ones normalize_kernel writes.  One launch less per cycle and no second read of the weights
+// (every cycle needs the moments: the sweep's shift, mean(), std(), the noise-parameter variance).
+template <int D>
+__global__ __launch_bounds__(kBlock) void normalize_moments_kernel(const double* __restrict__ partials_in,
+                                                                   int n_partials, const double* __restrict__ x,
+                                                                   int64_t ld, int64_t n, double* __restrict__ weights,
+                                                                   double* __restrict__ partials_w2,
+                                                                   double* __restrict__ partials_mom) {
+    __shared__ double red[kBlock / kWave];
+    const double total = block_sum_array(partials_in, n_partials, red);
+    double v[2 + 2 * D];
+#pragma unroll
+    for (int k = 0; k < 2 + 2 * D; ++k) v[k] = 0.0;
+    double acc = 0.0;
+    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (int64_t)gridDim.x * kBlock) {
+        double xi[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) xi[i] = x[(int64_t)i * ld + p];
+        const double w = nan_to_num(weights[p] / total);
+        weights[p] = w;
+        acc += nan_to_num(w * w);
+        accumulate_first_moments<D>(v, w, xi);
+    }
+    const double s = block_sum(acc, red);
+    if (threadIdx.x == 0) partials_w2[blockIdx.x] = s;
+    store_block_partials<2 + 2 * D>(v, partials_mom);
+}
+
+// ... and its fold: {sum t, sum w'^2} + the K3 block (mean, m1, m2, std), to the device copies and,
+// when the caller's h_out is page-locked, straight to the host: [0] sum t, [1] sum w'^2, [2..) K3 block
+__global__ __launch_bounds__(kFoldThreads) void fold_update_moments_kernel(
+    const double* __restrict__ pa, int n_pa, const double* __restrict__ pb, int n_pb,
+    const double* __restrict__ partials_mom, int d, double* __restrict__ scalars, double* __restrict__ mom_out,
+    double* __restrict__ host_out) {
+    __shared__ double raw[kMaxMomentValues];
+    __shared__ double red[kFoldThreads / kWave];
+    fold_values_block(partials_mom, n_pb, 2 + 2 * d, raw);
+    derive_first_moments(raw, d, mom_out, host_out ? host_out + 2 : nullptr);
+    const double a = block_sum_array(pa, n_pa, red);
+    __syncthreads();
+    const double b = block_sum_array(pb, n_pb, red);
+    if (threadIdx.x == 0) {
+        scalars[0] = a;
+        scalars[1] = b;
+        if (host_out) {
+            host_out[0] = a;
+            host_out[1] = b;
+        }
+    }
 }
 
 // pass C: scalars[0] = sum t, scalars[1] = sum w'^2
@@ -373,13 +429,16 @@ struct UpdateWs {
     double* pa;
     double* pb;
     double* scalars;
+    double* mom;        // block partials of the fused first moments (moments_dims > 0 only)
 };
-static int carve_update_ws(void* d_ws, int64_t ws_bytes, UpdateWs& w) {
-    const int64_t need = (2 * (int64_t)kMaxBlocks + 8) * sizeof(double);
+static int carve_update_ws(void* d_ws, int64_t ws_bytes, UpdateWs& w, int moments_dims = 0) {
+    const int64_t mom = moments_dims > 0 ? (int64_t)kMomBlocks * (2 + 2 * moments_dims) : 0;
+    const int64_t need = (2 * (int64_t)kMaxBlocks + 8 + mom) * sizeof(double);
     if (!d_ws || ws_bytes < need) return bad_arg("workspace too small");
     w.pa = static_cast<double*>(d_ws);
     w.pb = w.pa + kMaxBlocks;
     w.scalars = w.pb + kMaxBlocks;
+    w.mom = w.scalars + 8;
     return 0;
 }
 
@@ -429,6 +488,62 @@ int obe_bayes_update_model(const obe_model* m, const double* d_particles, int64_
     });
     if (rc) return rc;
     return finish_update(w, nb, n_particles, d_weights, h_out, st);
+}
+
+int obe_bayes_update_model_moments(const obe_model* m, const double* d_particles, int64_t ld_p, int64_t n_particles,
+                                   double* d_weights, const double* h_setting, const double* h_y_meas,
+                                   const double* h_sigma, const int32_t* h_noise_rows, int32_t n_lik_channels,
+                                   double choke, double* d_moments, void* d_ws, int64_t ws_bytes, double* h_out,
+                                   void* stream) {
+    if (!m || !d_particles || !d_weights || !d_moments || n_particles <= 0)
+        return bad_arg("obe_bayes_update_model_moments: bad pointer/size");
+    obe_model mm = *m;
+    if (int rc = obe_model_validate(&mm)) return rc;
+    if (n_lik_channels > mm.n_channels) return bad_arg("n_lik_channels exceeds model channels");
+    const int d = mm.n_params;
+    if (d < 1 || d > OBE_MAX_DIMS) return bad_arg("obe_bayes_update_model_moments: n_params must be 1..16");
+    LikArgs la;
+    if (int rc = fill_lik_args(la, h_y_meas, h_sigma, h_noise_rows, n_lik_channels, choke, mm.n_params)) return rc;
+    UpdateWs w;
+    if (int rc = carve_update_ws(d_ws, ws_bytes, w, d)) return rc;
+    SettingArg sa{};
+    for (int k = 0; k < mm.n_setdims; ++k) sa.x[k] = h_setting ? h_setting[k] : 0.0;
+    hipStream_t st = as_stream(stream);
+    const int nb = update_blocks(n_particles);
+    int rc = dispatch_model(mm, [&](auto M) -> int {
+        using Model = decltype(M);
+        update_model_kernel<Model><<<nb, kBlock, 0, st>>>(mm, sa, la, d_particles, ld_p, n_particles, d_weights, w.pa,
+                                                          SweepCtl{});
+        OBE_CHECK_LAUNCH("update_model_kernel");
+        return 0;
+    });
+    if (rc) return rc;
+    const int nm = moment_blocks(n_particles);
+#define OBE_UPD_MOM_CASE(DD)                                                                                       \
+    case DD:                                                                                                       \
+        normalize_moments_kernel<DD><<<nm, kBlock, 0, st>>>(w.pa, nb, d_particles, ld_p, n_particles, d_weights,  \
+                                                            w.pb, w.mom);                                          \
+        break;
+    switch (d) {
+        OBE_UPD_MOM_CASE(1) OBE_UPD_MOM_CASE(2) OBE_UPD_MOM_CASE(3) OBE_UPD_MOM_CASE(4) OBE_UPD_MOM_CASE(5)
+        OBE_UPD_MOM_CASE(6) OBE_UPD_MOM_CASE(7) OBE_UPD_MOM_CASE(8) OBE_UPD_MOM_CASE(9) OBE_UPD_MOM_CASE(10)
+        OBE_UPD_MOM_CASE(11) OBE_UPD_MOM_CASE(12) OBE_UPD_MOM_CASE(13) OBE_UPD_MOM_CASE(14) OBE_UPD_MOM_CASE(15)
+        OBE_UPD_MOM_CASE(16)
+    }
+#undef OBE_UPD_MOM_CASE
+    OBE_CHECK_LAUNCH("normalize_moments_kernel");
+    double* hv = static_cast<double*>(device_view_of_host(h_out));
+    fold_update_moments_kernel<<<1, kFoldThreads, 0, st>>>(w.pa, nb, w.pb, nm, w.mom, d, w.scalars, d_moments, hv);
+    OBE_CHECK_LAUNCH("fold_update_moments_kernel");
+    if (h_out) {
+        if (!hv) {
+            OBE_HIP_TRY(hipMemcpyAsync(h_out, w.scalars, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+            OBE_HIP_TRY(hipMemcpyAsync(h_out + 2, d_moments, (2 + 4 * (int64_t)d) * sizeof(double),
+                                       hipMemcpyDeviceToHost, st));
+        }
+        OBE_HIP_TRY(hipStreamSynchronize(st));
+    }
+    return 0;
 }
 
 int obe_bayes_update_sweep(const obe_model* m, const double* d_particles, int64_t ld_p, int64_t n_particles,

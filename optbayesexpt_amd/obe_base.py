@@ -311,12 +311,20 @@ class OptBayesExpt(ParticlePDF):
             w = self._weights.tensor()
             if par.shape[1] != w.shape[0]:
                 raise ValueError("parameters and particle_weights have different lengths")
-            self._mlib.call("obe_bayes_update_model", self._model_struct, _ptr(par), par.shape[1],
-                           self.n_particles, _ptr(w), _lib.host_ptr(self._setting_array(onesetting)),
-                           _lib.host_ptr(yy), None if s is None else _lib.host_ptr(s),
-                           None if rows is None else _lib.host_ptr(rows), n, self._choke_value(),
-                           _ptr(self._ws), self._ws_bytes, _lib.host_ptr(self._host_out), self._stream())
-            self._after_weight_update(self._host_out[1])
+            args = (self._model_struct, _ptr(par), par.shape[1],
+                    self.n_particles, _ptr(w), _lib.host_ptr(self._setting_array(onesetting)),
+                    _lib.host_ptr(yy), None if s is None else _lib.host_ptr(s),
+                    None if rows is None else _lib.host_ptr(rows), n, self._choke_value())
+            if self._parameters is self._particles and self.tuning_parameters.get("fused_moments", True):
+                # ... and the first moments of the posterior in the same pass over the cloud: the next
+                # sweep's shift, mean(), std() and the noise-parameter variance need no launch of their own
+                self._mlib.call("obe_bayes_update_model_moments", *args, _ptr(self._moments_dev), _ptr(self._ws),
+                                self._ws_bytes, _lib.host_ptr(self._upd_host), self._stream())
+                self._after_weight_update(self._upd_host[1], moments_fresh=True)
+            else:       # (a stale `parameters` alias after set_pdf, obe_base.py:185,395: not the cloud the moments describe)
+                self._mlib.call("obe_bayes_update_model", *args, _ptr(self._ws), self._ws_bytes,
+                                _lib.host_ptr(self._host_out), self._stream())
+                self._after_weight_update(self._host_out[1])
         else:
             if y_model_data is None:
                 y_model_data = self.eval_over_all_parameters(onesetting)

@@ -107,7 +107,10 @@ class ParticlePDF:
         self._ws = torch.empty(nbytes // 8 + 1, dtype=torch.float64, device=self._device)
         self._ws_bytes = self._ws.numel() * 8
         self._moments_dev = torch.zeros(self._lib.moments_len(d), dtype=torch.float64, device=self._device)
-        self._moments_host = _lib.pinned_array(self._lib.moments_len(d))
+        # page-locked landing zone of the fused update: [0] sum t, [1] sum w'^2, [2:] the K3 block —
+        # the host copy of the moments is that tail, whichever call fills it
+        self._upd_host = _lib.pinned_array(2 + self._lib.moments_len(d))
+        self._moments_host = self._upd_host[2:]
         self._mom_host_key = None      # (particles version, weights version, has_cov) of the host copy
         self._mom_dev_key = None       # same, for the device copy
         self._cdf_dev = torch.empty(n, dtype=torch.float64, device=self._device)
@@ -233,8 +236,10 @@ class ParticlePDF:
                        self._ws_bytes, _lib.host_ptr(self._host_out), self._stream())
         self._after_weight_update(self._host_out[1])
 
-    def _after_weight_update(self, sum_w2):
+    def _after_weight_update(self, sum_w2, moments_fresh=False):
         self._weights.mark_device_written()
+        if moments_fresh:     # the update also left the first moments of the new weights (device and host)
+            self._mom_host_key = self._mom_dev_key = (self._particles.version, self._weights.version, False)
         self._sumsq, self._sumsq_key = float(sum_w2), self._weights.version
         if self.tuning_parameters["auto_resample"]:
             self.resample_test()

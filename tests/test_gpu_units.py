@@ -1077,3 +1077,46 @@ def test_multi_peak_lorentzian_sweep_forms(obe, k):
         o2.particles = prior.copy()
         o2.yvar_from_parameter_draws()
         assert not o2.last_sweep["safe"] and o2._sweep_safe_streak == 0
+
+
+@pytest.mark.parametrize("k,noise,n", [(1, False, 70001), (7, True, 30011), (1, False, 300)])
+def test_fused_update_moments_is_update_then_moments(obe, k, noise, n):
+    """pdf_update() normalises the weights and accumulates the first moments of the posterior in one
+    pass (obe_bayes_update_model_moments): same weights, and mean / std / the K3 block bit for bit
+    what obe_bayes_update_model followed by obe_moments gives; N_eff to rounding (its partial sums are
+    grouped differently).  mean() and std() afterwards launch nothing."""
+    g = np.random.default_rng(500 + k)
+    rows = [g.uniform(2, 4, (k, n)), g.uniform(400, 2000, (1, n)), g.normal(500, 1000, (1, n))]
+    if noise:
+        rows.append(g.exponential(500, (1, n)) + 1.0)
+    prior = np.vstack(rows)
+    w = g.exponential(1.0, n)
+    w /= w.sum()
+    sv = (np.linspace(1.5, 4.5, 300),)
+    out = {}
+    for fused in (True, False):
+        if noise:
+            o = obe.OptBayesExptNoiseParameter(obe.models.lorentzian(k), sv, prior.copy(), (0.1,), scale=False,
+                                               noise_parameter_index=k + 2, auto_resample=False)
+            rec = ((2.9,), 1400.0)
+        else:
+            o = obe.OptBayesExpt(obe.models.lorentzian(k), sv, prior.copy(), (0.1,), scale=False, auto_resample=False)
+            rec = ((2.9,), 1400.0, 300.0)
+        o.tuning_parameters["fused_moments"] = fused
+        o.particle_weights = w
+        o.pdf_update(rec)
+        key = (o._particles.version, o._weights.version)
+        assert (o._mom_host_key is not None and o._mom_host_key[:2] == key) is fused
+        block = np.array(o._moments(False)[:2 + 4 * o.n_dims])
+        out[fused] = (np.array(o.particle_weights), o.mean(), o.std(), block, 1.0 / o._sum_w2(), o.covariance())
+    for a, b in zip(out[True][:4], out[False][:4]):
+        assert_array_equal(a, b)
+    assert_allclose(out[True][4], out[False][4], rtol=1e-14)
+    assert_array_equal(out[True][5], out[False][5])            # the covariance pass starts from the same mean
+    fn = omodels.multi_lorentzian(k) if k > 1 else omodels.lorentzian
+    y = fn((2.9,), prior, (0.1,))
+    sigma = prior[k + 2] if noise else 300.0
+    w1 = oracle.normalized_product(w, oracle.gauss_likelihood(y, 1400.0, sigma))
+    assert_allclose(out[True][0], w1, rtol=1e-10, atol=1e-13 * w1.max())
+    assert_allclose(out[True][1], oracle.weighted_mean(prior, w1), rtol=1e-10)
+    assert_allclose(out[True][4], oracle.effective_particles(w1), rtol=1e-10)
