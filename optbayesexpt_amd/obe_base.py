@@ -47,10 +47,18 @@ UTILITY_METHODS = ["variance_approx", "pseudo_utility", "full_kld_utility", "max
 SELECTION_METHODS = ["optimal", "good", "random"]
 
 
+_OVERRIDDEN = {}
+
+
 def _overridden(obj, name, *owners):
-    """True if ``obj``'s class replaces method ``name`` defined by one of ``owners``."""
-    impl = getattr(type(obj), name)
-    return all(impl is not getattr(o, name) for o in owners)
+    """True if ``obj``'s class replaces method ``name`` defined by one of ``owners`` (answered once
+    per class: the hooks are looked up several times in every cycle)."""
+    key = (type(obj), name, owners)
+    hit = _OVERRIDDEN.get(key)
+    if hit is None:
+        impl = getattr(type(obj), name)
+        hit = _OVERRIDDEN[key] = all(impl is not getattr(o, name) for o in owners)
+    return hit
 
 
 class _LazyState:
@@ -155,6 +163,12 @@ class OptBayesExpt(ParticlePDF):
 
         # settings on the device; a shard sweeps only [s_begin, s_end)
         self._shard = settings_shard
+        # the record of a measurement as the library takes it (filled in place, addresses made once)
+        self._hargs = _lib.HostArgs()
+        self._rec_x = self._hargs.keep(np.zeros(_lib.OBE_MAX_SETDIMS))
+        self._rec_y = self._hargs.keep(np.zeros(_lib.OBE_MAX_CHANNELS))
+        self._rec_s = self._hargs.keep(np.ones(_lib.OBE_MAX_CHANNELS))
+        self._hargs.keep(self._host_out)
         self._sweep_safe_streak = 0           # consecutive sweeps that had to be repeated with the safe twin
         self._sweep_safe_run = 0              # sweeps since the fast form was last tried (while pinned to the twin)
         self._range_hint_key = None           # particles version the model's range_hint last looked at
@@ -169,6 +183,7 @@ class OptBayesExpt(ParticlePDF):
         self._utility_dev = torch.zeros(max(n_local, 1), dtype=torch.float64, device=self._device)
         self._noise_dev = torch.zeros(self.n_channels, dtype=torch.float64, device=self._device)
         self._noise_cache = None
+        self._noise_src = None        # bytes of the default_noise_std the cached device value was made from
         self._sweep_unshifted = False      # see _sweep_device: adaptive variance shift
         self._alloc_scratch()
 
@@ -267,26 +282,31 @@ class OptBayesExpt(ParticlePDF):
         return y.cpu().numpy()
 
     def _setting_array(self, onesettingset):
-        st = np.zeros(_lib.OBE_MAX_SETDIMS)
+        """The setting of a record, zero-padded to OBE_MAX_SETDIMS — in this object's record buffer:
+        valid until the next call (every user passes it on or copies it at once)."""
+        st = self._rec_x
         vals = np.asarray(onesettingset, dtype=np.float64).reshape(-1)
-        st[:min(vals.size, _lib.OBE_MAX_SETDIMS)] = vals[:_lib.OBE_MAX_SETDIMS]
+        k = min(vals.size, _lib.OBE_MAX_SETDIMS)
+        st[:k] = vals[:k]
+        st[k:] = 0.0
         return st
 
     # -------------------------------------------------------------- pdf_update
     def _record_channels(self, y_meas, sigma):
         """zip(y_model, atleast_1d(y_meas), atleast_1d(sigma)) truncation
         (obe_base.py:453-455)."""
-        y = np.atleast_1d(np.asarray(y_meas, dtype=np.float64)).reshape(-1)
+        y = np.asarray(y_meas, dtype=np.float64).reshape(-1)
         n = min(self.n_channels, y.size)
         s = None
         if sigma is not None:
-            s = np.atleast_1d(np.asarray(sigma, dtype=np.float64)).reshape(-1)
-            n = min(n, s.size)
-            pad = np.ones(_lib.OBE_MAX_CHANNELS)
-            pad[:n] = s[:n]
-            s = pad
-        yy = np.zeros(_lib.OBE_MAX_CHANNELS)
+            sg = np.asarray(sigma, dtype=np.float64).reshape(-1)
+            n = min(n, sg.size)
+            s = self._rec_s                      # (record buffers: valid until the next call)
+            s[:n] = sg[:n]
+            s[n:] = 1.0
+        yy = self._rec_y
         yy[:n] = y[:n]
+        yy[n:] = 0.0
         return n, yy, s
 
     def _likelihood_inputs(self, measurement_record):
@@ -311,19 +331,20 @@ class OptBayesExpt(ParticlePDF):
             w = self._weights.tensor()
             if par.shape[1] != w.shape[0]:
                 raise ValueError("parameters and particle_weights have different lengths")
+            hp = self._hargs.ptr
             args = (self._model_struct, _ptr(par), par.shape[1],
-                    self.n_particles, _ptr(w), _lib.host_ptr(self._setting_array(onesetting)),
-                    _lib.host_ptr(yy), None if s is None else _lib.host_ptr(s),
-                    None if rows is None else _lib.host_ptr(rows), n, self._choke_value())
+                    self.n_particles, _ptr(w), hp(self._setting_array(onesetting)),
+                    hp(yy), None if s is None else hp(s),
+                    None if rows is None else hp(rows), n, self._choke_value())
             if self._parameters is self._particles and self.tuning_parameters.get("fused_moments", True):
                 # ... and the first moments of the posterior in the same pass over the cloud: the next
                 # sweep's shift, mean(), std() and the noise-parameter variance need no launch of their own
                 self._mlib.call("obe_bayes_update_model_moments", *args, _ptr(self._moments_dev), _ptr(self._ws),
-                                self._ws_bytes, _lib.host_ptr(self._upd_host), self._stream())
+                                self._ws_bytes, self._hargs.ptr_keep(self._upd_host), self._stream())
                 self._after_weight_update(self._upd_host[1], moments_fresh=True)
             else:       # (a stale `parameters` alias after set_pdf, obe_base.py:185,395: not the cloud the moments describe)
                 self._mlib.call("obe_bayes_update_model", *args, _ptr(self._ws), self._ws_bytes,
-                                _lib.host_ptr(self._host_out), self._stream())
+                                hp(self._host_out), self._stream())
                 self._after_weight_update(self._host_out[1])
         else:
             if y_model_data is None:
@@ -390,6 +411,10 @@ class OptBayesExpt(ParticlePDF):
         """(tensor, ld): noise variance on the device — one value per channel (ld = 0)
         or, for an overriding yvar_noise_model() that returns per-setting values, a
         (C, n_local) array (ld = n_local)."""
+        if type(self).yvar_noise_model is OptBayesExpt.yvar_noise_model and self._noise_cache is not None:
+            dns = self.default_noise_std
+            if isinstance(dns, np.ndarray) and dns.tobytes() == self._noise_src:
+                return self._noise_dev, 0        # the class's own model of an unchanged default_noise_std
         nv = np.asarray(self.yvar_noise_model(), dtype=np.float64)
         c, ns = self.n_channels, self._n_settings
         per_channel = nv.size == 1 or nv.shape in ((c,), (c, 1))
@@ -399,12 +424,16 @@ class OptBayesExpt(ParticlePDF):
             if self._noise_cache != key:
                 self._noise_dev.copy_(torch.from_numpy(flat))
                 self._noise_cache = key
+            dns = self.default_noise_std
+            self._noise_src = dns.tobytes() if isinstance(dns, np.ndarray) else None
             return self._noise_dev, 0
         full = np.broadcast_to(nv, (c, ns))[:, self._s_begin:self._s_end]
         t = torch.from_numpy(np.array(full)).to(self._device)
         return t, t.shape[1]
 
     def _cost_device(self):
+        if type(self).cost_estimate is OptBayesExpt.cost_estimate:
+            return None, 1.0
         cost = self.cost_estimate()
         if np.ndim(cost) == 0:
             return None, float(cost)
