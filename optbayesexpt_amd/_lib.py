@@ -186,6 +186,8 @@ class DeviceBound:
         self._lib = lib._lib if isinstance(lib, DeviceBound) else lib
         self._torch = torch
         self.index = device.index if device.index is not None else torch.cuda.current_device()
+        # one visible GPU: the current device cannot be another one
+        self._single = torch.cuda.device_count() == 1 and self.index == 0
 
     def guard(self):
         if self._torch.cuda.current_device() == self.index:
@@ -193,6 +195,8 @@ class DeviceBound:
         return self._torch.cuda.device(self.index)
 
     def call(self, name, *args):
+        if self._single:
+            return self._lib.call(name, *args)
         with self.guard():
             return self._lib.call(name, *args)
 

@@ -329,8 +329,13 @@ class ParticlePDF:
         own = stream is None
         if own:
             stream = self._device_stream(n_draws, 0)
-        idx = torch.empty(n_draws, dtype=torch.int64, device=self._device)
         if stream is None and n_draws <= 64:
+            # (the index buffer of small draws is made once per size: last_draw_indices_device is "the
+            # most recent draw", and every consumer reads it on the same stream before the next one)
+            bufs = self.__dict__.setdefault("_small_idx", {})
+            idx = bufs.get(n_draws)
+            if idx is None:
+                idx = bufs[n_draws] = torch.empty(n_draws, dtype=torch.int64, device=self._device)
             # small draw: uniforms as kernel arguments, CDF + search in one call, no synchronisation
             strict = bool(self.tuning_parameters.get("strict_cdf", False))
             key = (self._weights.version, strict)
@@ -355,6 +360,7 @@ class ParticlePDF:
                     self._check_pending_total()
             self.last_draw_indices_device = idx
             return idx
+        idx = torch.empty(n_draws, dtype=torch.int64, device=self._device)
         cdf = self._cdf()
         if stream is not None:
             u_dev = stream.uniforms()

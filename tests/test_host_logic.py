@@ -304,6 +304,7 @@ def test_device_bound_library_switches_device_around_calls(monkeypatch):
             log.append(("exit", idx))
     monkeypatch.setattr(torch.cuda, "current_device", lambda: current[0])
     monkeypatch.setattr(torch.cuda, "device", fake_device)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
     same = _lib.DeviceBound(FakeLib(), torch.device("cuda", 0))
     other = _lib.DeviceBound(FakeLib(), torch.device("cuda", 1))
     same.call("obe_x")
