@@ -19,7 +19,8 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                   ``valu_issue`` prices the kernel in FP64 issue slots counted in its ISA
                   (tools/count_isa.py) against the chip's issue rate — the flop roofline
                   treats every slot as an FMA, the kernel's mix is half mul/add.
-  roofline_update — the HBM-bound Bayes update (K2), bytes / time.
+  roofline_update — the HBM-bound Bayes update with the posterior's first moments (K2 + K3 pass 1, the three
+                  launches of pdf_update()), bytes / time.
   cpu_baseline  — the NumPy oracle on one host core, on a bounded sub-grid (N = 1 only);
                   for c1 the oracle class itself through whole reference-semantics cycles.
   cpu_baseline_allcores — the plain C + OpenMP restatement on every host core (full-sweep configs).
@@ -356,17 +357,25 @@ def main():
                                     "unit": "GB/s", "frac": k1_bytes / k1_s / 1e9 / HBM_PEAK_GBS,
                                     "note": "compute-bound kernel: ~1e4 flop per compulsory byte"}}
 
-    # ---- the HBM-bound update (K2: 3 launches), events around the whole call ----
+    # ---- the HBM-bound update as pdf_update() issues it (K2 + the first moments of the posterior:
+    #      3 launches), events around the whole call ----
     timer = ctypes.c_void_p()
     lib.call("obe_timer_create", ctypes.byref(timer))
     wcopy = w.clone()
-    host_out = np.zeros(4)
     st_arr, yy, ss = np.zeros(4), np.zeros(4), np.ones(4) * sigma
     st_arr[0], yy[0] = 3.0, 49500.0
     rows = None
     if not noise_rec:
         rows = np.zeros(16, dtype=np.int32)
         rows[0] = 9
+    mom_scratch = torch.zeros_like(obe._moments_dev)
+
+    def update_call(pp, ww):
+        obe._mlib.call("obe_bayes_update_model_moments", obe._model_struct, _ptr(pp), pp.shape[1], pp.shape[1], _ptr(ww),
+                       _lib.host_ptr(st_arr), _lib.host_ptr(yy), _lib.host_ptr(ss) if rows is None else None,
+                       None if rows is None else _lib.host_ptr(rows), 1, float("nan"), _ptr(mom_scratch), _ptr(obe._ws),
+                       obe._ws_bytes, None, stream)
+
     reps, rounds = 50, 9
     upd_ms = ctypes.c_float(0.0)
     round_us = []
@@ -376,10 +385,7 @@ def main():
     for rnd in range(2 + rounds):
         lib.call("obe_timer_start", timer, stream)
         for _ in range(reps):
-            obe._mlib.call("obe_bayes_update_model", obe._model_struct, _ptr(p), p.shape[1], n_p, _ptr(wcopy),
-                     _lib.host_ptr(st_arr), _lib.host_ptr(yy), _lib.host_ptr(ss) if rows is None else None,
-                     None if rows is None else _lib.host_ptr(rows), 1, float("nan"), _ptr(obe._ws),
-                     obe._ws_bytes, None, stream)
+            update_call(p, wcopy)
         lib.call("obe_timer_stop", timer, stream, ctypes.byref(upd_ms))
         if rnd >= 2:
             round_us.append(upd_ms.value * 1e3 / reps)
@@ -396,11 +402,7 @@ def main():
         for rnd in range(2 + 5):
             lib.call("obe_timer_start", timer, stream)
             for _ in range(10):
-                obe._mlib.call("obe_bayes_update_model", obe._model_struct, _ptr(p16), p16.shape[1], p16.shape[1],
-                         _ptr(w16c), _lib.host_ptr(st_arr), _lib.host_ptr(yy),
-                         _lib.host_ptr(ss) if rows is None else None,
-                         None if rows is None else _lib.host_ptr(rows), 1, float("nan"), _ptr(obe._ws),
-                         obe._ws_bytes, None, stream)
+                update_call(p16, w16c)
             lib.call("obe_timer_stop", timer, stream, ctypes.byref(upd_ms))
             if rnd >= 2:
                 big_us.append(upd_ms.value * 1e3 / 10)
@@ -409,11 +411,14 @@ def main():
         del p16, w16, w16c
     lib.call("obe_timer_destroy", timer)
     n_read = obe._device_model.n_read + (0 if noise_rec else 1)
-    k2_bytes = 8 * (n_read + 1) * n_p + 8 * n_p + 16 * n_p
+    # pass A: (n_read + 1) rows read, t written; pass B': t and all D rows read, w' written
+    k2_bytes = 8 * (n_read + 1) * n_p + 8 * n_p + 8 * (d + 1) * n_p + 8 * n_p
     k2_s = float(np.median(round_us)) * 1e-6
-    roofline_update = {"kernel": "update_model_kernel + normalize_kernel + fold2_kernel (K2)", "bound": "hbm",
+    roofline_update = {"kernel": "update_model_kernel + normalize_moments_kernel + fold_update_moments_kernel "
+                                 "(K2 + K3 pass 1: what pdf_update() launches)", "bound": "hbm",
                        "achieved": k2_bytes / k2_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": k2_bytes / k2_s / 1e9 / HBM_PEAK_GBS, "bytes": k2_bytes,
+                       "bytes_note": "8(n_read+1)N + 8N (likelihood pass) + 8(D+1)N + 8N (normalisation + first moments)",
                        "call_us": k2_s * 1e6, "call_us_min_max": [min(round_us), max(round_us)],
                        "timing": f"median of {rounds} rounds of {reps} back-to-back calls, HIP events on the launch stream",
                        "traffic": None}

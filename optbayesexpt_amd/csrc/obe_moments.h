@@ -169,8 +169,15 @@ __device__ __forceinline__ void derive_first_moments(const double* raw, int d, d
     }
 }
 
-inline int moment_blocks(int64_t n) {
-    return static_cast<int>(std::min<int64_t>(kMomBlocks, (n + kBlock - 1) / kBlock));
+// Grid of the moment passes (and of the update's normalisation pass that shares them): one workgroup per CU
+// up to 2 M particles; beyond that a wave per SIMD with only D + 1 loads in flight no longer fills HBM
+// (tools/measure_update.py, D = 3, 16.8 M particles: 4.0 TB/s with 256 workgroups, 4.8 with 768; D = 10 is
+// as fast with 256), so narrow clouds get up to three per CU.  kMomGridCap bounds it for the workspace.
+constexpr int kMomGridCap = 3 * kMomBlocks;
+static_assert(kMomGridCap <= 1024, "obe_workspace_bytes sizes the moment partials for at most 1024 workgroups");
+inline int moment_blocks(int64_t n, int d) {
+    const int per_cu = n < ((int64_t)1 << 21) ? 1 : (d <= 4 ? 3 : (d <= 7 ? 2 : 1));
+    return static_cast<int>(std::min<int64_t>((int64_t)per_cu * kMomBlocks, (n + kBlock - 1) / kBlock));
 }
 
 }  // namespace obe

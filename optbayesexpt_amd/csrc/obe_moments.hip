@@ -118,7 +118,7 @@ __global__ __launch_bounds__(kFoldThreads) void fold_derive_pass2(const double* 
 template <int D>
 static int launch_moments(const double* x, int64_t ld, int64_t n, const double* w, int want_cov, double* out,
                           double* partials, double* raw, double* host, hipStream_t st) {
-    const int nb = moment_blocks(n);
+    const int nb = moment_blocks(n, D);
     moments_pass1<D><<<nb, kBlock, 0, st>>>(x, ld, n, w, partials);
     OBE_CHECK_LAUNCH("moments_pass1");
     fold_derive_pass1<<<1, kFoldThreads, 0, st>>>(partials, nb, D, out, host);
@@ -146,10 +146,10 @@ int obe_moments(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t
     if (!d_particles || !d_weights || !d_out || n_particles <= 0) return bad_arg("obe_moments: bad pointer/size");
     if (n_dims < 1 || n_dims > OBE_MAX_DIMS) return bad_arg("obe_moments: n_dims must be 1..16");
     const int64_t nv_max = std::max<int64_t>(2 + 2 * n_dims, (int64_t)n_dims * (n_dims + 1) / 2);
-    const int64_t need = ((int64_t)kMomBlocks * nv_max + nv_max) * sizeof(double);
+    const int64_t need = ((int64_t)kMomGridCap * nv_max + nv_max) * sizeof(double);
     if (!d_ws || ws_bytes < need) return bad_arg("obe_moments: workspace too small");
     double* partials = static_cast<double*>(d_ws);
-    double* raw = partials + (int64_t)kMomBlocks * nv_max;
+    double* raw = partials + (int64_t)kMomGridCap * nv_max;
     hipStream_t st = as_stream(stream);
     double* hv = static_cast<double*>(device_view_of_host(h_out));     // page-locked h_out: the kernels write it
     int rc = -1;

@@ -432,7 +432,7 @@ struct UpdateWs {
     double* mom;        // block partials of the fused first moments (moments_dims > 0 only)
 };
 static int carve_update_ws(void* d_ws, int64_t ws_bytes, UpdateWs& w, int moments_dims = 0) {
-    const int64_t mom = moments_dims > 0 ? (int64_t)kMomBlocks * (2 + 2 * moments_dims) : 0;
+    const int64_t mom = moments_dims > 0 ? (int64_t)kMomGridCap * (2 + 2 * moments_dims) : 0;
     const int64_t need = (2 * (int64_t)kMaxBlocks + 8 + mom) * sizeof(double);
     if (!d_ws || ws_bytes < need) return bad_arg("workspace too small");
     w.pa = static_cast<double*>(d_ws);
@@ -518,7 +518,7 @@ int obe_bayes_update_model_moments(const obe_model* m, const double* d_particles
         return 0;
     });
     if (rc) return rc;
-    const int nm = moment_blocks(n_particles);
+    const int nm = moment_blocks(n_particles, d);
 #define OBE_UPD_MOM_CASE(DD)                                                                                       \
     case DD:                                                                                                       \
         normalize_moments_kernel<DD><<<nm, kBlock, 0, st>>>(w.pa, nb, d_particles, ld_p, n_particles, d_weights,  \
