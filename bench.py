@@ -45,10 +45,10 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s
 FLOP_PER_EVAL = {"lorentzian": 10, "lorentzian7": 46}
 # FP64 VALU issue slots per evaluation in the kernel's pair loop, counted in the gfx950 ISA
 # (tools/count_isa.py; v_rcp_f64 = 4 slots): (unshifted, shifted)
-ISSUE_SLOTS_PER_EVAL = {"lorentzian": (7.375, 8.375), "lorentzian7": (35.0, 36.0)}   # 7 peaks: 34.75 FP64 + 0.25 v_cndmask
+ISSUE_SLOTS_PER_EVAL = {"lorentzian": (7.3125, 8.3125), "lorentzian7": (34.875, 35.875)}   # 7 peaks: 34.625 FP64 + 0.25 v_cndmask
 # the form a sweep falls back to when the fast one leaves its range (last_sweep["safe"]): 7 peaks one by
 # one, two particles per reciprocal, always shifted
-ISSUE_SLOTS_SAFE_FORM = {"lorentzian7": 40.6}
+ISSUE_SLOTS_SAFE_FORM = {"lorentzian7": 40.2}
 VALU_ISSUE_PEAK = 256 * 4 * 16 * 2.4e9                   # lane-instructions/s: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz
 
 CONFIGS = {

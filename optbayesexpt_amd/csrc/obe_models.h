@@ -22,14 +22,24 @@
 
 namespace obe {
 
-// 1/q to ~1 ulp.  v_rcp_f64 seeds 2^-24.4 relative (measured on gfx950, tools/
-// microbench_fp64.hip); one cubically convergent step  r (1 + e + e^2),  e = 1 - q r,
-// takes that to 2^-73 before rounding: 3 FMAs instead of the 4 of two Newton steps.
+// 1/q for the root of a batch inversion in the sweep.  v_rcp_f64 seeds 2^-24.4 relative (measured on
+// gfx950, tools/microbench_fp64.hip); ONE Newton step  r (1 + e),  e = 1 - q r,  takes that to
+// e^2 <= 2^-48.8 = 2e-15.  Every inverse of the batch then carries the same relative error in [-2e-15, 0]:
+// the sweep's variances move by <= 4e-15 relative (1e-10 is the parity bar; the random part of the error
+// averages down by a further sqrt(N) over the particles).  The step sits on the one narrow dependent chain
+// of the group (product tree -> v_rcp_f64 -> correction -> back-substitution), which the wide phases of
+// the neighbouring pair have to cover: dropping the third FMA of the cubically convergent form
+// r (1 + e + e^2) (2^-73) shortened that chain and took 1.6 % off the c3 sweep (13.75 -> 13.52 ms on one
+// box) where the issue slot alone accounts for 0.85 %.  -DOBE_RCP_CUBIC restores the 1-ulp form.
 __device__ __forceinline__ double fast_rcp(double q) {
     const double r = __builtin_amdgcn_rcp(q);
     const double e = fma(-q, r, 1.0);
+#ifdef OBE_RCP_CUBIC
     const double t = fma(e, e, e);
     return fma(r, t, r);
+#else
+    return fma(r, e, r);
+#endif
 }
 
 // Batch inversion: r[j] = 1/q[j] for N values from one reciprocal of their product
@@ -95,8 +105,16 @@ __device__ __forceinline__ void batch_rcp_scaled2(const double (&q)[N], double s
         static_assert(N == 8, "batch_rcp_scaled2: N must be 2, 4 or 8");
         const double p01 = q[0] * q[1], p23 = q[2] * q[3], p45 = q[4] * q[5], p67 = q[6] * q[7];
         const double p03 = p01 * p23, p47 = p45 * p67;
+#ifdef OBE_RCP_SPLIT      // experiment: the Newton step applied to the two half inverses (one slot more, one dependent op less)
+        const double root = p03 * p47;
+        const double r0 = __builtin_amdgcn_rcp(root);
+        const double e = fma(-root, r0, 1.0);
+        const double m03 = r0 * (p47 * s_lo), m47 = r0 * (p03 * s_hi);
+        const double i03 = fma(m03, e, m03), i47 = fma(m47, e, m47);
+#else
         const double inv = fast_rcp(p03 * p47);
         const double i03 = inv * (p47 * s_lo), i47 = inv * (p03 * s_hi);
+#endif
         const double i01 = i03 * p23, i23 = i03 * p01, i45 = i47 * p67, i67 = i47 * p45;
         r[0] = i01 * q[1];
         r[1] = i01 * q[0];
