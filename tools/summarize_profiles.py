@@ -8,7 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")       # (c3; other configs: gpurun_out/prof_<cfg>, set below)
-DST = os.path.join(ROOT, "profiles")
+DST = os.environ.get("OBE_PROFILE_DST", os.path.join(ROOT, "profiles"))    # (on the GPU box: under gpurun_out/)
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 cfg = sys.argv[2] if len(sys.argv) > 2 else "c3"
 n_p, n_s, d = {"c3": (1048576, 65536, 3), "c2": (262144, 4096, 3), "c5": (524288, 16384, 10)}[cfg]
