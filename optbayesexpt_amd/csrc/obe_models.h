@@ -105,16 +105,10 @@ __device__ __forceinline__ void batch_rcp_scaled2(const double (&q)[N], double s
         static_assert(N == 8, "batch_rcp_scaled2: N must be 2, 4 or 8");
         const double p01 = q[0] * q[1], p23 = q[2] * q[3], p45 = q[4] * q[5], p67 = q[6] * q[7];
         const double p03 = p01 * p23, p47 = p45 * p67;
-#ifdef OBE_RCP_SPLIT      // experiment: the Newton step applied to the two half inverses (one slot more, one dependent op less)
-        const double root = p03 * p47;
-        const double r0 = __builtin_amdgcn_rcp(root);
-        const double e = fma(-root, r0, 1.0);
-        const double m03 = r0 * (p47 * s_lo), m47 = r0 * (p03 * s_hi);
-        const double i03 = fma(m03, e, m03), i47 = fma(m47, e, m47);
-#else
+        // (measured and rejected: the Newton step applied to the two half inverses instead of the root —
+        // one slot more, one dependent operation less: +1.6 % at c3, profiles/r03_sweep_accuracy.txt)
         const double inv = fast_rcp(p03 * p47);
         const double i03 = inv * (p47 * s_lo), i47 = inv * (p03 * s_hi);
-#endif
         const double i01 = i03 * p23, i23 = i03 * p01, i45 = i47 * p67, i67 = i47 * p45;
         r[0] = i01 * q[1];
         r[1] = i01 * q[0];
