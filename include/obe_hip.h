@@ -190,7 +190,8 @@ int obe_moments(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t
  * CDF of Generator.choice: cumsum(w) / cumsum(w)[-1].  strict_order != 0 reproduces
  * np.cumsum's serial rounding bit for bit (slow, one wavefront); 0 = parallel
  * blocked scan (same value to ~1e-13, indices identical unless a uniform falls
- * inside that gap).  h_total (nullable) receives sum(w) (sync). */
+ * inside that gap).  h_total (nullable) receives what numpy validates of p (sync): sum(w) — NaN if any
+ * weight is NaN — or -inf when some weight is negative ("Probabilities are not non-negative"). */
 int obe_weight_cdf(const double* d_weights, int64_t n_particles, int32_t strict_order,
                    double* d_cdf, double* h_total, void* d_ws, int64_t ws_bytes, void* stream);
 /* ---- sweeper composition (demos/sweeper/obe_sweeper.py:122-149) ----
@@ -210,7 +211,7 @@ int obe_interval_utility(const double* d_cum, int64_t n_settings, const int64_t*
  * unless cdf_is_fresh (d_cdf still holds the CDF of d_weights), and for clouds of up to
  * 14 336 particles scan and search are one launch (beyond that the three-kernel scan is faster).  Same CDF bits and indices as
  * obe_weight_cdf + obe_cdf_search.  Never synchronises: when the CDF is rebuilt and
- * h_total_pinned != NULL (pinned host memory), sum(w) is copied there asynchronously and is
+ * h_total_pinned != NULL (pinned host memory: written by the last kernel itself; pageable: an asynchronous copy), sum(w) lands there and is
  * valid after the caller's next synchronisation of the stream. */
 int obe_draw_indices(const double* d_weights, int64_t n_particles, int32_t strict_order,
                      int32_t cdf_is_fresh, double* d_cdf, const double* h_uniforms,

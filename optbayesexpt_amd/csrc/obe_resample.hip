@@ -56,22 +56,62 @@ __device__ __forceinline__ void load_tile(const double* __restrict__ w, int64_t 
     for (int k = 0; k < kScanItems; ++k) v[k] = (i0 + k < n) ? w[i0 + k] : 0.0;
 }
 
+// smallest value of a tile (its padding counts as 0: only "is anything negative" is asked of it)
+__device__ __forceinline__ double tile_min(const double (&v)[kScanItems], double* lds /* kBlock/kWave */) {
+    double m = v[0];
+#pragma unroll
+    for (int k = 1; k < kScanItems; ++k) m = fmin(m, v[k]);
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) m = fmin(m, __shfl_down(m, o, kWave));
+    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+    __syncthreads();
+    if (lane == 0) lds[wid] = m;
+    __syncthreads();
+    double r = lds[0];
+#pragma unroll
+    for (int i = 1; i < kBlock / kWave; ++i) r = fmin(r, lds[i]);
+    return r;
+}
+
+// What numpy's Generator.choice checks of p, in its order: NaN ("Probabilities contain NaN": the sum is
+// NaN), then a negative entry ("Probabilities are not non-negative"), then the sum.  The host gets ONE
+// number: the sum, or -inf when some weight is negative (no sum of probabilities is ever -inf otherwise).
+__device__ __forceinline__ double total_for_validation(double total, double smallest) {
+    return (total == total && smallest < 0.0) ? -INFINITY : total;
+}
+
 __global__ __launch_bounds__(kBlock) void scan_block_sums(const double* __restrict__ w, int64_t n,
-                                                          double* __restrict__ block_sums) {
+                                                          double* __restrict__ block_sums,
+                                                          double* __restrict__ block_mins) {
     __shared__ double lds[kBlock / kWave];
     double v[kScanItems];
     load_tile(w, n, (int64_t)blockIdx.x * kScanTile, v);
+    const double smallest = block_mins ? tile_min(v, lds) : 0.0;
     const double total = tile_scan(v, lds);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+    if (threadIdx.x == 0) {
+        block_sums[blockIdx.x] = total;
+        if (block_mins) block_mins[blockIdx.x] = smallest;
+    }
 }
 
 // Exclusive scan of the block sums (nb = N/2048: 512 at 1M particles) by one workgroup,
-// written in place; scalars[0] = total = offset[last] + sum[last].
+// written in place; scalars[0] = total = offset[last] + sum[last], scalars[1] = the value the host
+// validates (total_for_validation).
 __global__ __launch_bounds__(kBlock) void scan_offsets(double* __restrict__ block_sums, int64_t nb,
+                                                       const double* __restrict__ block_mins,
                                                        double* __restrict__ scalars) {
     __shared__ double lds[kBlock + 1];
-    const double total = block_exclusive_scan_inplace<double>(block_sums, nb, lds);
-    if (threadIdx.x == 0) scalars[0] = total;
+    __shared__ double mins[kBlock];
+    double m = 0.0;
+    if (block_mins)
+        for (int64_t i = threadIdx.x; i < nb; i += kBlock) m = fmin(m, block_mins[i]);
+    mins[threadIdx.x] = m;
+    const double total = block_exclusive_scan_inplace<double>(block_sums, nb, lds);     // (synchronises)
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < kBlock; ++i) m = fmin(m, mins[i]);
+        scalars[0] = total;
+        scalars[1] = total_for_validation(total, m);
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void scan_write_cdf(const double* __restrict__ w, int64_t n,
@@ -108,10 +148,11 @@ __global__ __launch_bounds__(kWave) void cdf_strict_kernel(const double* __restr
                                                            double* __restrict__ cdf,
                                                            double* __restrict__ scalars, int normalize) {
     const int lane = threadIdx.x;
-    double run = 0.0;
+    double run = 0.0, smallest = 0.0;
     for (int64_t base = 0; base < n; base += kWave) {
         const int64_t i = base + lane;
         const double x = (i < n) ? w[i] : 0.0;
+        smallest = fmin(smallest, x);
         double mine = 0.0;
 #pragma unroll
         for (int k = 0; k < kWave; ++k) {
@@ -120,7 +161,12 @@ __global__ __launch_bounds__(kWave) void cdf_strict_kernel(const double* __restr
         }
         if (i < n) cdf[i] = mine;
     }
-    if (lane == 0) scalars[0] = run;
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) smallest = fmin(smallest, __shfl_down(smallest, o, kWave));
+    if (lane == 0) {
+        scalars[0] = run;
+        scalars[1] = total_for_validation(run, smallest);
+    }
     if (!normalize) return;
     __threadfence_block();
     for (int64_t base = 0; base < n; base += kWave) {
@@ -146,9 +192,14 @@ __device__ __forceinline__ int64_t search_right(const double* cdf, int64_t n, do
     return lo;
 }
 
+// (total_host: the device view of the caller's page-locked sum(w) slot, or NULL — the last kernel of a small
+// draw delivers it itself; a hipMemcpyAsync of 8 bytes would be a blit kernel of its own)
 __global__ __launch_bounds__(kWave) void cdf_search_arg_kernel(const double* __restrict__ cdf, int64_t n, UniformArg ua,
-                                                               int nd, int64_t* __restrict__ idx) {
+                                                               int nd, int64_t* __restrict__ idx,
+                                                               const double* __restrict__ total_src,
+                                                               double* __restrict__ total_host) {
     if ((int)threadIdx.x < nd) idx[threadIdx.x] = search_right(cdf, n, ua.u[threadIdx.x]);
+    if (threadIdx.x == 0 && total_host) *total_host = *total_src;
 }
 
 // CDF + search in one launch for clouds of up to kSmallCloud particles: one workgroup walks the
@@ -163,13 +214,16 @@ constexpr int kSmallTiles = static_cast<int>(kSmallCloud / kScanTile);
 
 __global__ __launch_bounds__(kBlock) void draw_small_kernel(const double* __restrict__ w, int64_t n,
                                                             double* __restrict__ cdf, UniformArg ua, int nd,
-                                                            int64_t* __restrict__ idx, double* __restrict__ total_out) {
+                                                            int64_t* __restrict__ idx, double* __restrict__ total_out,
+                                                            double* __restrict__ total_host) {
     __shared__ double lds[kBlock / kWave];
     __shared__ double toff[kSmallTiles + 1];
     const int nb = static_cast<int>((n + kScanTile - 1) / kScanTile);
     double v[kScanItems];
+    double smallest = 0.0;
     for (int b = 0; b < nb; ++b) {
         load_tile(w, n, (int64_t)b * kScanTile, v);
+        smallest = fmin(smallest, tile_min(v, lds));
         const double total = tile_scan(v, lds);
         if (threadIdx.x == 0) toff[b] = total;
         __syncthreads();
@@ -183,6 +237,8 @@ __global__ __launch_bounds__(kBlock) void draw_small_kernel(const double* __rest
         }
         toff[nb] = run;
         total_out[0] = run;
+        total_out[1] = total_for_validation(run, smallest);
+        if (total_host) *total_host = total_out[1];
     }
     __syncthreads();
     const double total = toff[nb];
@@ -383,24 +439,25 @@ static int scan_common(const char* who, const double* d_x, int64_t n, int32_t st
                        double* d_out, double* h_total, void* d_ws, int64_t ws_bytes, void* stream) {
     if (!d_x || !d_out || n <= 0) return bad_arg(who);
     const int64_t nb = (n + kScanTile - 1) / kScanTile;
-    const int64_t need = (nb + 8) * (int64_t)sizeof(double);
+    const int64_t need = (2 * nb + 8) * (int64_t)sizeof(double);
     if (!d_ws || ws_bytes < need) return bad_arg("scan: workspace too small");
     double* scalars = static_cast<double*>(d_ws);
     double* block_sums = scalars + 8;
+    double* block_mins = normalize ? block_sums + nb : nullptr;       // a CDF of weights: validated like numpy's p
     hipStream_t st = as_stream(stream);
     if (strict_order) {
         cdf_strict_kernel<<<1, kWave, 0, st>>>(d_x, n, d_out, scalars, normalize);
         OBE_CHECK_LAUNCH("cdf_strict_kernel");
     } else {
-        scan_block_sums<<<(unsigned)nb, kBlock, 0, st>>>(d_x, n, block_sums);
+        scan_block_sums<<<(unsigned)nb, kBlock, 0, st>>>(d_x, n, block_sums, block_mins);
         OBE_CHECK_LAUNCH("scan_block_sums");
-        scan_offsets<<<1, kBlock, 0, st>>>(block_sums, nb, scalars);
+        scan_offsets<<<1, kBlock, 0, st>>>(block_sums, nb, block_mins, scalars);
         OBE_CHECK_LAUNCH("scan_offsets");
         scan_write_cdf<<<(unsigned)nb, kBlock, 0, st>>>(d_x, n, block_sums, scalars, d_out, normalize);
         OBE_CHECK_LAUNCH("scan_write_cdf");
     }
     if (h_total) {
-        OBE_HIP_TRY(hipMemcpyAsync(h_total, scalars, sizeof(double), hipMemcpyDeviceToHost, st));
+        OBE_HIP_TRY(hipMemcpyAsync(h_total, scalars + 1, sizeof(double), hipMemcpyDeviceToHost, st));
         if (!defer_host_sync()) OBE_HIP_TRY(hipStreamSynchronize(st));
     }
     return 0;
@@ -458,22 +515,24 @@ int obe_draw_indices(const double* d_weights, int64_t n_particles, int32_t stric
     for (int i = 0; i < n_draws; ++i) ua.u[i] = h_uniforms[i];
     double* scalars = static_cast<double*>(d_ws);
     if (cdf_is_fresh) {
-        cdf_search_arg_kernel<<<1, kWave, 0, st>>>(d_cdf, n_particles, ua, n_draws, d_idx);
+        cdf_search_arg_kernel<<<1, kWave, 0, st>>>(d_cdf, n_particles, ua, n_draws, d_idx, nullptr, nullptr);
         OBE_CHECK_LAUNCH("cdf_search_arg_kernel");
         return 0;
     }
+    double* hv = static_cast<double*>(device_view_of_host(h_total_pinned));      // NULL for pageable memory
     static const int64_t small_limit = getenv("OBE_SMALL_CLOUD") ? atoll(getenv("OBE_SMALL_CLOUD")) : kSmallCloudDefault;   // tuning aid
     if (!strict_order && n_particles <= std::min(small_limit, kSmallCloud)) {
-        draw_small_kernel<<<1, kBlock, 0, st>>>(d_weights, n_particles, d_cdf, ua, n_draws, d_idx, scalars);
+        draw_small_kernel<<<1, kBlock, 0, st>>>(d_weights, n_particles, d_cdf, ua, n_draws, d_idx, scalars, hv);
         OBE_CHECK_LAUNCH("draw_small_kernel");
     } else {
         if (int rc = scan_common("obe_draw_indices: bad pointer/size", d_weights, n_particles, strict_order, 1, d_cdf,
                                  nullptr, d_ws, ws_bytes, stream))
             return rc;
-        cdf_search_arg_kernel<<<1, kWave, 0, st>>>(d_cdf, n_particles, ua, n_draws, d_idx);
+        cdf_search_arg_kernel<<<1, kWave, 0, st>>>(d_cdf, n_particles, ua, n_draws, d_idx, scalars + 1, hv);
         OBE_CHECK_LAUNCH("cdf_search_arg_kernel");
     }
-    if (h_total_pinned) OBE_HIP_TRY(hipMemcpyAsync(h_total_pinned, scalars, sizeof(double), hipMemcpyDeviceToHost, st));
+    if (h_total_pinned && !hv)      // pageable memory after all: an asynchronous copy
+        OBE_HIP_TRY(hipMemcpyAsync(h_total_pinned, scalars + 1, sizeof(double), hipMemcpyDeviceToHost, st));
     return 0;
 }
 

@@ -800,7 +800,7 @@ int64_t obe_workspace_bytes(int64_t n_particles, int64_t n_settings, int32_t n_c
     const int64_t nv = std::max<int64_t>(2 + 2 * n_dims, (int64_t)n_dims * (n_dims + 1) / 2);
     d = std::max<int64_t>(d, 1024 * nv + nv);                       // moments (grid cap <= 1024)
     d = std::max<int64_t>(d, 2 * kMaxBlocks + 8 + 1024 * (2 + 2 * (int64_t)n_dims));   // update + fused first moments
-    d = std::max<int64_t>(d, (n_particles + 2047) / 2048 + 8);      // cdf block sums
+    d = std::max<int64_t>(d, 2 * ((n_particles + 2047) / 2048) + 8);      // cdf block sums and minima
     d = std::max<int64_t>(d, 2 * (int64_t)kMaxBlocks + 8);          // update partials
     return (d + 64) * (int64_t)sizeof(double);
 }

@@ -33,7 +33,7 @@ import warnings
 import numpy as np
 import torch
 
-from . import _lib
+from . import _devrng, _lib
 from . import models as _models
 from ._mirror import Mirror, TrackedArray
 from .models import DeviceModel
@@ -768,11 +768,20 @@ class OptBayesExpt(ParticlePDF):
         self._lib.call("obe_power_normalize", _ptr(u), n, float(pickiness), _ptr(prob), _ptr(self._ws),
                        self._ws_bytes, self._stream())
         uni = np.atleast_1d(self.rng.random())
-        # CDF of the selection probabilities + the search for one uniform (passed by value)
+        # CDF of the selection probabilities + the search for one uniform (passed by value); sum(p) lands in
+        # page-locked memory for numpy's validation of p (Generator.choice, obe_base.py:785)
+        total = self._total_pinned
         self._lib.call("obe_draw_indices", _ptr(prob), n, 0, 0, _ptr(cdf), _lib.host_ptr(uni), 1,
-                       idx_dev, None, _ptr(self._ws), self._ws_bytes, self._stream())
+                       idx_dev, _P(total.data_ptr() + 8), _ptr(self._ws), self._ws_bytes, self._stream())
         torch.cuda.current_stream(self._device).synchronize()
         self._check_pending_total()
+        try:
+            self._validate_total(float(total[1]))      # all-zero / NaN utilities: p = 0/0, ValueError in the reference
+        except ValueError:
+            # numpy validates p before it draws: give the uniform back (one raw value of a PCG64 stream)
+            if _devrng.pcg64_state(self.rng) is not None:
+                self.rng.bit_generator.advance((1 << 128) - 1)
+            raise
         goodindex = int(idx_host[0])
         self.last_setting_index = goodindex
         return tuple(self.allsettings[:, goodindex])

@@ -297,11 +297,14 @@ class ParticlePDF:
 
     @staticmethod
     def _validate_total(total):
-        # numpy's validation of p in Generator.choice (ValueError in the reference)
+        """numpy's validation of p in Generator.choice (ValueError in the reference), in numpy's order and
+        words.  ``total`` is what the CDF kernels report: sum(p), or -inf when some entry is negative."""
         if total != total:
-            raise ValueError("probabilities contain NaN")
+            raise ValueError("Probabilities contain NaN")
+        if total == float("-inf"):
+            raise ValueError("Probabilities are not non-negative")
         if abs(total - 1.0) > SQRT_EPS:
-            raise ValueError("probabilities do not sum to 1")
+            raise ValueError("Probabilities do not sum to 1. See Notes section of docstring for more information.")
 
     def _check_pending_total(self):
         """After a stream synchronisation: the deferred validation of the weights a small draw

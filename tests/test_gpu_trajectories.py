@@ -236,3 +236,18 @@ def test_long_run_stays_in_lock_step_with_the_oracle(hip, selection, device_rng)
     np.testing.assert_allclose(a.mean(), b.mean(), rtol=1e-9)
     np.testing.assert_allclose(a.covariance(), b.covariance(), rtol=1e-7, atol=1e-9 * np.abs(b.covariance()).max())
     np.testing.assert_allclose(a.particle_weights, b.particle_weights, rtol=1e-8, atol=1e-12 * b.particle_weights.max())
+
+
+def test_randomised_short_experiments_against_the_oracle(hip):
+    """tools/fuzz_parity.py: 250 seeded random recipes (model, cloud of 2 ... 20 000 particles, grid of
+    1 ... 6000 settings, zero weights, draw counts, opt / good selection, scale, choke, noise parameters —
+    incl. priors with sigma <= 0 —, resample thresholds that force resamples): every step against the
+    oracle class from the oracle's state — indices exact, floats 1e-10 — and numpy's ValueError /
+    LinAlgError where the reference fails (invalid probabilities, degenerate covariances)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "250", "7"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "250 cases, 0 failures" in r.stdout, r.stdout[-3000:] + r.stderr[-1500:]

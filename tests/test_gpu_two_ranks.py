@@ -63,7 +63,9 @@ def _yspace_log(obe_mod, shard):
         obe_base.rng = np.random.default_rng(32 if shard is None or shard.rank == 0 else 1000 + shard.rank)
         picks = []
         for cyc in range(3):
-            x = o.opt_setting() if cyc != 1 else o.good_setting(pickiness=9)
+            # (full_kld utilities can be negative: utility**9 then fails numpy's validation of p, here as
+            # in the reference — that method selects with opt_setting only)
+            x = o.good_setting(pickiness=9) if cyc == 1 and method != "full_kld_utility" else o.opt_setting()
             picks.append(int(o.last_setting_index))
             o.pdf_update((x, 49500.0, 500.0))
         out[method] = (picks, np.asarray(o.utility()).reshape(-1))

@@ -1120,3 +1120,57 @@ def test_fused_update_moments_is_update_then_moments(obe, k, noise, n):
     assert_allclose(out[True][0], w1, rtol=1e-10, atol=1e-13 * w1.max())
     assert_allclose(out[True][1], oracle.weighted_mean(prior, w1), rtol=1e-10)
     assert_allclose(out[True][4], oracle.effective_particles(w1), rtol=1e-10)
+
+
+def test_good_setting_validates_its_probabilities_like_numpy(obe):
+    """good_setting() draws with rng.choice(p = utility**pickiness / sum) (obe_base.py:781-785): when every
+    utility is zero p is 0/0 and numpy raises ValueError before it consumes a uniform — so does the
+    device path, and the generator is where it was."""
+    g = np.random.default_rng(4)
+    n = 300
+    prior = np.array([g.uniform(2, 4, n), g.uniform(400, 2000, n), g.normal(500, 300, n)])
+    sv = (np.linspace(1.5, 4.5, 40),)
+    for method in ("variance_approx", "variance_full"):
+        o = obe.OptBayesExpt(obe.models.lorentzian(), sv, prior.copy(), (0.1,), scale=False, n_draws=5,
+                             utility_method=method, auto_resample=False)
+        o.rng = np.random.default_rng(9)
+        x = o.good_setting(pickiness=7)                       # a regular draw first
+        assert len(x) == 1
+        o.default_noise_std = np.full((1, 1), np.inf)         # utility = variance / inf = 0 for every setting
+        ref = np.random.default_rng(9)
+        ref.random(2 * 5 + 1 if method == "variance_approx" else 1)     # (the failing call's own draws succeeded)
+        with pytest.raises(ValueError):
+            o.good_setting(pickiness=7)
+        assert o.rng.bit_generator.state == ref.bit_generator.state
+        assert o.opt_setting() == (sv[0][0],)                 # np.argmax of zeros: the first setting
+
+
+@pytest.mark.parametrize("n", [300, 70001])
+def test_negative_probabilities_are_refused_like_numpy(obe, n):
+    """Generator.choice(p=w) raises "Probabilities are not non-negative" for a negative weight (what a
+    noise parameter sigma < 0 in the prior produces through the likelihood 1/sigma): every draw on the
+    device does the same — small draws, resample-sized draws, the strict CDF — in numpy's order (NaN
+    first), and leaves the generator where it was."""
+    g = np.random.default_rng(n)
+    x = g.normal(0.0, 1.0, (2, n))
+    w = g.exponential(1.0, n)
+    w[5] = -w[5]
+    w /= w.sum()
+    with pytest.raises(ValueError, match="not non-negative"):
+        np.random.default_rng(0).choice(n, p=w)
+    for strict in (False, True):
+        pdf = obe.ParticlePDF(x.copy())
+        pdf.tuning_parameters["strict_cdf"] = strict
+        pdf.particle_weights = w
+        pdf.rng = np.random.default_rng(3)
+        before = pdf.rng.bit_generator.state
+        for call in (lambda: pdf.randdraw(7), lambda: pdf.randdraw(n), pdf.resample):
+            with pytest.raises(ValueError, match="not non-negative"):
+                call()
+            assert pdf.rng.bit_generator.state == before
+        w2 = w.copy()
+        w2[9] = np.nan
+        pdf.particle_weights = w2
+        with pytest.raises(ValueError, match="contain NaN"):
+            pdf.randdraw(7)
+        assert pdf.rng.bit_generator.state == before

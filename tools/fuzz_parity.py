@@ -1,0 +1,250 @@
+"""Randomised parity runs (developer aid, GPU): short seeded experiments with random models, cloud
+and grid sizes, weights with zeros, utility modes, draw counts, selection methods, scale / choke /
+noise-parameter options — the product classes against the oracle classes step by step.
+
+    python tools/fuzz_parity.py [n_cases=200] [seed=0]
+
+Every cycle: chosen setting index and resample decision exact, utility / weights / N_eff / moments
+1e-9 (with absolute floors for values that vanish by cancellation), particles after a resample
+given the same normals.  Prints the failing case's recipe so that it can be replayed."""
+import os
+import sys
+import traceback
+import warnings
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402,F401
+
+import optbayesexpt_amd as obe  # noqa: E402
+import oracle  # noqa: E402
+from oracle import models as om  # noqa: E402
+
+RTOL = 1e-9
+
+
+def close(a, b, what, rtol=RTOL, floor=1e-3):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, f"{what}: shapes {a.shape} vs {b.shape}"
+    if a.size == 0:
+        return
+    scale = np.max(np.abs(b[np.isfinite(b)])) if np.any(np.isfinite(b)) else 1.0
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=rtol * floor * max(scale, 1e-300), err_msg=what, equal_nan=True)
+
+
+def numpy_rejects(p):
+    """Would Generator.choice refuse these probabilities (NaN, negative entries, sum != 1)?"""
+    try:
+        np.random.default_rng(0).choice(len(p), p=p)
+        return False
+    except ValueError:
+        return True
+
+
+def make_case(g):
+    kind = g.choice(["lorentz1", "lorentz2", "lorentz3", "line_mb", "line_ab", "first", "rabi", "coil"])
+    n = int(np.exp(g.uniform(np.log(2), np.log(20000))))
+    case = dict(kind=str(kind), n=n, seed=int(g.integers(1 << 30)))
+    case["full"] = bool(g.random() < 0.5)
+    case["n_draws"] = int(g.integers(2, 41))
+    case["selection"] = str(g.choice(["opt", "good"]))
+    case["scale"] = bool(g.random() < 0.3)
+    case["choke"] = float(g.uniform(0.3, 1.0)) if g.random() < 0.2 else None
+    case["zeros"] = bool(g.random() < 0.3)
+    case["cycles"] = int(g.integers(2, 7))
+    case["threshold"] = float(g.choice([0.5, 0.9, 0.999]))          # high thresholds force resamples
+    case["ns"] = int(np.exp(g.uniform(0, np.log(6000))))
+    case["noise_param"] = bool(kind in ("line_mb", "lorentz1", "coil") and g.random() < 0.5)
+    return case
+
+
+def build(case):
+    g = np.random.default_rng(case["seed"])
+    n, ns, kind = case["n"], case["ns"], case["kind"]
+    cons, noise_idx = (), None
+    if kind.startswith("lorentz"):
+        k = int(kind[-1])
+        rows = [g.uniform(2, 4, n) for _ in range(k)] + [g.uniform(400, 2000, n), g.normal(500, 300, n)]
+        dm, fn = obe.models.lorentzian(k), (om.lorentzian if k == 1 else om.multi_lorentzian(k))
+        sv, cons = (np.linspace(1.5, 4.5, ns),), (0.1,)
+        true = tuple([3.0 + 0.1 * i for i in range(k)] + [1000.0, 500.0])
+        sigma = 200.0
+    elif kind in ("line_mb", "line_ab"):
+        rows = [g.normal(1.0, 0.5, n), g.normal(-0.5, 0.5, n)]
+        dm, fn = (obe.models.line_mb(), om.line_mb) if kind == "line_mb" else (obe.models.line_ab(), om.line_ab)
+        sv = (np.linspace(-2.0, 3.0, ns),)
+        true, sigma = (1.2, -0.4), 0.3
+    elif kind == "first":
+        rows = [g.normal(3.0, 1.0, n)]
+        dm, fn, sv, true, sigma = obe.models.first_parameter(), om.first_parameter, (np.linspace(0, 1, ns),), (3.3,), 0.5
+    elif kind == "rabi":
+        m1 = max(1, int(np.sqrt(ns)))
+        rows = [g.uniform(0.5, 2.0, n), g.normal(0.0, 1.0, n)]
+        dm, fn = obe.models.rabi(), om.rabi
+        sv = (np.linspace(0.05, 1.0, m1), np.linspace(-3.0, 3.0, max(1, ns // m1)))
+        cons, true, sigma = (1000.0, 0.3, 5.0), (1.2, 0.3), 15.0
+    else:
+        rows = [g.uniform(0.5e-3, 2e-3, n), g.uniform(5.0, 20.0, n), g.uniform(0.5e-9, 2e-9, n)]
+        dm, fn = obe.models.coil(), om.coil
+        sv = (np.linspace(2e5, 2e6, ns),)
+        true, sigma = (1e-3, 10.0, 1e-9), 2000.0
+    n_model_rows = len(rows)
+    if case["noise_param"]:
+        n_ch = 2 if kind == "coil" else 1
+        for _ in range(1):
+            rows.append(g.exponential(sigma, n) - (0.02 * sigma if g.random() < 0.5 else 0.0))   # a few sigma <= 0
+        noise_idx = tuple([n_model_rows] * n_ch) if n_ch > 1 else n_model_rows
+    prior = np.array(rows)
+    kw = dict(scale=case["scale"], choke=case["choke"], n_draws=case["n_draws"],
+              utility_method="variance_full" if case["full"] else "variance_approx",
+              resample_threshold=case["threshold"])
+    if noise_idx is None:
+        kw["default_noise_std"] = sigma
+        a = obe.OptBayesExpt(dm, sv, prior.copy(), cons, **kw)
+        b = oracle.OracleOptBayesExpt(fn, sv, prior.copy(), cons, **kw)
+    else:
+        a = obe.OptBayesExptNoiseParameter(dm, sv, prior.copy(), cons, noise_parameter_index=noise_idx, **kw)
+        b = oracle.OracleOptBayesExptNoiseParameter(fn, sv, prior.copy(), cons, noise_parameter_index=noise_idx, **kw)
+    if case["zeros"]:
+        w = g.exponential(1.0, n)
+        w[g.random(n) < 0.3] = 0.0
+        if w.sum() == 0:
+            w[0] = 1.0
+        w /= w.sum()
+        a.particle_weights = w.copy()
+        b.particle_weights = w.copy()
+    a.rng, b.rng = np.random.default_rng(case["seed"] + 1), np.random.default_rng(case["seed"] + 1)
+    return a, b, fn, true, cons, sigma, noise_idx is not None
+
+
+def run_case(case):
+    a, b, fn, true, cons, sigma, noise = build(case)
+    sim = np.random.default_rng(case["seed"] + 2)
+    n_ch = b.n_channels
+    for cyc in range(case["cycles"]):
+        tag = f"cycle {cyc}"
+        # every cycle starts from the oracle's state: each step is compared on its own, so the SVD-based
+        # nudge of a resample (which amplifies last-bit differences) cannot turn one
+        # step's rounding into the next step's mismatch
+        a.particles = np.array(b.particles)
+        a.particle_weights = np.array(b.particle_weights)
+        a.rng.bit_generator.state = b.rng.bit_generator.state
+        a._parameters = a._particles
+        pb, wb0 = np.array(b.particles), np.array(b.particle_weights)
+        if numpy_rejects(wb0):
+            # (a prior with sigma <= 0 gives negative likelihoods; all-zero likelihoods give zero weights)
+            # the reference's randdraw fails with numpy's ValueError: so must every draw on the device
+            if case["full"]:
+                return
+            try:
+                a.opt_setting() if case["selection"] == "opt" else a.good_setting(pickiness=7)
+            except ValueError:
+                return
+            raise AssertionError(f"{tag}: probabilities numpy rejects did not raise")
+        if case["selection"] == "opt":
+            xa, xb = a.opt_setting(), b.opt_setting()
+            if np.max(b.last_utility) <= 1e-20 * sigma ** -2:
+                return        # all draws identical: the reference's variance is exactly 0
+            close(a._gather_settings(a._utility_dev.reshape(1, -1))[0], b.last_utility, f"{tag} utility", rtol=1e-10)
+        else:
+            xb = b.good_setting(pickiness=7)
+            if np.max(b.last_utility) <= 1e-20 * sigma ** -2:
+                return
+            if not np.all(np.isfinite(np.nan_to_num(b.last_utility ** 7) / np.sum(np.nan_to_num(b.last_utility ** 7)))):
+                # p = 0/0: numpy's Generator.choice raises ValueError in the reference; so must the device path
+                try:
+                    a.good_setting(pickiness=7)
+                except ValueError:
+                    return
+                raise AssertionError(f"{tag}: NaN selection probabilities did not raise")
+            xa = a.good_setting(pickiness=7)
+        if not case["full"]:
+            np.testing.assert_array_equal(a.last_draw_indices, b.last_draw_indices, err_msg=f"{tag} draw indices")
+        assert a.last_setting_index == b.last_setting_index, f"{tag}: setting {a.last_setting_index} vs {b.last_setting_index}"
+        y = np.atleast_1d(fn(xb, true, cons)) + sigma * sim.standard_normal(n_ch)
+        ym = tuple(y) if n_ch > 1 else float(y[0])
+        rec = (xb, ym) if noise else (xb, ym, tuple([sigma] * n_ch) if n_ch > 1 else sigma)
+        # the weights the resample (if any) draws from and takes its covariance of
+        wpost = oracle.normalized_product(wb0, b.likelihood(b.eval_over_all_parameters(xb), rec))
+        try:
+            a.pdf_update((xa,) + rec[1:])
+        except np.linalg.LinAlgError:                       # (a subclass of ValueError: first)
+            # a degenerate covariance (two particles, one weight: np.cov divides by zero) makes the SVD
+            # inside multivariate_normal fail in the reference; the oracle must fail the same way
+            try:
+                b.pdf_update(rec)
+            except np.linalg.LinAlgError:
+                return
+            raise AssertionError(f"{tag}: LinAlgError on the device path only")
+        except ValueError:
+            # the resample inside pdf_update drew from weights numpy rejects (negative likelihoods)?
+            if numpy_rejects(wpost):
+                return
+            raise
+        b.pdf_update(rec)
+        assert bool(a.just_resampled) == bool(b.just_resampled), f"{tag}: resample decision"
+        wb = np.asarray(b.particle_weights)
+        close(a.particle_weights, wb, f"{tag} weights", rtol=1e-10)
+        if b.just_resampled:
+            np.testing.assert_array_equal(a.last_resample_indices_device.cpu().numpy(), b.last_draw_indices,
+                                          err_msg=f"{tag} resample indices")
+            # the nudge z @ F.T carries the LAPACK round-off of F = u sqrt(s): an absolute floor of
+            # ~256 eps sqrt(lambda_max) on every coordinate, whatever the coordinate's own scale
+            ev = np.linalg.eigvalsh(oracle.weighted_covariance(pb, wpost)) if pb.shape[1] > 1 else np.zeros(1)
+            lam = max(float(np.max(ev)), 0.0)
+            cond = lam / max(float(np.min(ev)), 1e-300)
+            floor = 1024 * 2.3e-16 * np.sqrt(lam) * max(1.0, np.sqrt(min(cond, 1e12)))
+            if float(np.min(ev)) < 1e-12 * lam or pb.shape[1] < 64:
+                # (nearly) rank-deficient covariance — fewer effective particles than parameters: eigenvalues
+                # below eps * lambda_max are rounding, their square roots sqrt(eps * lambda_max) are not small
+                floor = 64 * np.sqrt(2.3e-16 * lam)
+            pa_new, pb_new = np.array(a.particles), np.array(b.particles)
+            if np.sum(wpost) - np.sum(wpost * wpost) / np.sum(wpost) < 1e-6:
+                continue      # one particle carries the weight: np.cov's normalisation sum w - sum w^2 / sum w cancels
+            if not np.all(np.isfinite(pb_new)):
+                assert np.array_equal(np.isfinite(pa_new), np.isfinite(pb_new)), f"{tag}: NaN pattern after a degenerate resample"
+                return
+            assert np.all(np.abs(pa_new - pb_new) <= 1e-10 * np.abs(pb_new) + floor), \
+                f"{tag} particles after the resample: max abs diff {np.max(np.abs(pa_new - pb_new)):.3g}, floor {floor:.3g}"
+        elif np.sum(wb) > 0 and np.all(np.isfinite(wb)):
+            close(a.mean(), b.mean(), f"{tag} mean", rtol=1e-10)
+            cb = b.covariance()
+            if np.all(np.isfinite(cb)):
+                close(a.covariance(), cb, f"{tag} covariance", rtol=1e-9)
+            # one-pass <x^2> - <x>^2 (particlepdf.py:209-214): the variance is good to ~eps <x^2> whatever the order
+            sa, sb, m2 = a.std(), b.std(), np.sum(np.array(b.particles) ** 2 * wb, axis=1)
+            ok = np.isfinite(sa) & np.isfinite(sb)     # (sqrt of a rounding-level negative difference is NaN on either side)
+            assert np.all(np.abs(sa[ok] ** 2 - sb[ok] ** 2) <= 256 * 2.3e-16 * m2[ok] + 1e-10 * sb[ok] ** 2), \
+                f"{tag} std: {sa} vs {sb}"
+    assert a.rng.bit_generator.state == b.rng.bit_generator.state, "generator state"
+
+
+def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--case":       # replay one recipe printed by a failing run
+        warnings.simplefilter("ignore")
+        run_case(eval(sys.argv[2], {"__builtins__": {}}, {"True": True, "False": False, "None": None}))
+        print("case ok")
+        return 0
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    g = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    failures = 0
+    warnings.simplefilter("ignore")
+    for i in range(n_cases):
+        case = make_case(g)
+        try:
+            run_case(case)
+        except Exception as exc:        # noqa: BLE001
+            failures += 1
+            print(f"CASE {i} FAILED: {case}\n  {type(exc).__name__}: {str(exc)[:600]}")
+            if failures <= 3:
+                traceback.print_exc(limit=3)
+            if failures >= 10:
+                break
+    print(f"fuzz: {n_cases} cases, {failures} failures")
+    return failures
+
+
+if __name__ == "__main__":
+    sys.exit(1 if main() else 0)
