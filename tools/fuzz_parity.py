@@ -49,6 +49,11 @@ def make_case(g):
     case = dict(kind=str(kind), n=n, seed=int(g.integers(1 << 30)))
     case["full"] = bool(g.random() < 0.5)
     case["n_draws"] = int(g.integers(2, 41))
+    # the y-space utilities of obe_base.py:491-535 (reference semantics: N_DRAWS weighted draws)
+    case["yspace"] = str(g.choice(["", "", "", "max_min", "pseudo_utility"]))
+    if case["yspace"]:
+        case["full"] = False
+        case["n_draws"] = max(case["n_draws"], 6)
     case["selection"] = str(g.choice(["opt", "good"]))
     case["scale"] = bool(g.random() < 0.3)
     case["choke"] = float(g.uniform(0.3, 1.0)) if g.random() < 0.2 else None
@@ -98,7 +103,7 @@ def build(case):
         noise_idx = tuple([n_model_rows] * n_ch) if n_ch > 1 else n_model_rows
     prior = np.array(rows)
     kw = dict(scale=case["scale"], choke=case["choke"], n_draws=case["n_draws"],
-              utility_method="variance_full" if case["full"] else "variance_approx",
+              utility_method=case.get("yspace") or ("variance_full" if case["full"] else "variance_approx"),
               resample_threshold=case["threshold"])
     if noise_idx is None:
         kw["default_noise_std"] = sigma
@@ -147,7 +152,9 @@ def run_case(case):
             xa, xb = a.opt_setting(), b.opt_setting()
             if np.max(b.last_utility) <= 1e-20 * sigma ** -2:
                 return        # all draws identical: the reference's variance is exactly 0
-            close(a._gather_settings(a._utility_dev.reshape(1, -1))[0], b.last_utility, f"{tag} utility", rtol=1e-10)
+            ua = a.last_utility if case.get("yspace") else a._gather_settings(a._utility_dev.reshape(1, -1))[0]
+            close(np.asarray(ua).reshape(-1), np.asarray(b.last_utility).reshape(-1), f"{tag} utility",
+                  rtol=1e-9 if case.get("yspace") else 1e-10)
         else:
             xb = b.good_setting(pickiness=7)
             if np.max(b.last_utility) <= 1e-20 * sigma ** -2:
