@@ -180,7 +180,10 @@ int obe_eval_over_settings(const obe_model* m, const double* d_settings, int64_t
  * d_out layout (doubles): [0]=sum w, [1]=sum w^2, [2..2+D) mean (np.average),
  * [2+D..2+2D) m1 = sum w x, [2+2D..2+3D) m2 = sum w x^2, [2+3D..2+4D) std,
  * then (if want_cov) D*D covariance (np.cov aweights, ddof=1 form).  Stays on the
- * device (other kernels consume it); copied to h_out too when h_out != NULL (sync). */
+ * device (other kernels consume it); copied to h_out too when h_out != NULL (sync).
+ * want_cov = 2: d_out already holds the first moments of these particles and weights (from an earlier
+ * call or from obe_bayes_update_model_moments): only the covariance pass runs, about the mean found
+ * there; of h_out only the covariance part is then written by a page-locked delivery. */
 int64_t obe_moments_len(int32_t n_dims);
 int obe_moments(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t n_particles,
                 const double* d_weights, int32_t want_cov,

@@ -119,10 +119,12 @@ template <int D>
 static int launch_moments(const double* x, int64_t ld, int64_t n, const double* w, int want_cov, double* out,
                           double* partials, double* raw, double* host, hipStream_t st) {
     const int nb = moment_blocks(n, D);
-    moments_pass1<D><<<nb, kBlock, 0, st>>>(x, ld, n, w, partials);
-    OBE_CHECK_LAUNCH("moments_pass1");
-    fold_derive_pass1<<<1, kFoldThreads, 0, st>>>(partials, nb, D, out, host);
-    OBE_CHECK_LAUNCH("fold_derive_pass1");
+    if (want_cov != 2) {            // (2: `out` already holds the first moments of these weights)
+        moments_pass1<D><<<nb, kBlock, 0, st>>>(x, ld, n, w, partials);
+        OBE_CHECK_LAUNCH("moments_pass1");
+        fold_derive_pass1<<<1, kFoldThreads, 0, st>>>(partials, nb, D, out, host);
+        OBE_CHECK_LAUNCH("fold_derive_pass1");
+    }
     if (want_cov) {
         moments_pass2<D><<<nb, kBlock, 0, st>>>(x, ld, n, w, out, partials);
         OBE_CHECK_LAUNCH("moments_pass2");

@@ -189,9 +189,13 @@ class ParticlePDF:
         if hk is not None and hk[:2] == key and (hk[2] or not want_cov):
             return self._moments_host
         p, w = self._pw_tensors()
+        # the first moments are already there, on the device and on the host (the last update left them, or
+        # an earlier mean()/std()): only the covariance pass is missing
+        have_first = want_cov and hk is not None and hk[:2] == key and self._mom_dev_key is not None \
+            and self._mom_dev_key[:2] == key
         self._lib.call("obe_moments", _ptr(p), p.shape[1], self.n_dims, self.n_particles, _ptr(w),
-                       1 if want_cov else 0, _ptr(self._moments_dev), _lib.host_ptr(self._moments_host),
-                       _ptr(self._ws), self._ws_bytes, self._stream())
+                       (2 if have_first else 1) if want_cov else 0, _ptr(self._moments_dev),
+                       _lib.host_ptr(self._moments_host), _ptr(self._ws), self._ws_bytes, self._stream())
         self._mom_host_key = self._mom_dev_key = key + (bool(want_cov),)
         return self._moments_host
 
@@ -474,8 +478,12 @@ class ParticlePDF:
             u_dev = rstream.uniforms()
             self._lib.call("obe_cdf_search", _ptr(self._cdf_dev), n, _ptr(u_dev), n, _ptr(idx), _ptr(self._ws),
                            self._ws_bytes, self._stream())
-            self._lib.call("obe_moments", _ptr(p), p.shape[1], d, n, _ptr(w), 1, _ptr(self._moments_dev),
-                           _P(pin_f.data_ptr() + 8), _ptr(self._ws), self._ws_bytes, self._stream())
+            mkey = (self._particles.version, self._weights.version)
+            have_first = self._mom_host_key is not None and self._mom_host_key[:2] == mkey \
+                and self._mom_dev_key is not None and self._mom_dev_key[:2] == mkey
+            self._lib.call("obe_moments", _ptr(p), p.shape[1], d, n, _ptr(w), 2 if have_first else 1,
+                           _ptr(self._moments_dev), _P(pin_f.data_ptr() + 8), _ptr(self._ws), self._ws_bytes,
+                           self._stream())
             have_cov = torch.cuda.Event()
             have_cov.record(stream)
             z_dev = rstream.normals_deferred(pin_i)
@@ -484,8 +492,9 @@ class ParticlePDF:
         have_cov.synchronize()                        # the normals are still being generated
         self._validate_total(float(pin_f[0]))         # (raises before any generator state has moved)
         self._cdf_key = key
-        self._moments_host[:mlen] = pin_f[1:1 + mlen].numpy()
-        mkey = (self._particles.version, self._weights.version)
+        first = 2 + 4 * d                              # (a covariance-only pass delivers only the covariance)
+        lo = first if have_first else 0
+        self._moments_host[lo:mlen] = pin_f[1 + lo:1 + mlen].numpy()
         self._mom_host_key = self._mom_dev_key = mkey + (True,)
         factor, mean = self._nudge_factor(self._moments_host)
         self.last_draw_indices_device = idx
