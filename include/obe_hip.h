@@ -87,6 +87,16 @@ int obe_defer_host_sync(int32_t on);
  * only a few values — the index of obe_draw_indices for good_setting() — may be given as this
  * address: the kernel then delivers the result to the host itself, with no copy back. */
 int obe_host_device_pointer(const void* h_pinned, void** d_out);
+/* Waiting for such a result by watching it: obe_host_word_arm stores a bit pattern no result has
+ * (0x7ff8c0dec0dec0de: a NaN payload / an impossible index) into one 8-byte page-locked word, the call
+ * whose last kernel writes that word is enqueued, and obe_host_word_wait spins until the word changes
+ * (bounded: after 400 us it synchronises `stream` instead, which also reports a kernel that failed).
+ * 5.9 us per round trip of a short kernel instead of 11.1 us through hipStreamSynchronize
+ * (tools/microbench_sync.hip).  The entry points that deliver host results into page-locked memory
+ * (obe_sweep_utility, obe_utility_argmax, obe_argmax, obe_bayes_update_*, obe_weight_sums) wait this
+ * way themselves. */
+int obe_host_word_arm(void* h_pinned_word);
+int obe_host_word_wait(const void* h_pinned_word, void* stream);
 /* Name, CU count and memory of the current device; returns 0 if a gfx950 device is current. */
 int obe_device_info(char* name, int name_len, int* n_cu, int64_t* hbm_bytes);
 

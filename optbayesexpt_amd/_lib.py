@@ -105,6 +105,8 @@ _SIGNATURES = {
     "obe_timer_destroy": (c_int, [_P]),
     "obe_sweep_settings_per_lane": (c_int, [c_int64]),
     "obe_host_device_pointer": (c_int, [_P, ctypes.POINTER(c_void_p)]),
+    "obe_host_word_arm": (c_int, [_P]),
+    "obe_host_word_wait": (c_int, [_P, _P]),
     "obe_sweep_timing": (c_int, [c_int32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64)]),
     "obe_sweep_kernel_time": (c_int, [ctypes.POINTER(ObeModelStruct), _P, c_int64, c_int64, _P, c_int64, c_int64,
                                       _P, _P, c_int32, _P, c_int64, c_int32, ctypes.POINTER(ctypes.c_float), _P]),

@@ -2,10 +2,32 @@
 #include <cstdio>
 #include <cstring>
 
+#include <atomic>
+#include <chrono>
+
 #include "obe_common.h"
 #include "obe_models.h"
 
 namespace obe {
+
+int wait_host_word(const void* h_word, hipStream_t st) {
+    const volatile uint64_t* p = static_cast<const volatile uint64_t*>(h_word);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        for (int i = 0; i < 64; ++i) {
+            if (*p != kHostSentinel) {
+                std::atomic_thread_fence(std::memory_order_acquire);
+                return 0;
+            }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > kHostWaitSpinUs) break;
+    }
+    OBE_HIP_TRY(hipStreamSynchronize(st));       // long kernel, or one that never delivered: the stream knows
+    return 0;
+}
 
 static thread_local std::string g_last_error;
 static thread_local bool g_defer_host_sync = false;
@@ -68,6 +90,17 @@ int obe_model_validate(obe_model* m) {
     if (m->n_params < info.n_read || m->n_params > OBE_MAX_DIMS) return bad_arg("model: n_params out of range for the model");
     if (m->n_consts < info.n_consts || m->n_consts > OBE_MAX_CONSTS) return bad_arg("model: too few constants");
     return 0;
+}
+
+int obe_host_word_arm(void* h_pinned_word) {
+    if (!h_pinned_word) return bad_arg("obe_host_word_arm: null pointer");
+    arm_host_word(h_pinned_word);
+    return 0;
+}
+
+int obe_host_word_wait(const void* h_pinned_word, void* stream) {
+    if (!h_pinned_word) return bad_arg("obe_host_word_wait: null pointer");
+    return wait_host_word(h_pinned_word, as_stream(stream));
 }
 
 int obe_host_device_pointer(const void* h_pinned, void** d_out) {

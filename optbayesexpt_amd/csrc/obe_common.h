@@ -52,6 +52,21 @@ inline void* device_view_of_host(const void* h) {
     return attr.type == hipMemoryTypeHost ? attr.devicePointer : nullptr;
 }
 
+// Results that a call's LAST kernel writes straight into the caller's page-locked memory are waited for
+// by watching that memory, not by hipStreamSynchronize: the host arms one designated word with a bit pattern
+// no result can have (a NaN payload / an impossible index), the kernel stores its results, fences at system
+// scope and stores that word last, and the host spins until it changes.  On MI355X the round trip of a
+// short kernel is 5.9 us this way against 11.1 us through the stream's completion signal
+// (tools/microbench_sync.hip) — a cycle of the reference-sized workloads has two of them.  A kernel that
+// never delivers (a fault) ends the spin after kHostWaitSpinUs and the stream is synchronised, which
+// reports the error; later work on the stream is ordered behind the kernel as usual.
+constexpr uint64_t kHostSentinel = 0x7ff8c0dec0dec0deULL;
+constexpr double kHostWaitSpinUs = 400.0;        // (longer kernels: the stream's own wait; its 5 us no longer matter)
+inline void arm_host_word(void* h_word) { *reinterpret_cast<volatile uint64_t*>(h_word) = kHostSentinel; }
+int wait_host_word(const void* h_word, hipStream_t st);      // obe_capi.hip
+// device side: everything stored to the host before this call is visible there before what follows
+__device__ __forceinline__ void host_results_before_flag() { __threadfence_system(); }
+
 inline int stream_blocks(int64_t n, int per_block) {
     int64_t b = (n + per_block - 1) / per_block;
     if (b < 1) b = 1;

@@ -198,8 +198,13 @@ __global__ __launch_bounds__(kWave) void cdf_search_arg_kernel(const double* __r
                                                                int nd, int64_t* __restrict__ idx,
                                                                const double* __restrict__ total_src,
                                                                double* __restrict__ total_host) {
+    // (sum(p) first and fenced: a caller that watches the page-locked index of a single draw — good_setting —
+    // finds the sum there as well)
+    if (threadIdx.x == 0 && total_host) {
+        *total_host = *total_src;
+        host_results_before_flag();
+    }
     if ((int)threadIdx.x < nd) idx[threadIdx.x] = search_right(cdf, n, ua.u[threadIdx.x]);
-    if (threadIdx.x == 0 && total_host) *total_host = *total_src;
 }
 
 // CDF + search in one launch for clouds of up to kSmallCloud particles: one workgroup walks the
@@ -238,7 +243,10 @@ __global__ __launch_bounds__(kBlock) void draw_small_kernel(const double* __rest
         toff[nb] = run;
         total_out[0] = run;
         total_out[1] = total_for_validation(run, smallest);
-        if (total_host) *total_host = total_out[1];
+        if (total_host) {
+            *total_host = total_out[1];
+            host_results_before_flag();
+        }
     }
     __syncthreads();
     const double total = toff[nb];

@@ -206,15 +206,17 @@ __global__ __launch_bounds__(kFoldThreads) void fold_update_moments_kernel(
     __shared__ double red[kFoldThreads / kWave];
     fold_values_block(partials_mom, n_pb, 2 + 2 * d, raw);
     derive_first_moments(raw, d, mom_out, host_out ? host_out + 2 : nullptr);
+    if (host_out) host_results_before_flag();            // (every thread that stored a moment to the host)
     const double a = block_sum_array(pa, n_pa, red);
     __syncthreads();
-    const double b = block_sum_array(pb, n_pb, red);
+    const double b = block_sum_array(pb, n_pb, red);     // (its barriers order the moment stores before thread 0)
     if (threadIdx.x == 0) {
         scalars[0] = a;
         scalars[1] = b;
         if (host_out) {
             host_out[0] = a;
-            host_out[1] = b;
+            host_results_before_flag();
+            host_out[1] = b;                             // the word the host watches (wait_host_word)
         }
     }
 }
@@ -233,7 +235,8 @@ __global__ __launch_bounds__(kBlock) void fold2_kernel(const double* __restrict_
         scalars[1] = b;
         if (host_out) {
             host_out[0] = a;
-            host_out[1] = b;
+            host_results_before_flag();
+            host_out[1] = b;                             // the word the host watches (wait_host_word)
         }
     }
 }
@@ -241,10 +244,12 @@ __global__ __launch_bounds__(kBlock) void fold2_kernel(const double* __restrict_
 // fold + delivery of {sum t, sum w'^2} to h_out: written by the kernel itself when h_out is page-locked
 static int fold2_to_host(const double* pa, const double* pb, int nb, double* scalars, double* h_out, hipStream_t st) {
     double* hv = static_cast<double*>(device_view_of_host(h_out));
+    if (hv) arm_host_word(h_out + 1);
     fold2_kernel<<<1, kBlock, 0, st>>>(pa, pb, nb, scalars, hv);
     OBE_CHECK_LAUNCH("fold2_kernel");
     if (h_out) {
-        if (!hv) OBE_HIP_TRY(hipMemcpyAsync(h_out, scalars, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+        if (hv) return wait_host_word(h_out + 1, st);
+        OBE_HIP_TRY(hipMemcpyAsync(h_out, scalars, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
         OBE_HIP_TRY(hipStreamSynchronize(st));
     }
     return 0;
@@ -533,10 +538,12 @@ int obe_bayes_update_model_moments(const obe_model* m, const double* d_particles
 #undef OBE_UPD_MOM_CASE
     OBE_CHECK_LAUNCH("normalize_moments_kernel");
     double* hv = static_cast<double*>(device_view_of_host(h_out));
+    if (hv) arm_host_word(h_out + 1);
     fold_update_moments_kernel<<<1, kFoldThreads, 0, st>>>(w.pa, nb, w.pb, nm, w.mom, d, w.scalars, d_moments, hv);
     OBE_CHECK_LAUNCH("fold_update_moments_kernel");
     if (h_out) {
-        if (!hv) {
+        if (hv) return wait_host_word(h_out + 1, st);
+        {
             OBE_HIP_TRY(hipMemcpyAsync(h_out, w.scalars, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
             OBE_HIP_TRY(hipMemcpyAsync(h_out + 2, d_moments, (2 + 4 * (int64_t)d) * sizeof(double),
                                        hipMemcpyDeviceToHost, st));

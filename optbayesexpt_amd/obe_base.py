@@ -763,17 +763,19 @@ class OptBayesExpt(ParticlePDF):
             idx_host = _lib.pinned_array(1, np.int64)
             bufs = self._good_bufs = (torch.empty(n, dtype=torch.float64, device=self._device),
                                       torch.empty(n, dtype=torch.float64, device=self._device),
-                                      idx_host, _lib.device_ptr_of_pinned(self._lib, idx_host))
-        prob, cdf, idx_host, idx_dev = bufs
+                                      idx_host, _lib.device_ptr_of_pinned(self._lib, idx_host), _lib.host_ptr(idx_host))
+        prob, cdf, idx_host, idx_dev, idx_hptr = bufs
         self._lib.call("obe_power_normalize", _ptr(u), n, float(pickiness), _ptr(prob), _ptr(self._ws),
                        self._ws_bytes, self._stream())
         uni = np.atleast_1d(self.rng.random())
         # CDF of the selection probabilities + the search for one uniform (passed by value); sum(p) lands in
         # page-locked memory for numpy's validation of p (Generator.choice, obe_base.py:785)
         total = self._total_pinned
+        stream = self._stream()
+        self._lib.call("obe_host_word_arm", idx_hptr)        # the index is the search kernel's last word: watched, not synchronised
         self._lib.call("obe_draw_indices", _ptr(prob), n, 0, 0, _ptr(cdf), _lib.host_ptr(uni), 1,
-                       idx_dev, _P(total.data_ptr() + 8), _ptr(self._ws), self._ws_bytes, self._stream())
-        torch.cuda.current_stream(self._device).synchronize()
+                       idx_dev, _P(total.data_ptr() + 8), _ptr(self._ws), self._ws_bytes, stream)
+        self._lib.call("obe_host_word_wait", idx_hptr, stream)
         self._check_pending_total()
         try:
             self._validate_total(float(total[1]))      # all-zero / NaN utilities: p = 0/0, ValueError in the reference
