@@ -206,7 +206,8 @@ __global__ __launch_bounds__(kFoldThreads) void fold_update_moments_kernel(
     __shared__ double red[kFoldThreads / kWave];
     fold_values_block(partials_mom, n_pb, 2 + 2 * d, raw);
     derive_first_moments(raw, d, mom_out, host_out ? host_out + 2 : nullptr);
-    if (host_out) host_results_before_flag();            // (every thread that stored a moment to the host)
+    if (host_out && (int)threadIdx.x < d) host_results_before_flag();      // (the threads that stored a moment to the host;
+                                                                             // a fence by all 1024 costs 5 us)
     const double a = block_sum_array(pa, n_pa, red);
     __syncthreads();
     const double b = block_sum_array(pb, n_pb, red);     // (its barriers order the moment stores before thread 0)
