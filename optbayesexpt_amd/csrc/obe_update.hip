@@ -707,11 +707,14 @@ int obe_mask_nonpositive(const double* d_particles, int64_t ld_p, int64_t n_part
     fold2_kernel<<<1, kBlock, 0, st>>>(w.pa, w.pb, nb, w.scalars, nullptr);
     OBE_CHECK_LAUNCH("fold2_kernel");
     int64_t* hv = static_cast<int64_t*>(device_view_of_host(h_changed));
+    if (hv) arm_host_word(h_changed);
     mask_renorm_kernel<<<nb, kBlock, 0, st>>>(w.scalars, n_particles, d_weights, hv);
     OBE_CHECK_LAUNCH("mask_renorm_kernel");
     if (h_changed) {
         if (hv) {
-            OBE_HIP_TRY(hipStreamSynchronize(st));
+            // (the count is the kernel's first store; the renormalisation that may still be running is ordered
+            // before everything the caller enqueues next)
+            if (int rc = wait_host_word(h_changed, st)) return rc;
         } else {
             double sc[2];
             OBE_HIP_TRY(hipMemcpyAsync(sc, w.scalars, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
