@@ -723,6 +723,17 @@ class OptBayesExpt(ParticlePDF):
         return self._shard.gather_rows(local, self._n_settings)
 
     # --------------------------------------------------------------- selection
+    def utility(self):
+        """The utility of every setting, (N_s,).  Like the reference's placeholder of this name
+        (obe_base.py:579-600) it is replaced per object in ``__init__`` by the method that
+        ``utility_method`` names (``utility_variance`` by default)."""
+        raise NotImplementedError("utility is bound in __init__ (utility_method)")
+
+    def get_setting(self):
+        """The next setting by the ``selection_method`` chosen at construction: ``opt_setting``,
+        ``good_setting`` or ``random_setting`` (obe_base.py:722-731; bound per object in ``__init__``)."""
+        raise NotImplementedError("get_setting is bound in __init__ (selection_method)")
+
     def opt_setting(self):
         """The setting with maximum utility (obe_base.py:733-756)."""
         if self._utility_fusable():

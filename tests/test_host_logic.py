@@ -314,3 +314,19 @@ def test_device_bound_library_switches_device_around_calls(monkeypatch):
     assert log == [("enter", 1), ("call", "obe_y", 1), ("exit", 1)] and current[0] == 0
     assert other.workspace_bytes(1, 1, 1, 1) == 64                     # plain delegation
     assert _lib.DeviceBound(other, torch.device("cuda", 1))._lib is other._lib      # no double wrapping
+
+
+def test_classes_carry_every_public_method_of_the_reference_classes():
+    """The public (non-underscore) members of the reference's three classes at v1.2.0 (recorded by
+    introspection of optbayesexpt.ParticlePDF / OptBayesExpt / OptBayesExptNoiseParameter): every one
+    exists here under the same name (the class surface is the drop-in boundary)."""
+    import optbayesexpt_amd as obe
+    pdf = ["bayesian_update", "covariance", "mean", "randdraw", "resample", "resample_test", "set_pdf", "std"]
+    base = pdf + ["cost_estimate", "enforce_parameter_constraints", "eval_over_all_parameters",
+                  "eval_over_all_settings", "get_setting", "good_setting", "likelihood", "opt_setting",
+                  "pdf_update", "random_setting", "set_n_draws", "utility", "utility_full_kld",
+                  "utility_max_min", "utility_pseudo", "utility_variance", "y_var_noise_model",
+                  "yvar_from_entropy", "yvar_from_parameter_draws", "yvar_max_min", "yvar_noise_model"]
+    for cls, names in ((obe.ParticlePDF, pdf), (obe.OptBayesExpt, base), (obe.OptBayesExptNoiseParameter, base)):
+        missing = [n for n in names if not callable(getattr(cls, n, None))]
+        assert not missing, (cls.__name__, missing)
