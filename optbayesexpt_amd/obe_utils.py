@@ -39,3 +39,11 @@ def trace_sort(settings, measurements):
         means.append(np.mean(chunk))
         errs.append(np.std(chunk) / np.sqrt(c))
     return list(uniq), means, errs, list(counts)
+
+
+try:        # the reference keeps a copy of scipy's estimator for installations without scipy
+    from scipy.stats import differential_entropy      # noqa: F401  (obe_utils.py:116-310; obe_base.py:7-10)
+except ImportError:      # pragma: no cover
+    def differential_entropy(*args, **kwargs):
+        raise ImportError("differential_entropy needs scipy (the device utilities pseudo_utility / "
+                          "full_kld_utility carry their own estimator)")
