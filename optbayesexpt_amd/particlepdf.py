@@ -382,6 +382,8 @@ class ParticlePDF:
 
     def randdraw(self, n_draws=1):
         """``n_dims x n_draws`` weighted random draws (particlepdf.py:312-345)."""
+        if n_draws == 0:          # rng.choice(size=0): nothing drawn, nothing consumed, an (n_dims, 0) array
+            return np.empty((self.n_dims, 0))
         idx = self._draw_indices(n_draws)
         p = self._particles.tensor()
         out = torch.empty((self.n_dims, n_draws), dtype=torch.float64, device=self._device)

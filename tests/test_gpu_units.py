@@ -151,6 +151,10 @@ def test_small_draws_on_large_clouds(obe, n):
         pdf = obe.ParticlePDF(x.copy())
         pdf.tuning_parameters["strict_cdf"] = strict
         pdf.particle_weights = w.copy()
+        pdf.rng = np.random.default_rng(2)
+        state = pdf.rng.bit_generator.state
+        empty = pdf.randdraw(0)              # rng.choice(size=0): an (n_dims, 0) array, nothing consumed
+        assert empty.shape == (2, 0) and pdf.rng.bit_generator.state == state
         pdf.rng = np.random.default_rng(11)
         ref = np.random.default_rng(11)
         for n_draws in (30, 1, 64):                      # the second and third draw reuse the CDF
