@@ -200,6 +200,61 @@ def published_workload(cycles=1500, warm=100):
             "speedup_vs_published_numpy": (13109.0 / 3000) / ms}
 
 
+def launch_ranks(n, argv):
+    """``python bench.py --gpus N`` without a launcher around it: start one child process per GPU
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment, as torch.distributed.run would set
+    them) BEFORE this process has touched the GPU — it never does: no torch import, no HIP call —
+    relay rank 0's single JSON line and exit non-zero if any rank does.  Children are fresh
+    interpreters (subprocess, not fork / exec of an initialised process)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OBE_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0 = procs[0].stdout
+    lines, rcs, failed_at = [], [None] * n, None
+    import selectors
+    sel = selectors.DefaultSelector()
+    sel.register(out0, selectors.EVENT_READ)
+    open_pipe = True
+    while any(rc is None for rc in rcs) or open_pipe:
+        if open_pipe and sel.select(timeout=0.2):
+            chunk = out0.readline()
+            if chunk:
+                lines.append(chunk.decode(errors="replace"))
+            else:
+                open_pipe = False
+                sel.unregister(out0)
+        elif not open_pipe:
+            time.sleep(0.2)
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+        bad = [r for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad and failed_at is None:
+            failed_at = time.time()
+        if failed_at is not None and time.time() - failed_at > 10.0:
+            # a rank died: the others wait in a collective for ever — end exactly the processes started here
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    p.kill()
+    sys.stdout.write("".join(lines))
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write(f"bench.py: ranks failed (rank, exit code): {bad}\n")
+        return 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -211,12 +266,18 @@ def main():
                     help="initialise the RCCL process group even with one rank (exercises the N > 1 code path)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around this process: be the launcher (nothing here has touched the GPU yet)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launched by a torch.distributed.run with "
+                 f"a different --nproc-per-node?)")
     # test hooks (flow check on a 1-GPU box): OBE_BENCH_BACKEND=gloo OBE_BENCH_ONE_DEVICE=1 lets
     # several ranks share cuda:0; the numbers of such a run mean nothing
     backend = os.environ.get("OBE_BENCH_BACKEND", "nccl")

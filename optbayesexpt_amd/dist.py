@@ -3,8 +3,11 @@
 Every setting's utility is independent given the particle cloud, so
 rank r sweeps the contiguous slice ``[r*N_s/G, (r+1)*N_s/G)`` of the flattened settings
 and the cloud (34 MB at 1M particles) is replicated: each rank applies the same Bayes
-update and the same seeded resample, so replicas stay bit-identical and no particle
-data ever crosses xGMI.  The only data-path collective is the arg-max combine of
+update and the same resample — rank 0's generator state is broadcast when a sharded object
+is built and whenever its ``rng`` is assigned (the reference's generator is unseeded,
+particlepdf.py:142-145), so replicas stay bit-identical and no particle data ever crosses
+xGMI; a periodic all-gather of a digest of (generator state, sum w, sum w^2) raises on
+every rank if they ever differ.  The only data-path collective is the arg-max combine of
 ``opt_setting``: one all-gather of a 32-byte record per rank ``(best value, local index,
 kappa, 0)`` straight from device memory over RCCL (``torch.distributed`` backend "nccl"), followed by a local first-max —
 the message is latency-bound (tens of microseconds), irrelevant next to a
@@ -109,6 +112,26 @@ class SettingsShard:
         src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
         dist.broadcast(t, src=src, group=self.group)
         return t.cpu().numpy()
+
+    def broadcast_object_from_rank0(self, obj, device="cpu"):
+        """Rank 0's picklable object on every rank (generator states: a dict with 128-bit integers)."""
+        if self.world_size == 1:
+            return obj
+        box = [obj if self.rank == 0 else None]
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        dev = self._comm_device(device)
+        dist.broadcast_object_list(box, src=src, group=self.group, device=dev)
+        return box[0]
+
+    def all_gather_int64(self, values, device="cpu"):
+        """(world, len(values)) host array of every rank's int64 values (replica checks)."""
+        v = np.ascontiguousarray(values, dtype=np.int64)
+        if self.world_size == 1:
+            return v.reshape(1, -1)
+        dev = self._comm_device(device)
+        gathered = torch.empty(self.world_size * v.size, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(gathered, torch.from_numpy(v.copy()).to(dev), group=self.group)
+        return gathered.cpu().numpy().reshape(self.world_size, v.size)
 
     @staticmethod
     def make_record(value, local_index, kappa=0.0, device="cpu"):

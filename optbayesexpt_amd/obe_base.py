@@ -163,6 +163,8 @@ class OptBayesExpt(ParticlePDF):
 
         # settings on the device; a shard sweeps only [s_begin, s_end)
         self._shard = settings_shard
+        self._sharded_sweeps = 0
+        self._sync_rng()          # replicas of a sharded object draw from rank 0's (unseeded) generator state
         # the record of a measurement as the library takes it (filled in place, addresses made once)
         self._hargs = _lib.HostArgs()
         self._rec_x = self._hargs.keep(np.zeros(_lib.OBE_MAX_SETDIMS))
@@ -237,6 +239,62 @@ class OptBayesExpt(ParticlePDF):
             self._parameters = self._particles           # ``self.parameters = self.particles``
         else:
             self._parameters = Mirror(self._device, host=np.asarray(value))
+
+    # -------------------------------------------------- replicas of a sharded object
+    def _rng_assigned(self):
+        self._sync_rng()
+
+    def _sync_rng(self):
+        """A sharded object is one experiment in G processes: every rank must draw the same particles
+        and the same nudges, or the replicated clouds drift apart and the arg-max combine mixes
+        utilities of different posteriors.  The reference's generator is unseeded
+        (particlepdf.py:142-145), so rank 0's generator state is adopted by every rank — here, when the
+        object is built, and again whenever ``rng`` is assigned (both are collective on a sharded
+        object: every rank runs the same script).  Ranks that were seeded alike are left as they are."""
+        shard = self.__dict__.get("_shard")
+        if shard is None or shard.world_size == 1:
+            return
+        bg = getattr(self._rng, "bit_generator", None)
+        state = shard.broadcast_object_from_rank0(None if bg is None else bg.state, self._device)
+        if state is None or shard.rank == 0:
+            return
+        if bg is None or bg.state.get("bit_generator") != state.get("bit_generator"):
+            self._rng = np.random.Generator(getattr(np.random, state["bit_generator"])())
+        self._rng.bit_generator.state = state
+
+    def _replica_digest(self):
+        """(generator digest, bits of sum w, bits of sum w^2): equal on all ranks while the replicas agree."""
+        bg = getattr(self._rng, "bit_generator", None)
+        st = 0
+        if bg is not None:
+            inner = bg.state.get("state", {})
+            for v in (inner.values() if isinstance(inner, dict) else ()):
+                for word in np.atleast_1d(np.asarray(v, dtype=object)).reshape(-1):
+                    word = int(word)
+                    while word:
+                        st = (st * 1000003) ^ (word & 0xFFFFFFFF)
+                        st &= (1 << 62) - 1
+                        word >>= 32
+        m = self._moments(False)
+        sums = np.array([m[0], m[1]], dtype=np.float64).view(np.int64)
+        return np.array([st, sums[0], sums[1]], dtype=np.int64)
+
+    def check_replicas(self):
+        """All-gather the digest of this rank's replica and raise — on every rank, they all see the same
+        table — if the ranks of a sharded object no longer hold the same experiment.  Called every
+        ``tuning_parameters['replica_check_every']`` sharded sweeps (default 64; 0 = never)."""
+        shard = self._shard
+        if shard is None or shard.world_size == 1:
+            return True
+        table = shard.all_gather_int64(self._replica_digest(), self._device)
+        bad = [r for r in range(shard.world_size) if not np.array_equal(table[r], table[0])]
+        if bad:
+            what = [name for k, name in enumerate(("generator state", "sum of weights", "sum of squared weights"))
+                    if np.any(table[:, k] != table[0, k])]
+            raise RuntimeError(f"sharded OptBayesExpt: the replicas on ranks {bad} differ from rank 0 in "
+                               f"{', '.join(what)} — every rank must apply the same measurements and draw "
+                               "from the same generator (assign `rng` on all ranks, never on one)")
+        return True
 
     def set_n_draws(self, n_draws=None):
         """obe_base.py:274-296."""
@@ -474,6 +532,11 @@ class OptBayesExpt(ParticlePDF):
         mom = self._moments_on_device()
 
         sharded = self._shard is not None     # every sweep of a sharded object gathers: ranks stay in lockstep
+        if sharded:
+            every = int(self.tuning_parameters.get("replica_check_every", 64) or 0)
+            self._sharded_sweeps += 1
+            if every > 0 and self._sharded_sweeps % every == 0:
+                self.check_replicas()
         result = {}
         # Nobody waits for this sweep: its caller wants the utility on the device (good_setting,
         # utility_variance), a draws-mode sweep is always shifted (kappa decides nothing) and the model's

@@ -125,6 +125,20 @@ class ParticlePDF:
         self.last_draw_indices_device = None
 
     @property
+    def rng(self):
+        """The numpy ``Generator`` behind ``randdraw()`` and ``resample()`` (particlepdf.py:142-145):
+        a public attribute of the reference that callers reseed by assignment."""
+        return self._rng
+
+    @rng.setter
+    def rng(self, value):
+        self._rng = value
+        self._rng_assigned()
+
+    def _rng_assigned(self):
+        """Hook: OptBayesExpt makes the replicas of a sharded object adopt rank 0's generator."""
+
+    @property
     def particles(self):
         """``n_dims x n_particles`` ndarray (host mirror of the device array)."""
         return self._particles.host()

@@ -45,6 +45,23 @@ def _utility_cases():
     return cases
 
 
+class _ShardedStub:
+    """The generator logic of OptBayesExpt on a sharded settings axis, without a GPU: the
+    methods themselves, bound to an object that has only the attributes they touch."""
+    from optbayesexpt_amd.obe_base import OptBayesExpt as _cls
+    _sync_rng = _cls._sync_rng
+    _device = "cpu"
+
+    def __init__(self, shard, rng):
+        self._shard, self._rng = shard, rng
+
+
+def _adopt_rank0_generator(shard, rng):
+    stub = _ShardedStub(shard, rng)
+    stub._sync_rng()
+    return stub._rng.random(5), type(stub._rng.bit_generator).__name__
+
+
 def _worker(rank, world, port, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -74,6 +91,12 @@ def _worker(rank, world, port, ret):
         i = shard.broadcast_from_rank0(np.atleast_1d(mine.choice(np.arange(1000))))
         ret[rank] = results
         ret[f"bcast{rank}"] = (f, i)
+        # the generator of a sharded object: every rank adopts rank 0's (unseeded) state
+        ret[f"rng{rank}"] = _adopt_rank0_generator(shard, np.random.default_rng())
+        ret[f"rng_mt{rank}"] = _adopt_rank0_generator(
+            shard, np.random.Generator(np.random.MT19937(5)) if rank == 0 else np.random.default_rng())
+        table = shard.all_gather_int64(np.array([7, rank, -rank]))
+        assert table.shape == (world, 3) and table[:, 1].tolist() == list(range(world))
     finally:
         dist.destroy_process_group()
 
@@ -94,3 +117,7 @@ def test_sharded_argmax_and_gather_match_single_process(world):
         np.testing.assert_array_equal(ret[f"bcast{rank}"][0], rank0.normal(0, 1, 7))
         got = ret[f"bcast{rank}"][1]
         assert got.dtype == np.int64 and got[0] == rank0.choice(np.arange(1000))
+        # unseeded generators: all ranks continue rank 0's stream; a different bit generator is adopted too
+        np.testing.assert_array_equal(ret[f"rng{rank}"][0], ret["rng0"][0])
+        np.testing.assert_array_equal(ret[f"rng_mt{rank}"][0], np.random.Generator(np.random.MT19937(5)).random(5))
+        assert ret[f"rng_mt{rank}"][1] == "MT19937"

@@ -133,3 +133,86 @@ def test_two_ranks_share_one_gpu(hip):
         np.testing.assert_allclose(util, ref_util, rtol=1e-12)
     assert [l[2] for l in ret[0][0]] == [l[2] for l in ret[1][0]]           # lock-step shift decisions
     assert sum(l[1] for l in ref_log) >= 1
+
+
+def _unseeded_log(obe_mod, shard, rank):
+    """A sharded object built the way every demo builds one — `rng` never assigned (the reference's
+    generator is unseeded, particlepdf.py:142-145) — through 20 cycles with resamples."""
+    import bench
+    settings, prior, cons, true, sigma = bench.make_workload("c2")
+    sv = (np.ascontiguousarray(settings[0][::8]),)
+    o = obe_mod.OptBayesExpt(obe_mod.models.lorentzian(), sv, prior[:, :65536].copy(), cons, scale=False,
+                             default_noise_std=sigma, settings_shard=shard)       # reference semantics: 30 draws
+    o.tuning_parameters["replica_check_every"] = 5
+    sim = np.random.default_rng(77)                     # the "experiment": the same data on every rank
+    log = []
+    for cyc in range(20):
+        x = o.opt_setting() if cyc % 4 else o.good_setting(pickiness=9)
+        y = float(o.model_function(x, true, cons)) + sigma * sim.standard_normal()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            o.pdf_update((x, y, sigma))
+        log.append((int(o.last_setting_index), bool(o.just_resampled)))
+    assert o.check_replicas()
+    digest = o._replica_digest().tolist()
+    mean, w = o.mean(), np.array(o.particle_weights)
+    # a generator assigned on every rank with DIFFERENT seeds: rank 0's is adopted (collective assignment)
+    o.rng = np.random.default_rng(1000 + rank)
+    after = o.rng.random(3)
+    # ... and one that is pushed in behind the setter's back is what check_replicas() exists for
+    o._rng = np.random.default_rng(2000 + rank)
+    try:
+        o.check_replicas()
+        caught = ""
+    except RuntimeError as exc:
+        caught = str(exc)
+    return log, digest, mean, w, after, caught
+
+
+def _unseeded_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import optbayesexpt_amd as obe_mod
+        ret[rank] = _unseeded_log(obe_mod, obe_mod.SettingsShard(), rank)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_unseeded_sharded_objects_stay_one_experiment(hip):
+    """nobody seeds anything, and the two ranks still pick identical settings and
+    resample together for 20 cycles; a desynchronised generator is reported on every rank."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_unseeded_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    a, b = ret[0], ret[1]
+    assert a[0] == b[0]                                   # settings and resample decisions, cycle by cycle
+    assert sum(r for _, r in a[0]) >= 1                   # ... through at least one resample
+    assert a[1] == b[1]
+    np.testing.assert_array_equal(a[2], b[2])
+    np.testing.assert_array_equal(a[3], b[3])             # bit-identical replicas of the weights
+    np.testing.assert_array_equal(a[4], b[4])
+    np.testing.assert_array_equal(a[4], np.random.default_rng(1000).random(3))
+    assert "generator state" in a[5] and "ranks [1]" in a[5] and a[5] == b[5]
+
+
+def test_bench_starts_its_own_ranks(hip):
+    """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's command):
+    two ranks share this box's one GPU over gloo (the numbers of such a run mean nothing), one JSON
+    line, exit code 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(OBE_BENCH_BACKEND="gloo", OBE_BENCH_ONE_DEVICE="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "c2", "--steps", "4",
+                        "--warmup", "2"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["config"]["settings_per_rank"] == 2048
+    assert out["value"] > 0 and "roofline" in out

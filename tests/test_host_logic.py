@@ -330,3 +330,31 @@ def test_classes_carry_every_public_method_of_the_reference_classes():
     for cls, names in ((obe.ParticlePDF, pdf), (obe.OptBayesExpt, base), (obe.OptBayesExptNoiseParameter, base)):
         missing = [n for n in names if not callable(getattr(cls, n, None))]
         assert not missing, (cls.__name__, missing)
+
+
+def test_bench_launches_its_own_ranks_and_reports_failure(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it starts its two ranks itself (fresh
+    processes, before anything touches the GPU).  Without a GPU both ranks fail: the launcher must
+    come back with a non-zero exit code and no JSON line, not hang."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("the failure path needs a box without a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "c1", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert r.stdout.strip() == ""
+    assert "ranks failed" in r.stderr
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr
