@@ -61,6 +61,11 @@ class SettingsShard:
     def bounds(self, n_settings):
         return shard_bounds(n_settings, self.rank, self.world_size)
 
+    def connected(self):
+        """True when there are other ranks to talk to (a shard built with an explicit rank / world_size in
+        a process without torch.distributed — one slice of a sweep computed on its own — has none)."""
+        return self.world_size > 1 and dist.is_available() and dist.is_initialized()
+
     def _comm_device(self, device):
         backend = dist.get_backend(self.group)
         return torch.device(device) if backend == "nccl" else torch.device("cpu")

@@ -252,7 +252,7 @@ class OptBayesExpt(ParticlePDF):
         object is built, and again whenever ``rng`` is assigned (both are collective on a sharded
         object: every rank runs the same script).  Ranks that were seeded alike are left as they are."""
         shard = self.__dict__.get("_shard")
-        if shard is None or shard.world_size == 1:
+        if shard is None or not shard.connected():
             return
         bg = getattr(self._rng, "bit_generator", None)
         state = shard.broadcast_object_from_rank0(None if bg is None else bg.state, self._device)
@@ -284,7 +284,7 @@ class OptBayesExpt(ParticlePDF):
         table — if the ranks of a sharded object no longer hold the same experiment.  Called every
         ``tuning_parameters['replica_check_every']`` sharded sweeps (default 64; 0 = never)."""
         shard = self._shard
-        if shard is None or shard.world_size == 1:
+        if shard is None or not shard.connected():
             return True
         table = shard.all_gather_int64(self._replica_digest(), self._device)
         bad = [r for r in range(shard.world_size) if not np.array_equal(table[r], table[0])]

@@ -202,3 +202,63 @@ def replay_sweeper(fx, obe, rtol, set_sweep_rng, get_draw_idx=None, get_utility=
     close(obe.particle_weights, fx["w_snaps"][-1], rtol, "weights, last cycle")
     assert pos == len(fx["y_concat"])
     return dict(cycles=meta["n_cycles"], points=points)
+
+
+def generator_from_words(state_words, inc_words):
+    """A PCG64 Generator in the recorded state ([hi, lo] 64-bit halves of the 128-bit state and increment)."""
+    g = np.random.Generator(np.random.PCG64())
+    st = g.bit_generator.state
+    st["state"]["state"] = (int(state_words[0]) << 64) | int(state_words[1])
+    st["state"]["inc"] = (int(inc_words[0]) << 64) | int(inc_words[1])
+    st["has_uint32"], st["uinteger"] = 0, 0
+    g.bit_generator.state = st
+    return g
+
+
+def replay_state_reset(fx, obe, rtol, get_draw_idx, get_utility, get_resample_idx, particle_floor_units=256):
+    """tests/golden/state_multilorentz7_noise.npz: EVERY cycle starts from the reference's own recorded
+    state (particles, weights, generator), so one opt_setting + pdf_update step is compared with the
+    reference's at ``rtol`` without the drift of a free-running 10-parameter trajectory.  Integers
+    (draws, chosen setting, resample decision, resample indices, constrained particles) exact."""
+    meta = fx["meta"]
+    n_res = 0
+    worst = dict(utility=0.0, weights=0.0, particles=0.0)
+    for cyc in range(meta["n_cycles"]):
+        obe.set_pdf(fx["particles_before"][cyc].copy())
+        obe.particle_weights = fx["weights_before"][cyc].copy()
+        obe.parameters = obe.particles                     # (set_pdf leaves the alias stale: obe_base.py:185,395)
+        obe.rng = generator_from_words(fx["rng_state_before"][cyc], fx["rng_inc"][cyc])
+        x = obe.opt_setting()
+        assert_array_equal(np.asarray(get_draw_idx(obe)), fx["draw_idx"][cyc], err_msg=f"draw indices, cycle {cyc}")
+        u = np.asarray(get_utility(obe), dtype=np.float64).reshape(-1)
+        close(u, fx["utility"][cyc], rtol, f"utility, cycle {cyc}")
+        worst["utility"] = max(worst["utility"], float(np.max(np.abs(u / fx["utility"][cyc] - 1))))
+        assert int(obe.last_setting_index) == int(fx["chosen_index"][cyc]), f"chosen setting, cycle {cyc}"
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            obe.pdf_update((x, float(fx["y_meas"][cyc])))
+        assert bool(obe.just_resampled) == bool(fx["resampled"][cyc]), f"resample decision, cycle {cyc}"
+        w = np.asarray(obe.particle_weights, dtype=np.float64)
+        want_w = fx["weights_after"][cyc]
+        close(w, want_w, rtol, f"weights, cycle {cyc}")
+        assert_array_equal(w == 0.0, want_w == 0.0, err_msg=f"zero weights, cycle {cyc}")
+        worst["weights"] = max(worst["weights"], float(np.max(np.abs(w - want_w)) / np.max(want_w)))
+        if fx["resampled"][cyc]:
+            n_res += 1
+            assert_array_equal(np.asarray(get_resample_idx(obe)), fx["resample_idx"][cyc],
+                               err_msg=f"resample indices, cycle {cyc}")
+            assert int(np.sum(w == 0.0)) == int(fx["n_constrained"][cyc])
+            got, want = np.asarray(obe.particles, dtype=np.float64), fx["particles_after"][cyc]
+            # absolute floor of the SVD nudge (see replay()): eps * sqrt(largest eigenvalue of the covariance)
+            pre_cov = np.cov(fx["particles_before"][cyc], aweights=fx["weights_before"][cyc])
+            floor = particle_floor_units * 2.3e-16 * np.sqrt(np.max(np.linalg.eigvalsh(pre_cov)))
+            for d in range(want.shape[0]):
+                assert_allclose(got[d], want[d], rtol=rtol, atol=floor, err_msg=f"particles[{d}] after resample, cycle {cyc}")
+            worst["particles"] = max(worst["particles"], float(np.max(np.abs(got - want)) / floor * particle_floor_units))
+        mtol = rtol * (np.abs(fx["mean"][cyc]) + fx["std"][cyc])
+        assert np.all(np.abs(np.asarray(obe.mean()) - fx["mean"][cyc]) <= mtol), f"mean, cycle {cyc}"
+        sd = fx["std"][cyc]
+        tol = rtol * sd + 64 * 2.3e-16 * fx["mean"][cyc] ** 2 / np.maximum(sd, 1e-300)
+        assert np.all(np.abs(np.asarray(obe.std()) - sd) <= tol), f"std, cycle {cyc}"
+        close(obe.covariance(), fx["cov"][cyc], rtol, f"covariance, cycle {cyc}")
+    return dict(cycles=meta["n_cycles"], resamples=n_res, worst=worst)

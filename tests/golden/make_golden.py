@@ -365,6 +365,129 @@ def full_sweep_cases():
     print("full_sweep_uniform: written")
 
 
+class IntegerWeightsMixin:
+    """The real reference as the oracle of the WEIGHTED full sweep: ``randdraw``
+    returns particle i duplicated k_i times (integer multiplicities, zeros included), so the
+    reference's own ``np.var`` over the N_DRAWS = sum(k) model outputs (obe_base.py:463-489) IS the
+    weighted variance with w_i = k_i / sum(k) — exactly, not statistically."""
+    multiplicity = None
+
+    def randdraw(self, n_draws=1):
+        if self.multiplicity is not None and n_draws == int(self.multiplicity.sum()):
+            return np.repeat(np.array(self.particles, dtype=np.float64), self.multiplicity, axis=1)
+        return super().randdraw(n_draws)
+
+
+class IntegerWeightsRef(IntegerWeightsMixin, ref.OptBayesExpt):
+    pass
+
+
+class IntegerWeightsRefNoise(IntegerWeightsMixin, ref.OptBayesExptNoiseParameter):
+    pass
+
+
+def full_sweep_integer_weights():
+    g = np.random.default_rng(27182)
+    arrays = {}
+
+    def case(tag, cls, model, sv, prior, cons, **ctor):
+        n = prior.shape[1]
+        k = g.integers(0, 8, n)                     # k_i in [0, 7], about one particle in eight unweighted
+        k[g.integers(0, n, 5)] = 0
+        obe = cls(model, sv, prior.copy(), cons, n_draws=int(k.sum()), **ctor)
+        obe.multiplicity = k
+        obe.particle_weights = k / k.sum()          # (the noise-parameter class weights its sigma^2 with these)
+        arrays[f"iw_{tag}_prior"], arrays[f"iw_{tag}_k"] = prior, k
+        arrays[f"iw_{tag}_yvar"] = obe.yvar_from_parameter_draws()
+        arrays[f"iw_{tag}_utility"] = obe.utility()
+        print(f"integer weights {tag}: {n} particles, {int(k.sum())} draws, {int((k == 0).sum())} with k = 0")
+
+    n = 2048
+    x48 = np.linspace(1.5, 4.5, 48)
+    arrays["iw_x48"] = x48
+    case("lor", IntegerWeightsRef, models.lorentzian, (x48,), lorentz_prior(g, n), (0.1,), default_noise_std=500.0)
+    # a narrowed cloud far from zero mean (kappa ~ 1e4: the regime of the shifted variance)
+    narrow = np.array([g.normal(3.0, 0.004, n), g.normal(-1000.0, 8.0, n), g.normal(50000.0, 15.0, n)])
+    case("lornarrow", IntegerWeightsRef, models.lorentzian, (x48,), narrow, (0.1,), default_noise_std=500.0)
+    prior = np.vstack([g.uniform(2, 4, (7, n)), g.uniform(400, 2000, (1, n)),
+                       g.normal(500, 1000, (1, n)), g.exponential(500, (1, n))])
+    case("ml7", IntegerWeightsRefNoise, models.multi_lorentzian(7), (x48,), prior, (0.1,), noise_parameter_index=9)
+    n = 1024
+    prior = np.array([g.uniform(0.9, 1.1, n), g.uniform(0.08, 0.12, n),
+                      g.uniform(0.9, 1.1, n), g.exponential(0.3, n)])
+    wset = np.logspace(-1, 1, 40)
+    arrays["iw_coil_w"] = wset
+    case("coil", IntegerWeightsRefNoise, models.coil, (wset,), prior, (), noise_parameter_index=(3, 3))
+    prior = np.array([g.uniform(1.0, 6.0, n), g.uniform(-4, 4, n)])
+    sv = (np.linspace(0.02, 1, 13), np.linspace(-10, 10, 9))
+    arrays["iw_rabi_s0"], arrays["iw_rabi_s1"] = sv
+    case("rabi", IntegerWeightsRef, models.rabi, sv, prior, (100000.0, 0.01, 2.0), default_noise_std=300.0)
+    np.savez_compressed(os.path.join(HERE, "full_sweep_integer_weights.npz"), **arrays)
+    print("full_sweep_integer_weights: written")
+
+
+def state_reset_10_parameters():
+    """The 10-parameter noise-parameter trajectory (config 5 in miniature) once more, shorter, with the
+    COMPLETE state before every cycle (particles, weights, generator state) and everything the cycle
+    produces: a replay can start every cycle from the reference's own state, so that one step is
+    compared at 1e-10 although the free-running trajectory drifts (the SVD nudge of resample()
+    amplifies last-bit differences of the covariance: DESIGN.md section 5)."""
+    g = np.random.default_rng(20240426)
+    n, n_cycles, seed = 2048, 12, 717
+    fn = MODELS["multi_lorentzian_7"]
+    prior = np.vstack([g.uniform(2, 4, (7, n)), g.uniform(400, 2000, (1, n)),
+                       g.normal(500, 1000, (1, n)), g.exponential(1000, (1, n))])
+    sv = (np.linspace(1.5, 4.5, 48),)
+    cons = (0.1,)
+    true_pars = (2.2, 2.5, 2.8, 3.1, 3.4, 3.7, 3.9, 1000.0, 500.0, 1000.0)
+    ctor = dict(scale=False, noise_parameter_index=9)
+    obe = ref.OptBayesExptNoiseParameter(fn, sv, prior.copy(), cons, **ctor)
+    rng = RecordingRNG(seed)
+    obe.rng = rng
+    sim = np.random.default_rng(seed + 1)
+    out = dict(particles_before=[], weights_before=[], rng_state_before=[], rng_inc=[], draw_idx=[], utility=[],
+               noise_var=[], chosen_index=[], y_meas=[], resampled=[], resample_idx=[], particles_after=[],
+               weights_after=[], mean=[], std=[], cov=[], n_constrained=[])
+    for cyc in range(n_cycles):
+        st = rng._g.bit_generator.state
+        assert st["bit_generator"] == "PCG64" and st["has_uint32"] == 0
+        out["particles_before"].append(np.array(obe.particles, dtype=np.float64))
+        out["weights_before"].append(np.array(obe.particle_weights, dtype=np.float64))
+        s128, i128 = int(st["state"]["state"]), int(st["state"]["inc"])
+        out["rng_state_before"].append([s128 >> 64, s128 & (2 ** 64 - 1)])
+        out["rng_inc"].append([i128 >> 64, i128 & (2 ** 64 - 1)])
+        rng.choices.clear()
+        util = obe.utility()
+        out["draw_idx"].append(rng.choices[0].copy())
+        best = int(np.argmax(util))
+        obe.last_setting_index = best
+        x = tuple(obe.allsettings[:, best])
+        out["noise_var"].append(np.asarray(obe.yvar_noise_model(), dtype=np.float64).reshape(-1))
+        y = float(fn(x, true_pars, cons)) + 1000.0 * sim.standard_normal()
+        rng.choices.clear()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            obe.pdf_update((x, y))
+        out["utility"].append(np.asarray(util).reshape(-1))
+        out["chosen_index"].append(best)
+        out["y_meas"].append(y)
+        out["resampled"].append(bool(obe.just_resampled))
+        out["resample_idx"].append(rng.choices[0].copy() if obe.just_resampled else np.zeros(n, dtype=np.int64))
+        out["particles_after"].append(np.array(obe.particles, dtype=np.float64))
+        out["weights_after"].append(np.array(obe.particle_weights, dtype=np.float64))
+        out["n_constrained"].append(int(np.sum(np.asarray(obe.particle_weights) == 0.0)) if obe.just_resampled else 0)
+        out["mean"].append(obe.mean())
+        out["std"].append(obe.std())
+        out["cov"].append(obe.covariance())
+    meta = dict(name="state10", model="multi_lorentzian_7", cls="noise", ctor=ctor, seed=seed, n_cycles=n_cycles,
+                true_pars=list(true_pars), numpy=np.__version__, reference=ref.__version__)
+    arrays = {k: np.array(v, dtype=np.uint64 if k.startswith("rng_") else None) for k, v in out.items()}
+    arrays.update(prior=prior, cons=np.array(cons), setval_0=sv[0], meta=np.array(json.dumps(meta)))
+    path = os.path.join(HERE, "state_multilorentz7_noise.npz")
+    np.savez_compressed(path, **arrays)
+    print(f"state10: {n_cycles} cycles, {int(np.sum(out['resampled']))} resamples, {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def sweeper_cases():
     """the sweeper composition.  The reference's OptBayesExptSweeper lives in
     demos/sweeper/obe_sweeper.py (a subclass of OptBayesExptNoiseParameter); it is loaded
@@ -444,6 +567,7 @@ def sweeper_cases():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["trajectories", "yspace", "units", "full_sweep", "sweeper"]
     steps = dict(trajectories=trajectories, yspace=yspace_utilities, units=unit_cases,
-                 full_sweep=full_sweep_cases, sweeper=sweeper_cases, demo_size=demo_size)
+                 full_sweep=full_sweep_cases, sweeper=sweeper_cases, demo_size=demo_size,
+                 integer_weights=full_sweep_integer_weights, state10=state_reset_10_parameters)
     for w in which:
         steps[w]()

@@ -57,6 +57,29 @@ def test_trajectory_with_device_rng_forced(hip, name, monkeypatch):
     assert o.rng.bit_generator.state["state"]["inc"] == ref.bit_generator.state["state"]["inc"]
 
 
+@pytest.mark.parametrize("device_rng", [False, True])
+def test_state_reset_replay_of_the_10_parameter_model(hip, device_rng, monkeypatch):
+    """the 7-peak / 10-parameter noise-parameter model (config 5 in miniature) at
+    1e-10 per step.  Every cycle starts from the REFERENCE's recorded state (particles, weights,
+    generator), so the conditioning of one resample cannot leak into the next cycle; the free-running
+    `multilorentz7_noise` trajectory (1e-6) remains the drift test.  Draws, chosen setting, resample
+    decision, resample indices and the constrained particles exact; utility, weights, moments 1e-10;
+    resampled particles 1e-10 with the absolute floor of the reference's SVD nudge."""
+    import optbayesexpt_amd as obe
+    from optbayesexpt_amd import _devrng
+    if device_rng:
+        monkeypatch.setattr(_devrng, "MIN_DEVICE_DRAWS", 64)
+    fx = _replay.load("state_multilorentz7_noise.npz")
+    o = obe.OptBayesExptNoiseParameter(obe.models.lorentzian(7), (fx["setval_0"],), fx["prior"].copy(),
+                                       tuple(fx["cons"]), scale=False, noise_parameter_index=9)
+    stats = _replay.replay_state_reset(fx, o, RTOL, lambda x: x.last_draw_indices,
+                                       lambda x: x._utility_dev.cpu().numpy(),
+                                       lambda x: x.last_resample_indices_device.cpu().numpy(),
+                                       particle_floor_units=2048)
+    print("state-reset replay, worst relative differences:", stats["worst"])
+    assert stats["resamples"] == int(np.sum(fx["resampled"])) >= 5
+
+
 @pytest.mark.parametrize("name", ["lorentz3_opt", "line_noiseparam"])
 def test_trajectory_strict_cdf(hip, name):
     """Same replay with the serial-order CDF (tuning_parameters['strict_cdf'])."""

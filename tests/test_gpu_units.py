@@ -447,6 +447,39 @@ def test_full_sweep_nonuniform_weights_matches_oracle(obe):
         assert_allclose(yvar, ref, rtol=RTOL, atol=1e-13 * ref.max(), err_msg=tag)
 
 
+@pytest.mark.parametrize("shift", ["always", "never", "auto"])
+def test_weighted_full_sweep_matches_the_reference_with_integer_multiplicities(obe, shift):
+    """the weighted full sweep — the mode every BASELINE config runs in — against the REAL
+    reference.  The fixture drove the reference with randdraw() returning particle i duplicated k_i times
+    (k in 0..7, zeros included): its np.var over the sum(k) draws (obe_base.py:463-489) is the weighted
+    variance with w = k / sum(k) exactly.  HIP `variance_full` with those weights, both variance-shift
+    variants (and what the adaptive policy picks), 1e-10; the chosen setting exact."""
+    f = _replay.load("full_sweep_integer_weights.npz")
+    m = obe.models
+    cases = [("lor", m.lorentzian(), (f["iw_x48"],), (0.1,), None, 500.0),
+             ("lornarrow", m.lorentzian(), (f["iw_x48"],), (0.1,), None, 500.0),
+             ("ml7", m.lorentzian(7), (f["iw_x48"],), (0.1,), 9, None),
+             ("coil", m.coil(), (f["iw_coil_w"],), (), (3, 3), None),
+             ("rabi", m.rabi(), (f["iw_rabi_s0"], f["iw_rabi_s1"]), (100000.0, 0.01, 2.0), None, 300.0)]
+    for tag, dm, sv, cons, nidx, nstd in cases:
+        if shift == "never" and tag == "lornarrow":
+            continue          # kappa ~ 1e5: the unshifted one-pass variance is not meant for it (the policy never picks it)
+        k = f[f"iw_{tag}_k"]
+        o = _make(obe, dm, sv, f[f"iw_{tag}_prior"], cons, nidx, nstd, auto_resample=False)
+        o.tuning_parameters["sweep_shift"] = shift
+        o.particle_weights = k / k.sum()
+        yvar = o.yvar_from_parameter_draws()
+        ref = f[f"iw_{tag}_yvar"]
+        assert yvar.shape == ref.shape
+        assert_allclose(yvar, ref, rtol=RTOL, atol=1e-13 * ref.max(), err_msg=f"{tag} {shift}")
+        want = f[f"iw_{tag}_utility"]
+        assert_allclose(o.utility(), want, rtol=RTOL, atol=1e-13 * want.max(), err_msg=f"{tag} {shift}")
+        o.opt_setting()
+        assert o.last_setting_index == int(np.argmax(want))
+        if shift == "auto" and tag == "lornarrow":
+            assert o.last_sweep["shifted"] and o.last_sweep["kappa"] > 3000
+
+
 def test_sweep_shapes_ragged(obe):
     """Setting counts around every tile boundary, particle counts around chunk/tile
     boundaries, draws mode and full mode; against the oracle."""

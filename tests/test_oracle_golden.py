@@ -132,6 +132,42 @@ def test_full_sweep_matches_reference_limit():
         assert_allclose(yvar, ref, rtol=1e-11, atol=1e-13 * ref.max(), err_msg=tag)
 
 
+def test_weighted_full_sweep_matches_the_reference_with_integer_multiplicities():
+    """VERDICT r3 #3 / SURVEY 8(c): the weighted full sweep pinned to the REAL reference, exactly.  The
+    fixture drove the reference with randdraw() returning particle i duplicated k_i times (k in 0..7), so
+    its np.var over the sum(k) draws (obe_base.py:463-489) is the weighted variance with w = k / sum(k)."""
+    f = _replay.load("full_sweep_integer_weights.npz")
+    cases = [("lor", models.lorentzian, (f["iw_x48"],), (0.1,), 500.0 ** 2, None),
+             ("lornarrow", models.lorentzian, (f["iw_x48"],), (0.1,), 500.0 ** 2, None),
+             ("ml7", models.multi_lorentzian(7), (f["iw_x48"],), (0.1,), None, (9,)),
+             ("coil", models.coil, (f["iw_coil_w"],), (), None, (3, 3)),
+             ("rabi", models.rabi, (f["iw_rabi_s0"], f["iw_rabi_s1"]), (100000.0, 0.01, 2.0), 300.0 ** 2, None)]
+    for tag, fn, sv, cons, noise_var, noise_rows in cases:
+        prior, k = f[f"iw_{tag}_prior"], f[f"iw_{tag}_k"]
+        assert k.min() == 0 and k.max() == 7
+        w = k / k.sum()
+        yvar = oracle.yvar_full_sweep(fn, oracle.flatten_settings(sv), prior, w, cons, chunk=300)
+        ref = f[f"iw_{tag}_yvar"]
+        assert yvar.shape == ref.shape
+        assert_allclose(yvar, ref, rtol=ORACLE_RTOL * 10, atol=1e-13 * ref.max(), err_msg=tag)
+        if noise_rows is not None:       # obe_noiseparam.py:122-136
+            noise_var = np.array([np.average(prior[r] ** 2, weights=w) for r in noise_rows]).reshape(-1, 1)
+        util = oracle.utility_from_yvar(yvar, noise_var, 1.0)
+        assert_allclose(util, f[f"iw_{tag}_utility"], rtol=ORACLE_RTOL * 10, err_msg=tag)
+
+
+def test_state_reset_replay_of_the_10_parameter_model():
+    """every cycle of the 7-peak noise-parameter model from the reference's own
+    state, at the oracle's tolerance (the free-running trajectory above stays as the drift test)."""
+    fx = _replay.load("state_multilorentz7_noise.npz")
+    obe = oracle.OracleOptBayesExptNoiseParameter(models.multi_lorentzian(7), (fx["setval_0"],), fx["prior"].copy(),
+                                                  tuple(fx["cons"]), scale=False, noise_parameter_index=9)
+    stats = _replay.replay_state_reset(fx, obe, ORACLE_RTOL, lambda o: o.last_draw_indices, lambda o: o.last_utility,
+                                       lambda o: o.last_draw_indices)
+    assert stats["resamples"] == int(np.sum(fx["resampled"])) >= 5
+    assert int(np.max(fx["n_constrained"])) > 0          # the constraint mask is exercised
+
+
 # ---- the reference's own unit-test expectations, restated against the oracle ----
 
 def _toy_pdf():
