@@ -4,6 +4,8 @@
 
 #include <atomic>
 #include <chrono>
+#include <mutex>
+#include <unordered_map>
 
 #include "obe_common.h"
 #include "obe_models.h"
@@ -27,6 +29,50 @@ int wait_host_word(const void* h_word, hipStream_t st) {
     }
     OBE_HIP_TRY(hipStreamSynchronize(st));       // long kernel, or one that never delivered: the stream knows
     return 0;
+}
+
+// Arrival counters for "the last workgroup to finish folds the partials" (obe_moments.h: arrive_last):
+// one zeroed 128-byte slot of device memory per (device, stream), allocated in one small block per device
+// on first use and never freed.  Kernels on one stream never overlap, the counter wraps back to zero with
+// the last arrival (atomicInc), so a slot is always zero between launches — no per-call memset, and nothing
+// is asked of the caller's workspace.  nullptr (table full, allocation failed): callers fold in a launch
+// of their own.
+namespace {
+struct ControlTable {
+    std::mutex mu;
+    std::unordered_map<uint64_t, unsigned*> slot;      // (device << 56) ^ stream -> its words
+    unsigned* base[64] = {};
+    int used[64] = {};
+};
+ControlTable& control_table() {
+    static ControlTable* t = new ControlTable;          // (leaked on purpose: no destructor order games at exit)
+    return *t;
+}
+constexpr int kControlSlots = 256, kControlSlotWords = 32;
+}  // namespace
+
+unsigned* stream_control_words(hipStream_t st) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    ControlTable& t = control_table();
+    const uint64_t key = ((uint64_t)dev << 56) ^ (uint64_t)reinterpret_cast<uintptr_t>(st);
+    std::lock_guard<std::mutex> lock(t.mu);
+    auto it = t.slot.find(key);
+    if (it != t.slot.end()) return it->second;
+    if (!t.base[dev]) {
+        void* p = nullptr;
+        const size_t bytes = (size_t)kControlSlots * kControlSlotWords * sizeof(unsigned);
+        if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess ||
+            hipDeviceSynchronize() != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        t.base[dev] = static_cast<unsigned*>(p);
+    }
+    if (t.used[dev] >= kControlSlots) return nullptr;
+    unsigned* w = t.base[dev] + (size_t)t.used[dev]++ * kControlSlotWords;
+    t.slot.emplace(key, w);
+    return w;
 }
 
 static thread_local std::string g_last_error;

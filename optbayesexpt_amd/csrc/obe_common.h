@@ -67,6 +67,36 @@ int wait_host_word(const void* h_word, hipStream_t st);      // obe_capi.hip
 // device side: everything stored to the host before this call is visible there before what follows
 __device__ __forceinline__ void host_results_before_flag() { __threadfence_system(); }
 
+// ---- "the last workgroup to arrive folds": arrival counter + write-through partials ----
+// Zeroed device words owned by the library, one slot per (device, stream) (obe_capi.hip); nullptr: none.
+unsigned* stream_control_words(hipStream_t st);
+
+// A block partial that another workgroup of the same launch will read: written through to memory
+// (a relaxed agent-scope atomic store lowers to `global_store ... sc1`), so publishing needs no release
+// fence — an agent-scope release writes back every dirty line of the XCD's L2, i.e. the weights the
+// kernel has just written (MI355X_MICROARCH.md, inter-workgroup visibility: publish-large).
+__device__ __forceinline__ void store_published(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Call after every thread of the workgroup has issued its store_published() calls.  Returns true in
+// EVERY thread of the workgroup that arrived last: by then all workgroups' published values are in
+// memory, and after the acquire below plain loads see them.  The counter wraps to zero with the last
+// arrival (atomicInc), ready for the next launch on the stream.  `flag` = one int of LDS.
+__device__ __forceinline__ bool arrive_last(unsigned* counter, int* flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned ticket = atomicInc(counter, gridDim.x - 1);      // device scope
+        const int last = ticket == gridDim.x - 1;
+        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");    // drop this CU's stale lines
+        *flag = last;
+    }
+    __syncthreads();
+    return *flag != 0;
+}
+
 inline int stream_blocks(int64_t n, int per_block) {
     int64_t b = (n + per_block - 1) / per_block;
     if (b < 1) b = 1;
