@@ -84,13 +84,16 @@ __device__ __forceinline__ void store_published(double* p, double v) {
 // EVERY thread of the workgroup that arrived last: by then all workgroups' published values are in
 // memory, and after the acquire below plain loads see them.  The counter wraps to zero with the last
 // arrival (atomicInc), ready for the next launch on the stream.  `flag` = one int of LDS.
+// ACQUIRE = false: the caller reads the published values with load_published() (sc1 loads, past this CU's
+// L1) instead of plain loads behind an agent-scope acquire (~1.7 us).
+template <bool ACQUIRE = true>
 __device__ __forceinline__ bool arrive_last(unsigned* counter, int* flag) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned ticket = atomicInc(counter, gridDim.x - 1);      // device scope
         const int last = ticket == gridDim.x - 1;
-        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");    // drop this CU's stale lines
+        if (ACQUIRE && last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");    // drop this CU's stale lines
         *flag = last;
     }
     __syncthreads();

@@ -76,7 +76,9 @@ __device__ __forceinline__ void reduce_value_groups(const double (&v)[NV], doubl
     }
 }
 
-template <int NV>
+// PUBLISHED: the row is read by another workgroup of the same launch (the last one to arrive folds,
+// obe_common.h: arrive_last) and is therefore stored write-through.
+template <int NV, bool PUBLISHED = false>
 __device__ __forceinline__ void store_block_partials(double (&v)[NV], double* __restrict__ partials) {
     constexpr int NW = kBlock / kWave;
     __shared__ double red[NW][NV];
@@ -87,7 +89,8 @@ __device__ __forceinline__ void store_block_partials(double (&v)[NV], double* __
         double s = 0.0;
 #pragma unroll
         for (int i = 0; i < NW; ++i) s += red[i][k];
-        partials[(int64_t)blockIdx.x * NV + k] = s;
+        if constexpr (PUBLISHED) store_published(partials + (int64_t)blockIdx.x * NV + k, s);
+        else partials[(int64_t)blockIdx.x * NV + k] = s;
     }
 }
 
@@ -110,9 +113,16 @@ __device__ __forceinline__ void accumulate_first_moments(double (&v)[2 + 2 * D],
 // values of a 10-parameter covariance).  `vals` in LDS.
 constexpr int kFoldThreads = 1024;
 constexpr int kFoldBatch = 4;
-__device__ __forceinline__ void fold_values_block(const double* __restrict__ partials, int nb, int nv,
-                                                  double* __restrict__ vals) {
-    constexpr int NW = kFoldThreads / kWave;
+// (NT threads in the folding workgroup: which wave folds a value does not change its sum)
+// (PUBLISHED: the rows were stored write-through by other workgroups of THIS launch — store_published —
+// and are read past this CU's L1 with sc1 loads, which stands in for an agent-scope acquire)
+__device__ __forceinline__ double load_published(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p),
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+template <int NT = kFoldThreads, bool PUBLISHED = false>
+__device__ __forceinline__ void fold_values_block(const double* partials, int nb, int nv, double* vals) {
+    constexpr int NW = NT / kWave;
     const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
     for (int k0 = wid; k0 < nv; k0 += NW * kFoldBatch) {
         double s[kFoldBatch];
@@ -122,7 +132,7 @@ __device__ __forceinline__ void fold_values_block(const double* __restrict__ par
 #pragma unroll
             for (int u = 0; u < kFoldBatch; ++u) {
                 const int k = k0 + u * NW;
-                if (k < nv) s[u] += partials[(int64_t)b * nv + k];
+                if (k < nv) s[u] += PUBLISHED ? load_published(partials + (int64_t)b * nv + k) : partials[(int64_t)b * nv + k];
             }
         }
 #pragma unroll

@@ -15,6 +15,7 @@
 // 100 us at 50 000 (one CU's bandwidth) against 15 us for the three launches at any size up to
 // 1M — the launches are ~5 us each and already the floor; not kept.
 #include <cstdlib>
+#include <cstring>
 
 #include "obe_common.h"
 #include "obe_models.h"
@@ -93,6 +94,9 @@ __device__ __forceinline__ bool sweep_prologue(const SweepCtl& c, double* red) {
 }
 
 // pass A, model fused
+// (round 4, measured and not kept: issuing the loads of 6 particles per thread together before their ~170
+// dependent FP64 instructions each — 23.2 vs 23.0 us per update at 1 M particles, 17.4 vs 15.7 at 262 144:
+// three waves per SIMD already hide the latency)
 template <class M>
 __global__ __launch_bounds__(kBlock) void update_model_kernel(
     obe_model m, SettingArg st, LikArgs la, const double* __restrict__ particles, int64_t ld,
@@ -170,17 +174,30 @@ __global__ __launch_bounds__(kBlock) void normalize_kernel(const double* __restr
 // are bit-identical to obe_moments() called on the updated weights; the weights themselves are
 // the ones normalize_kernel writes.  One launch less per cycle and no second read of the weights
 // (every cycle needs the moments: the sweep's shift, mean(), std(), the noise-parameter variance).
-template <int D>
+// FOLD (round 4): the launch also does what fold_update_moments_kernel did — the workgroup that arrives
+// last folds everybody's partials (written through, so no release fence has to write back the weights just
+// dirtied; obe_common.h: arrive_last) and delivers {sum t, sum w'^2} and the K3 block.  Same sums in the
+// same order as the separate fold: identical bits, one dependent launch (its ~7 us) less per update.
+struct UpdateFold {
+    unsigned* counter;          // arrival counter of this stream (zero between launches)
+    double* scalars;            // [0] sum t, [1] sum w'^2
+    double* mom_out;            // K3 block on the device
+    double* host_out;           // device view of the caller's page-locked h_out, or NULL
+};
+
+template <int D, bool FOLD>
 __global__ __launch_bounds__(kBlock) void normalize_moments_kernel(const double* __restrict__ partials_in,
                                                                    int n_partials, const double* __restrict__ x,
                                                                    int64_t ld, int64_t n, double* __restrict__ weights,
-                                                                   double* __restrict__ partials_w2,
-                                                                   double* __restrict__ partials_mom) {
+                                                                   double* partials_w2, double* partials_mom,
+                                                                   UpdateFold fold) {
     __shared__ double red[kBlock / kWave];
     const double total = block_sum_array(partials_in, n_partials, red);
-    double v[2 + 2 * D];
+    // FOLD: sum nan_to_num(w'^2) travels as one more column of the moment rows (one round of loads in the fold)
+    constexpr int NV = 2 + 2 * D + (FOLD ? 1 : 0);
+    double v[NV];
 #pragma unroll
-    for (int k = 0; k < 2 + 2 * D; ++k) v[k] = 0.0;
+    for (int k = 0; k < NV; ++k) v[k] = 0.0;
     double acc = 0.0;
     for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (int64_t)gridDim.x * kBlock) {
         double xi[D];
@@ -189,11 +206,35 @@ __global__ __launch_bounds__(kBlock) void normalize_moments_kernel(const double*
         const double w = nan_to_num(weights[p] / total);
         weights[p] = w;
         acc += nan_to_num(w * w);
-        accumulate_first_moments<D>(v, w, xi);
+        accumulate_first_moments<D>(reinterpret_cast<double(&)[2 + 2 * D]>(v), w, xi);
     }
-    const double s = block_sum(acc, red);
-    if (threadIdx.x == 0) partials_w2[blockIdx.x] = s;
-    store_block_partials<2 + 2 * D>(v, partials_mom);
+    if constexpr (!FOLD) {
+        const double s = block_sum(acc, red);
+        if (threadIdx.x == 0) partials_w2[blockIdx.x] = s;
+        store_block_partials<NV>(v, partials_mom);
+    } else {
+        v[NV - 1] = acc;
+        store_block_partials<NV, true>(v, partials_mom);
+        __shared__ int last;
+        if (!arrive_last<false>(fold.counter, &last)) return;
+        __shared__ double raw[kMaxMomentValues + 1];
+        fold_values_block<kBlock, true>(partials_mom, gridDim.x, NV, raw);
+        // delivery by ONE wave: K3 block to the device copy and to the host, one system-scope fence, then the
+        // word the host watches (wait_host_word) — [0] sum t, [1] sum w'^2, [2..) K3 block
+        if (threadIdx.x < kWave) {
+            derive_first_moments(raw, D, fold.mom_out, fold.host_out ? fold.host_out + 2 : nullptr);
+            const double b = raw[NV - 1];
+            if (threadIdx.x == 0) {
+                fold.scalars[0] = total;
+                fold.scalars[1] = b;
+                if (fold.host_out) fold.host_out[0] = total;
+            }
+            if (fold.host_out) {
+                host_results_before_flag();
+                if (threadIdx.x == 0) fold.host_out[1] = b;
+            }
+        }
+    }
 }
 
 // ... and its fold: {sum t, sum w'^2} + the K3 block (mean, m1, m2, std), to the device copies and,
@@ -438,7 +479,7 @@ struct UpdateWs {
     double* mom;        // block partials of the fused first moments (moments_dims > 0 only)
 };
 static int carve_update_ws(void* d_ws, int64_t ws_bytes, UpdateWs& w, int moments_dims = 0) {
-    const int64_t mom = moments_dims > 0 ? (int64_t)kMomGridCap * (2 + 2 * moments_dims) : 0;
+    const int64_t mom = moments_dims > 0 ? (int64_t)kMomGridCap * (3 + 2 * moments_dims) : 0;   // (+1: sum w'^2 rides along)
     const int64_t need = (2 * (int64_t)kMaxBlocks + 8 + mom) * sizeof(double);
     if (!d_ws || ws_bytes < need) return bad_arg("workspace too small");
     w.pa = static_cast<double*>(d_ws);
@@ -525,10 +566,21 @@ int obe_bayes_update_model_moments(const obe_model* m, const double* d_particles
     });
     if (rc) return rc;
     const int nm = moment_blocks(n_particles, d);
-#define OBE_UPD_MOM_CASE(DD)                                                                                       \
-    case DD:                                                                                                       \
-        normalize_moments_kernel<DD><<<nm, kBlock, 0, st>>>(w.pa, nb, d_particles, ld_p, n_particles, d_weights,  \
-                                                            w.pb, w.mom);                                          \
+    double* hv = static_cast<double*>(device_view_of_host(h_out));
+    if (hv) arm_host_word(h_out + 1);
+    // the fold rides in the normalisation launch (its last workgroup to arrive) unless there is no counter
+    // for this stream or OBE_UPDATE_FOLD=separate asks for the round-3 shape (A/B measurements)
+    static const bool separate = getenv("OBE_UPDATE_FOLD") && !strcmp(getenv("OBE_UPDATE_FOLD"), "separate");
+    unsigned* counter = separate ? nullptr : stream_control_words(st);
+    const UpdateFold fold{counter, w.scalars, d_moments, hv};
+#define OBE_UPD_MOM_CASE(DD)                                                                                           \
+    case DD:                                                                                                           \
+        if (counter)                                                                                                   \
+            normalize_moments_kernel<DD, true><<<nm, kBlock, 0, st>>>(w.pa, nb, d_particles, ld_p, n_particles,       \
+                                                                      d_weights, w.pb, w.mom, fold);                   \
+        else                                                                                                           \
+            normalize_moments_kernel<DD, false><<<nm, kBlock, 0, st>>>(w.pa, nb, d_particles, ld_p, n_particles,      \
+                                                                       d_weights, w.pb, w.mom, fold);                  \
         break;
     switch (d) {
         OBE_UPD_MOM_CASE(1) OBE_UPD_MOM_CASE(2) OBE_UPD_MOM_CASE(3) OBE_UPD_MOM_CASE(4) OBE_UPD_MOM_CASE(5)
@@ -538,10 +590,10 @@ int obe_bayes_update_model_moments(const obe_model* m, const double* d_particles
     }
 #undef OBE_UPD_MOM_CASE
     OBE_CHECK_LAUNCH("normalize_moments_kernel");
-    double* hv = static_cast<double*>(device_view_of_host(h_out));
-    if (hv) arm_host_word(h_out + 1);
-    fold_update_moments_kernel<<<1, kFoldThreads, 0, st>>>(w.pa, nb, w.pb, nm, w.mom, d, w.scalars, d_moments, hv);
-    OBE_CHECK_LAUNCH("fold_update_moments_kernel");
+    if (!counter) {
+        fold_update_moments_kernel<<<1, kFoldThreads, 0, st>>>(w.pa, nb, w.pb, nm, w.mom, d, w.scalars, d_moments, hv);
+        OBE_CHECK_LAUNCH("fold_update_moments_kernel");
+    }
     if (h_out) {
         if (hv) return wait_host_word(h_out + 1, st);
         {
