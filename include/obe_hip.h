@@ -258,6 +258,26 @@ int obe_resample_particles(const double* d_old, int64_t ld_old, int32_t n_dims, 
                            double* d_new, int64_t ld_new, double* d_weights,
                            void* d_ws, int64_t ws_bytes, void* stream);
 
+/* resample(), the device side up to the host's factorisation of the covariance, enqueued by ONE call
+ * (particlepdf.py:260-301; RNG order as there: N uniforms for rng.choice, then N x D normals): the caller's
+ * PCG64 stream continued on the device (h_pcg_state4 = {state hi, lo, increment hi, lo}; n_raw >= N + N D +
+ * 4096 raw values into d_raw), the weight CDF into d_cdf (skipped when cdf_is_fresh), the N uniforms, the
+ * search of the N draws (d_idx), the covariance of the PRE-resample cloud (have_first_moments: d_moments
+ * already holds mean / std of these weights) and the N x D ziggurat normals (d_normals; d_zig_ws of
+ * obe_ziggurat_workspace_bytes(n_raw - N) bytes).  Nothing is waited for.  All three host buffers must be
+ * page-locked: h_f64[0] = sum(w) for numpy's validation of p (1.0 when the CDF was fresh), h_f64[1..] =
+ * the K3 block incl. the covariance; h_flags[0] is armed here and stored last by the covariance kernel —
+ * obe_host_word_wait(h_flags) returns when the block is there; h_i64[0..1] = {raw values the normals
+ * consumed, normals found}, h_i64[1] armed and stored last — obe_host_word_wait(h_i64 + 1), then
+ * obe_ziggurat_check().  Same kernels, same numbers as the calls one by one. */
+int obe_resample_begin(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t n_particles,
+                       const double* d_weights, const uint64_t* h_pcg_state4, int32_t strict_cdf,
+                       int32_t cdf_is_fresh, int32_t have_first_moments, uint64_t* d_raw, int64_t n_raw,
+                       double* d_cdf, double* d_uniforms, int64_t* d_idx, const void* d_zig_tables,
+                       double* d_normals, void* d_zig_ws, int64_t zig_ws_bytes, double* d_moments,
+                       double* h_f64, uint64_t* h_flags, int64_t* h_i64, void* d_ws, int64_t ws_bytes,
+                       void* stream);
+
 /* ---- K6: OptBayesExptNoiseParameter extras ----
  * enforce_parameter_constraints (obe_noiseparam.py:57-79): zero the weight of every
  * particle whose row h_rows[k] <= 0 for any k, renormalise if anything changed.
@@ -265,6 +285,17 @@ int obe_resample_particles(const double* d_old, int64_t ld_old, int32_t n_dims, 
 int obe_mask_nonpositive(const double* d_particles, int64_t ld_p, int64_t n_particles,
                          const int32_t* h_rows, int32_t n_rows, double* d_weights,
                          int64_t* h_changed, void* d_ws, int64_t ws_bytes, void* stream);
+
+/* The same mask AND the first moments of the constrained cloud (what obe_moments(want_cov = 0) would
+ * compute next: every cycle needs them for the sweep's shift and the noise-parameter variance), bit for
+ * bit, in two launches without a host round trip in between (obe_noiseparam.py:57-79 + particlepdf.py:
+ * 173-214).  Does not wait: with page-locked h_changed / h_moments (either may be NULL) the count is armed
+ * here and stored last by the second kernel — obe_host_word_wait(h_changed) — and h_moments receives the
+ * K3 block's 2 + 4 n_dims first-moment values.  Pageable host buffers: the two calls above, synchronously. */
+int obe_mask_nonpositive_moments(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t n_particles,
+                                 const int32_t* h_rows, int32_t n_rows, double* d_weights, double* d_moments,
+                                 double* h_moments, int64_t* h_changed, void* d_ws, int64_t ws_bytes,
+                                 void* stream);
 
 /* yvar_noise_model (obe_noiseparam.py:122-136): d_out[c] = weighted mean of
  * (particle row h_rows[c])^2, read from the K3 block: m2[row] / sum w.  No sync. */

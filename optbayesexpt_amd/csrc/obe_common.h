@@ -80,6 +80,12 @@ __device__ __forceinline__ void store_published(double* p, double v) {
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ... and read back past this CU's L1 (sc1 load): stands in for an agent-scope acquire
+__device__ __forceinline__ double load_published_f64(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p),
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
 // Call after every thread of the workgroup has issued its store_published() calls.  Returns true in
 // EVERY thread of the workgroup that arrived last: by then all workgroups' published values are in
 // memory, and after the acquire below plain loads see them.  The counter wraps to zero with the last

@@ -116,34 +116,74 @@ constexpr int kFoldBatch = 4;
 // (NT threads in the folding workgroup: which wave folds a value does not change its sum)
 // (PUBLISHED: the rows were stored write-through by other workgroups of THIS launch — store_published —
 // and are read past this CU's L1 with sc1 loads, which stands in for an agent-scope acquire)
-__device__ __forceinline__ double load_published(const double* p) {
-    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p),
-                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-template <int NT = kFoldThreads, bool PUBLISHED = false>
+__device__ __forceinline__ double load_published(const double* p) { return load_published_f64(p); }
+// (BATCH values per wave and trip: a 4-wave workgroup that folds inside the producing launch takes 8 at a
+// time to keep as many loads in flight as the 16-wave fold kernels do with 4)
+template <int NT = kFoldThreads, bool PUBLISHED = false, int BATCH = kFoldBatch>
 __device__ __forceinline__ void fold_values_block(const double* partials, int nb, int nv, double* vals) {
     constexpr int NW = NT / kWave;
     const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
-    for (int k0 = wid; k0 < nv; k0 += NW * kFoldBatch) {
-        double s[kFoldBatch];
+    for (int k0 = wid; k0 < nv; k0 += NW * BATCH) {
+        double s[BATCH];
 #pragma unroll
-        for (int u = 0; u < kFoldBatch; ++u) s[u] = 0.0;
+        for (int u = 0; u < BATCH; ++u) s[u] = 0.0;
         for (int b = lane; b < nb; b += kWave) {
 #pragma unroll
-            for (int u = 0; u < kFoldBatch; ++u) {
+            for (int u = 0; u < BATCH; ++u) {
                 const int k = k0 + u * NW;
                 if (k < nv) s[u] += PUBLISHED ? load_published(partials + (int64_t)b * nv + k) : partials[(int64_t)b * nv + k];
             }
         }
 #pragma unroll
-        for (int u = 0; u < kFoldBatch; ++u) s[u] = wave_sum(s[u]);
+        for (int u = 0; u < BATCH; ++u) s[u] = wave_sum(s[u]);
 #pragma unroll
-        for (int u = 0; u < kFoldBatch; ++u) {
+        for (int u = 0; u < BATCH; ++u) {
             const int k = k0 + u * NW;
             if (lane == 0 && k < nv) vals[k] = s[u];
         }
     }
     __syncthreads();
+}
+
+// Where a folding workgroup delivers: the K3 block on the device, the device view of the caller's
+// page-locked copy (or NULL) and, optionally, one more page-locked word that is stored LAST, behind a
+// system-scope fence (the host watches it instead of synchronising the stream: obe_common.h).
+struct MomentsOut {
+    double* out;
+    double* host;
+    uint64_t* host_flag;
+    unsigned* counter;          // arrival counter of the stream (the fold rides in the producing launch), or NULL
+};
+
+// every storing wave has drained its stores to the host, then one thread raises the flag
+__device__ __forceinline__ void raise_host_flag(uint64_t* host_flag) {
+    if (!host_flag) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        host_results_before_flag();
+        *host_flag = 1;
+    }
+}
+
+// cov = S * (1 / (W - W2/W))  (np.cov scales by the reciprocal); raw = the folded upper triangle
+__device__ __forceinline__ void derive_covariance(const double* raw, int d, double* __restrict__ out,
+                                                  double* __restrict__ host) {
+    const double fact = out[0] - out[1] / out[0];
+    const double scale = 1.0 / fact;
+    double* cov = out + 2 + 4 * d;
+    for (int e = threadIdx.x; e < d * d; e += blockDim.x) {
+        int i = e / d, j = e % d;
+        if (i > j) {
+            const int t = i;
+            i = j;
+            j = t;
+        }
+        const int k = i * d - i * (i - 1) / 2 + (j - i);     // index of (i, j), i <= j, in the packed upper triangle
+        const double c = raw[k] * scale;
+        cov[e] = c;
+        if (host) host[2 + 4 * d + e] = c;
+    }
 }
 
 constexpr int kMaxMomentValues = OBE_MAX_DIMS * (OBE_MAX_DIMS + 1) / 2;     // >= 2 + 2 D
@@ -178,6 +218,12 @@ __device__ __forceinline__ void derive_first_moments(const double* raw, int d, d
         }
     }
 }
+
+// obe_moments() with an optional page-locked word that the call's last kernel raises (set to 1) behind its
+// host stores; *host_written tells whether h_out was page-locked, i.e. written by the kernels themselves
+int moments_call(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t n_particles, const double* d_weights,
+                 int32_t want_cov, double* d_out, double* h_out, uint64_t* h_flag, void* d_ws, int64_t ws_bytes,
+                 hipStream_t st, bool* host_written);
 
 // Grid of the moment passes (and of the update's normalisation pass that shares them): one workgroup per CU
 // up to 2 M particles; beyond that a wave per SIMD with only D + 1 loads in flight no longer fills HBM

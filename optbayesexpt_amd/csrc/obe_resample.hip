@@ -12,6 +12,7 @@
 #include <cstdlib>
 
 #include "obe_common.h"
+#include "obe_moments.h"
 
 namespace obe {
 
@@ -97,9 +98,10 @@ __global__ __launch_bounds__(kBlock) void scan_block_sums(const double* __restri
 // Exclusive scan of the block sums (nb = N/2048: 512 at 1M particles) by one workgroup,
 // written in place; scalars[0] = total = offset[last] + sum[last], scalars[1] = the value the host
 // validates (total_for_validation).
+// (host_total: the device view of the caller's page-locked h_total, or NULL)
 __global__ __launch_bounds__(kBlock) void scan_offsets(double* __restrict__ block_sums, int64_t nb,
                                                        const double* __restrict__ block_mins,
-                                                       double* __restrict__ scalars) {
+                                                       double* __restrict__ scalars, double* __restrict__ host_total) {
     __shared__ double lds[kBlock + 1];
     __shared__ double mins[kBlock];
     double m = 0.0;
@@ -111,6 +113,7 @@ __global__ __launch_bounds__(kBlock) void scan_offsets(double* __restrict__ bloc
         for (int i = 1; i < kBlock; ++i) m = fmin(m, mins[i]);
         scalars[0] = total;
         scalars[1] = total_for_validation(total, m);
+        if (host_total) *host_total = scalars[1];
     }
 }
 
@@ -453,18 +456,22 @@ static int scan_common(const char* who, const double* d_x, int64_t n, int32_t st
     double* block_sums = scalars + 8;
     double* block_mins = normalize ? block_sums + nb : nullptr;       // a CDF of weights: validated like numpy's p
     hipStream_t st = as_stream(stream);
+    double* hv = nullptr;
     if (strict_order) {
         cdf_strict_kernel<<<1, kWave, 0, st>>>(d_x, n, d_out, scalars, normalize);
         OBE_CHECK_LAUNCH("cdf_strict_kernel");
     } else {
         scan_block_sums<<<(unsigned)nb, kBlock, 0, st>>>(d_x, n, block_sums, block_mins);
         OBE_CHECK_LAUNCH("scan_block_sums");
-        scan_offsets<<<1, kBlock, 0, st>>>(block_sums, nb, block_mins, scalars);
+        // a deferred, page-locked h_total is stored by the kernel itself (no copy node); the caller reads it
+        // after synchronising with anything later on the stream
+        hv = defer_host_sync() ? static_cast<double*>(device_view_of_host(h_total)) : nullptr;
+        scan_offsets<<<1, kBlock, 0, st>>>(block_sums, nb, block_mins, scalars, hv);
         OBE_CHECK_LAUNCH("scan_offsets");
         scan_write_cdf<<<(unsigned)nb, kBlock, 0, st>>>(d_x, n, block_sums, scalars, d_out, normalize);
         OBE_CHECK_LAUNCH("scan_write_cdf");
     }
-    if (h_total) {
+    if (h_total && !hv) {
         OBE_HIP_TRY(hipMemcpyAsync(h_total, scalars + 1, sizeof(double), hipMemcpyDeviceToHost, st));
         if (!defer_host_sync()) OBE_HIP_TRY(hipStreamSynchronize(st));
     }
@@ -621,6 +628,56 @@ int obe_resample_particles(const double* d_old, int64_t ld_old, int32_t n_dims, 
     }
 #undef OBE_RS_CASE
     return bad_arg("obe_resample_particles: n_dims must be 1..16");
+}
+
+// The device side of ParticlePDF.resample() up to the point where the host must factorise the covariance
+// (particlepdf.py:260-301), enqueued by ONE call: the caller's PCG64 stream continued on the device (raw
+// values, N uniforms), the weight CDF (unless the caller's is fresh), the N-draw search, the covariance of
+// the pre-resample cloud and the N x D ziggurat normals.  Nothing is waited for: h_f64[0] receives sum(w)
+// for numpy's validation of p (1.0 is stored when the CDF was fresh), h_f64[1..] the K3 block incl. the
+// covariance, h_flags[0] is raised (set to 1) when that block is complete, h_i64[0..1] = {raw values the
+// normals consumed, normals found} with h_i64[1] stored last (armed here with a pattern no count has) —
+// all three page-locked; the caller watches h_flags[0], factorises, calls obe_resample_particles(), then
+// watches h_i64[1] for the generator bookkeeping (obe_host_word_wait).  Python issued these ~12 launches one
+// library call at a time (5-15 us of interpreter between two launches: the GPU idled for most of a
+// resample cycle at 262 144 particles).
+int obe_resample_begin(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t n_particles,
+                       const double* d_weights, const uint64_t* h_pcg_state4, int32_t strict_cdf,
+                       int32_t cdf_is_fresh, int32_t have_first_moments, uint64_t* d_raw, int64_t n_raw,
+                       double* d_cdf, double* d_uniforms, int64_t* d_idx, const void* d_zig_tables,
+                       double* d_normals, void* d_zig_ws, int64_t zig_ws_bytes, double* d_moments, double* h_f64,
+                       uint64_t* h_flags, int64_t* h_i64, void* d_ws, int64_t ws_bytes, void* stream) {
+    if (!d_particles || !d_weights || !h_pcg_state4 || !d_raw || !d_cdf || !d_uniforms || !d_idx || !d_zig_tables ||
+        !d_normals || !d_zig_ws || !d_moments || !h_f64 || !h_flags || !h_i64 || n_particles <= 0)
+        return bad_arg("obe_resample_begin: bad pointer/size");
+    if (n_dims < 1 || n_dims > OBE_MAX_DIMS) return bad_arg("obe_resample_begin: n_dims must be 1..16");
+    const int64_t n = n_particles, n_normal = n * n_dims;
+    if (n_raw < n + n_normal + 4096) return bad_arg("obe_resample_begin: raw buffer shorter than the draws");
+    if (!device_view_of_host(h_f64) || !device_view_of_host(h_flags) || !device_view_of_host(h_i64))
+        return bad_arg("obe_resample_begin: the host result buffers must be page-locked");
+    hipStream_t st = as_stream(stream);
+    const int prev = obe_defer_host_sync(1);
+    int rc = 0;
+    do {
+        if ((rc = obe_pcg64_raw(h_pcg_state4, n_raw, d_raw, stream))) break;
+        if (!cdf_is_fresh) {
+            if ((rc = obe_weight_cdf(d_weights, n, strict_cdf, d_cdf, h_f64, d_ws, ws_bytes, stream))) break;
+        } else {
+            h_f64[0] = 1.0;
+        }
+        if ((rc = obe_pcg64_uniform(d_raw, n, d_uniforms, stream))) break;
+        if ((rc = obe_cdf_search(d_cdf, n, d_uniforms, n, d_idx, d_ws, ws_bytes, stream))) break;
+        arm_host_word(h_flags);
+        bool host_written = false;
+        if ((rc = moments_call(d_particles, ld_p, n_dims, n, d_weights, have_first_moments ? 2 : 1, d_moments,
+                               h_f64 + 1, h_flags, d_ws, ws_bytes, st, &host_written)))
+            break;
+        if ((rc = obe_ziggurat_normal(d_raw + n, n_raw - n, 0, d_zig_tables, n_normal, d_normals, h_i64, d_zig_ws,
+                                      zig_ws_bytes, stream)))
+            break;
+    } while (false);
+    obe_defer_host_sync(prev);
+    return rc;
 }
 
 }  // extern "C"

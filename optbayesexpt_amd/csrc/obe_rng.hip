@@ -117,7 +117,8 @@ __device__ __forceinline__ double next_double(uint64_t r) { return (double)(r >>
 // started at raw[i].  length = raw values consumed (0 = ran off the buffer / too long).
 __global__ __launch_bounds__(kBlock) void zig_classify_kernel(const uint64_t* __restrict__ raw, int64_t n_raw,
                                                               ZigTables t, double* __restrict__ val,
-                                                              uint8_t* __restrict__ len) {
+                                                              uint8_t* __restrict__ len, int64_t* __restrict__ result) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) result[0] = result[1] = 0;    // (what a memset node did: one launch less)
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n_raw; i += (int64_t)gridDim.x * kBlock) {
         int64_t pos = i;
         double x = 0.0;
@@ -266,12 +267,15 @@ __global__ __launch_bounds__(kBlock) void flag_scan_offsets(uint32_t* __restrict
 // positions for the scan, but reading val[] and writing out[] that way makes every load / store
 // instruction of a wave touch 64 different cache lines; instead the tile is read with lane-contiguous
 // loads, compacted inside LDS (98.8 % of the positions are starts) and written out lane-contiguously.
+// (host: the device view of the caller's page-locked {consumed, found}, with `counter` the stream's arrival
+// counter — then the workgroup that finishes last stores both there, `found` behind a system-scope fence:
+// the host watches that word instead of waiting for a copy and a stream synchronisation)
 __global__ __launch_bounds__(kBlock) void zig_compact_kernel(const uint8_t* __restrict__ flag,
                                                              const uint32_t* __restrict__ block_off,
                                                              const double* __restrict__ val,
                                                              const uint8_t* __restrict__ len, int64_t n_raw,
                                                              int64_t first, int64_t n, double* __restrict__ out,
-                                                             int64_t* __restrict__ result) {
+                                                             int64_t* result, int64_t* host, unsigned* counter) {
     __shared__ uint32_t lds[kBlock / kWave];
     __shared__ double sval[kFlagTile];
     __shared__ double sout[kFlagTile];
@@ -295,7 +299,7 @@ __global__ __launch_bounds__(kBlock) void zig_compact_kernel(const uint8_t* __re
             const int64_t rank = (int64_t)off + v[k] - 1;
             if (rank == n - 1) {
                 const int64_t i = i0 + k;
-                result[0] = i + (int64_t)len[i] - first;
+                __hip_atomic_store(result, i + (int64_t)len[i] - first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -304,7 +308,17 @@ __global__ __launch_bounds__(kBlock) void zig_compact_kernel(const uint8_t* __re
         const int64_t rank = (int64_t)off + j;
         if (rank < n) out[rank] = sout[j];
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) result[1] = (int64_t)off + total;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+        __hip_atomic_store(result + 1, (int64_t)off + total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (host) {
+        __shared__ int last;
+        if (!arrive_last<false>(counter, &last)) return;
+        if (threadIdx.x == 0) {
+            host[0] = __hip_atomic_load(result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            host_results_before_flag();
+            host[1] = __hip_atomic_load(result + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 }  // namespace obe
@@ -358,18 +372,24 @@ int obe_ziggurat_normal(const uint64_t* d_raw, int64_t n_raw, int64_t offset, co
     t.ki = static_cast<const uint64_t*>(d_tables);
     t.wi = reinterpret_cast<const double*>(t.ki + 256);
     t.fi = t.wi + 256;
-    OBE_HIP_TRY(hipMemsetAsync(base, 0, 64, st));
-    zig_classify_kernel<<<stream_blocks(n_raw, kBlock), kBlock, 0, st>>>(d_raw, n_raw, t, val, len);
+    zig_classify_kernel<<<stream_blocks(n_raw, kBlock), kBlock, 0, st>>>(d_raw, n_raw, t, val, len, result);
     OBE_CHECK_LAUNCH("zig_classify_kernel");
     static_assert(kStartTile == kFlagTile && kStartItems == kFlagItems, "the start flags and their scan share one tiling");
     zig_starts_kernel<<<(unsigned)nb, kBlock, 0, st>>>(len, n_raw, offset, flag, sums);
     OBE_CHECK_LAUNCH("zig_starts_kernel");
     flag_scan_offsets<<<1, kBlock, 0, st>>>(sums, nb);
     OBE_CHECK_LAUNCH("flag_scan_offsets");
-    zig_compact_kernel<<<(unsigned)nb, kBlock, 0, st>>>(flag, sums, val, len, n_raw, offset, n, d_out, result);
+    // deferred + page-locked h_consumed: the kernel delivers {consumed, found} itself and the caller watches
+    // h_consumed[1] (armed here: no count of normals has that bit pattern)
+    int64_t* hv = defer_host_sync() ? static_cast<int64_t*>(device_view_of_host(h_consumed)) : nullptr;
+    unsigned* counter = hv ? stream_control_words(st) : nullptr;
+    if (hv) arm_host_word(h_consumed + 1);        // (also when the copy node below delivers: it overwrites the word)
+    if (!counter) hv = nullptr;
+    zig_compact_kernel<<<(unsigned)nb, kBlock, 0, st>>>(flag, sums, val, len, n_raw, offset, n, d_out, result, hv,
+                                                        counter);
     OBE_CHECK_LAUNCH("zig_compact_kernel");
     if (defer_host_sync()) {       // {consumed, found} -> h_consumed[0..1]; the caller checks them after its sync
-        OBE_HIP_TRY(hipMemcpyAsync(h_consumed, result, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        if (!hv) OBE_HIP_TRY(hipMemcpyAsync(h_consumed, result, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
         return 0;
     }
     int64_t host[2];

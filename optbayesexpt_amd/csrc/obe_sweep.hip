@@ -376,27 +376,87 @@ __device__ __forceinline__ void block_argmax(Best b, double* bv, int64_t* bi) {
     }
 }
 
-// folds the chunk partials -> yvar, utility; per-block first-max.
-// A workgroup owns 64 consecutive settings; its 4 wavefronts each sum a quarter of the
-// chunks (coalesced 512-byte rows, independent loads in flight), the quarters are combined
-// in a fixed order through LDS.  (One thread per setting walking all chunks serially was
-// latency-bound: 100+ us at 512 chunks.)
-constexpr int kFinGroups = kBlock / kWave;          // chunk groups = wavefronts
+// folds the chunk partials -> yvar, utility; first maximum and worst kappa over all settings.
+// A workgroup owns 64 consecutive settings; its 16 wavefronts each sum a sixteenth of the chunks
+// (coalesced 512-byte rows, up to 8 independent loads in flight per lane), the groups are combined in a
+// fixed order through LDS.  (One thread per setting walking all chunks serially was latency-bound: 100+ us
+// at 512 chunks; 4 wavefronts with 4 loads in flight still took 10.8 us for the 12.6 MB of a 4096 x 262 144
+// sweep — 48 dependent-latency trips per wave — as long as for the 42 MB of 65 536 x 1 048 576.)
+// Round 4: the launch also does what argmax_fold did — every workgroup publishes its {first max, index,
+// kappa} write-through and the one that arrives last folds them and delivers the result record (host
+// words included): one dependent launch less between two sweeps.
+constexpr int kFinGroups = 16;                      // chunk groups = wavefronts of a finalize workgroup
+constexpr int kFinThreads = kFinGroups * kWave;
 
 // worst cancellation factor so far; a NaN (some variance is NaN) is sticky
 __device__ __forceinline__ double kappa_worst(double a, double b) {
     return a != a ? a : (b != b ? b : (a > b ? a : b));
 }
 
-__global__ __launch_bounds__(kBlock) void sweep_finalize(const double* __restrict__ part1,
-                                                         const double* __restrict__ part2, int nchunks, int nc,
-                                                         int64_t ns, const double* __restrict__ moments,
-                                                         int full_mode, UtilArgs ua,
-                                                         const double* __restrict__ cs,
-                                                         double* __restrict__ yvar,
-                                                         double* __restrict__ utility, double* __restrict__ bv,
-                                                         int64_t* __restrict__ bi, double* __restrict__ bk) {
-    __shared__ double red[kBlock];
+// Where the result goes on the host, as device-visible addresses (page-locked host memory), or all
+// NULL: then read_best() copies it.
+struct HostResult {
+    double* best;
+    int64_t* idx;
+    double* kappa;
+};
+// (the word the host watches is stored last, behind a system-scope fence: the index if it is asked for,
+// else kappa, else the value — host_flag_of() names the same one)
+__device__ __forceinline__ void deliver(const HostResult& h, double v, int64_t i, double k) {
+    if (h.idx) {
+        if (h.best) *h.best = v;
+        if (h.kappa) *h.kappa = k;
+        host_results_before_flag();
+        *h.idx = i;
+    } else if (h.kappa) {
+        if (h.best) *h.best = v;
+        host_results_before_flag();
+        *h.kappa = k;
+    } else if (h.best) {
+        *h.best = v;
+    }
+}
+
+// first maximum (np.argmax order) and worst kappa over a wavefront; valid in lane 0
+__device__ __forceinline__ void wave_best(Best& b, double& kappa) {
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        const Best y{__shfl_down(b.v, o, kWave), __shfl_down(b.i, o, kWave)};
+        if (better(y, b)) b = y;
+        kappa = kappa_worst(kappa, __shfl_down(kappa, o, kWave));
+    }
+}
+
+// the result record of a sweep / argmax call: out_v[0] best value, [1] kappa, out_i[0] index, and the same as
+// one contiguous 32-byte record {value, index bits, kappa, 0} at OBE_WS_RESULT_OFFSET (out_v + 2), so that a
+// sharded caller can all-gather it straight from device memory without a host round trip
+__device__ __forceinline__ void write_result_record(double* out_v, int64_t* out_i, const Best& b, double k,
+                                                    const HostResult& host) {
+    out_v[0] = b.v;
+    out_i[0] = b.i;
+    out_v[1] = k;
+    out_v[2] = b.v;
+    reinterpret_cast<int64_t*>(out_v)[3] = b.i;
+    out_v[4] = k;
+    out_v[5] = 0.0;
+    deliver(host, b.v, b.i, k);
+}
+
+struct FinalizeFold {
+    unsigned* counter;        // arrival counter of the stream, or NULL: argmax_fold follows in its own launch
+    double* out_v;
+    int64_t* out_i;
+    HostResult host;
+};
+
+__global__ __launch_bounds__(kFinThreads) void sweep_finalize(const double* __restrict__ part1,
+                                                              const double* __restrict__ part2, int nchunks, int nc,
+                                                              int64_t ns, const double* __restrict__ moments,
+                                                              int full_mode, UtilArgs ua,
+                                                              const double* __restrict__ cs,
+                                                              double* __restrict__ yvar,
+                                                              double* __restrict__ utility, double* bv,
+                                                              int64_t* bi, double* bk, FinalizeFold ff) {
     __shared__ double acc1[OBE_MAX_CHANNELS][kFinGroups][kFinSettings];
     __shared__ double acc2[OBE_MAX_CHANNELS][kFinGroups][kFinSettings];
     const double W = full_mode ? moments[0] : 1.0;
@@ -405,8 +465,22 @@ __global__ __launch_bounds__(kBlock) void sweep_finalize(const double* __restric
     for (int c = 0; c < nc; ++c) {
         double a1 = 0.0, a2 = 0.0;
         if (s < ns) {
-#pragma unroll 4
-            for (int k = grp; k < nchunks; k += kFinGroups) {
+            int k = grp;
+            for (; k + 3 * kFinGroups < nchunks; k += 4 * kFinGroups) {        // 8 loads in flight
+                double t1[4], t2[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t o = ((int64_t)(k + u * kFinGroups) * nc + c) * ns + s;
+                    t1[u] = part1[o];
+                    t2[u] = part2[o];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    a1 += t1[u];
+                    a2 += t2[u];
+                }
+            }
+            for (; k < nchunks; k += kFinGroups) {
                 const int64_t o = ((int64_t)k * nc + c) * ns + s;
                 a1 += part1[o];
                 a2 += part2[o];
@@ -416,43 +490,77 @@ __global__ __launch_bounds__(kBlock) void sweep_finalize(const double* __restric
         acc2[c][grp][lane] = a2;
     }
     __syncthreads();
-    Best best{-INFINITY, INT64_MAX};
-    double kappa = 0.0;     // worst (mean of y')^2 / var: the cancellation an UNSHIFTED sweep would suffer
-    if (grp == 0 && s < ns) {
-        double var[OBE_MAX_CHANNELS];
-        for (int c = 0; c < nc; ++c) {
-            double a1 = 0.0, a2 = 0.0;
+    if (grp == 0) {
+        Best best{-INFINITY, INT64_MAX};
+        double kappa = 0.0;     // worst (mean of y')^2 / var: the cancellation an UNSHIFTED sweep would suffer
+        if (s < ns) {
+            double var[OBE_MAX_CHANNELS];
+            for (int c = 0; c < nc; ++c) {
+                double a1 = 0.0, a2 = 0.0;
 #pragma unroll
-            for (int g = 0; g < kFinGroups; ++g) {
-                a1 += acc1[c][g][lane];
-                a2 += acc2[c][g][lane];
+                for (int g = 0; g < kFinGroups; ++g) {
+                    a1 += acc1[c][g][lane];
+                    a2 += acc2[c][g][lane];
+                }
+                // (Measured alternative: chunk partials combined with TwoSum and S1*(S1/W) formed exactly
+                // with FMAs, plus per-tile flushing of the running sums, lowers the error of the
+                // unshifted variance from ~1e-15*kappa to ~2e-16*kappa — but the exact product then
+                // exposes the rounding of S2 itself, e.g. a non-zero variance for a single draw where
+                // the plain formula cancels to the reference's exact 0.  Not kept.)
+                const double mu = a1 / W;
+                double v = (a2 - a1 * mu) / W;
+                v = v > 0.0 ? v : (v != v ? v : 0.0);          // rounding may leave -0 / tiny negatives; NaN stays NaN (np.var)
+                var[c] = v;
+                yvar[(int64_t)c * ns + s] = v;
+                const double m = cs[(int64_t)c * ns + s] + mu;
+                const double k = v != v ? v : (v > 0.0 ? (m * m) / v : (m == 0.0 ? 0.0 : INFINITY));
+                kappa = kappa_worst(kappa, k);                 // a NaN variance is reported as kappa = NaN
             }
-            // (Measured alternative: chunk partials combined with TwoSum and S1*(S1/W) formed exactly
-            // with FMAs, plus per-tile flushing of the running sums, lowers the error of the
-            // unshifted variance from ~1e-15*kappa to ~2e-16*kappa — but the exact product then
-            // exposes the rounding of S2 itself, e.g. a non-zero variance for a single draw where
-            // the plain formula cancels to the reference's exact 0.  Not kept.)
-            const double mu = a1 / W;
-            double v = (a2 - a1 * mu) / W;
-            v = v > 0.0 ? v : (v != v ? v : 0.0);          // rounding may leave -0 / tiny negatives; NaN stays NaN (np.var)
-            var[c] = v;
-            yvar[(int64_t)c * ns + s] = v;
-            const double m = cs[(int64_t)c * ns + s] + mu;
-            const double k = v != v ? v : (v > 0.0 ? (m * m) / v : (m == 0.0 ? 0.0 : INFINITY));
-            kappa = kappa_worst(kappa, k);                 // a NaN variance is reported as kappa = NaN
+            const double u = utility_of(var, nc, s, ua);
+            utility[s] = u;
+            best = Best{u, s};
         }
-        const double u = utility_of(var, nc, s, ua);
-        utility[s] = u;
-        best = Best{u, s};
+        wave_best(best, kappa);
+        if (lane == 0) {
+            if (ff.counter) {
+                store_published(bv + blockIdx.x, best.v);
+                store_published(reinterpret_cast<double*>(bi) + blockIdx.x, __longlong_as_double(best.i));
+                store_published(bk + blockIdx.x, kappa);
+            } else {
+                bv[blockIdx.x] = best.v;
+                bi[blockIdx.x] = best.i;
+                bk[blockIdx.x] = kappa;
+            }
+        }
     }
-    block_argmax(best, bv, bi);
-    red[threadIdx.x] = kappa;
+    if (!ff.counter) return;
+    __shared__ int last;
+    if (!arrive_last<false>(ff.counter, &last)) return;
+    // the last workgroup to arrive: first maximum and worst kappa over every workgroup's entry
+    Best best{-INFINITY, INT64_MAX};
+    double kmax = 0.0;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += kFinThreads) {
+        const Best cand{load_published_f64(bv + b), __double_as_longlong(load_published_f64(reinterpret_cast<double*>(bi) + b))};
+        if (better(cand, best)) best = cand;
+        kmax = kappa_worst(kmax, load_published_f64(bk + b));
+    }
+    wave_best(best, kmax);
+    __shared__ double wv[kFinGroups], wk[kFinGroups];
+    __shared__ int64_t wi[kFinGroups];
+    if (lane == 0) {
+        wv[grp] = best.v;
+        wi[grp] = best.i;
+        wk[grp] = kmax;
+    }
     __syncthreads();
-    for (int o = kBlock / 2; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) red[threadIdx.x] = kappa_worst(red[threadIdx.x], red[threadIdx.x + o]);
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int g = 1; g < kFinGroups; ++g) {
+            const Best y{wv[g], wi[g]};
+            if (better(y, best)) best = y;
+            kmax = kappa_worst(kmax, wk[g]);
+        }
+        write_result_record(ff.out_v, ff.out_i, best, kmax, ff.host);
     }
-    if (threadIdx.x == 0) bk[blockIdx.x] = red[0];
 }
 
 __global__ __launch_bounds__(kBlock) void utility_kernel(const double* __restrict__ yvar, int nc, int64_t ns,
@@ -480,30 +588,6 @@ __global__ __launch_bounds__(kBlock) void argmax_kernel(const double* __restrict
     block_argmax(best, bv, bi);
 }
 
-// Where the result goes on the host, as device-visible addresses (page-locked host memory), or all
-// NULL: then read_best() copies it.
-struct HostResult {
-    double* best;
-    int64_t* idx;
-    double* kappa;
-};
-// (the word the host watches is stored last, behind a system-scope fence: the index if it is asked for,
-// else kappa, else the value — host_flag_of() names the same one)
-__device__ __forceinline__ void deliver(const HostResult& h, double v, int64_t i, double k) {
-    if (h.idx) {
-        if (h.best) *h.best = v;
-        if (h.kappa) *h.kappa = k;
-        host_results_before_flag();
-        *h.idx = i;
-    } else if (h.kappa) {
-        if (h.best) *h.best = v;
-        host_results_before_flag();
-        *h.kappa = k;
-    } else if (h.best) {
-        *h.best = v;
-    }
-}
-
 // one block: first-max over the block partials -> scalars {value, index (as int64 bits)}
 __global__ __launch_bounds__(kBlock) void argmax_fold(const double* __restrict__ bv, const int64_t* __restrict__ bi,
                                                       int nb, const double* __restrict__ bk,
@@ -525,18 +609,7 @@ __global__ __launch_bounds__(kBlock) void argmax_fold(const double* __restrict__
         if ((int)threadIdx.x < o) kred[threadIdx.x] = kappa_worst(kred[threadIdx.x], kred[threadIdx.x + o]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        const double k = kred[0];
-        out_v[1] = k;
-        // the same result as one contiguous 32-byte record {value, index bits, kappa, 0} at
-        // OBE_WS_RESULT_OFFSET, so that a sharded caller can all-gather it straight from
-        // device memory without a host round trip
-        out_v[2] = out_v[0];
-        reinterpret_cast<int64_t*>(out_v)[3] = out_i[0];
-        out_v[4] = k;
-        out_v[5] = 0.0;
-        deliver(host, out_v[0], out_i[0], k);
-    }
+    if (threadIdx.x == 0) write_result_record(out_v, out_i, Best{out_v[0], out_i[0]}, kred[0], host);
 }
 
 // Reference-semantics sweeps are tiny (201 settings x 30 draws in the demos): one workgroup
@@ -879,11 +952,15 @@ int obe_sweep_utility(const obe_model* m, const double* d_settings, int64_t ld_s
     if (rc) return rc;
     const int nb = static_cast<int>((n_settings + kFinSettings - 1) / kFinSettings);
     if (nb > kFinMaxBlocks) return bad_arg("obe_sweep_utility: more than 4 194 304 settings per call");
-    sweep_finalize<<<nb, kBlock, 0, st>>>(w.part1, w.part2, plan.nchunks, mm.n_channels, n_settings, d_moments,
-                                          d_draw_idx == nullptr, ua, w.cs, d_yvar, d_utility, w.bv, w.bi, w.bk);
+    static const bool separate = getenv("OBE_SWEEP_FOLD") && !strcmp(getenv("OBE_SWEEP_FOLD"), "separate");   // A/B aid
+    const FinalizeFold ff{separate ? nullptr : stream_control_words(st), w.out_v, w.out_i, hr};
+    sweep_finalize<<<nb, kFinThreads, 0, st>>>(w.part1, w.part2, plan.nchunks, mm.n_channels, n_settings, d_moments,
+                                               d_draw_idx == nullptr, ua, w.cs, d_yvar, d_utility, w.bv, w.bi, w.bk, ff);
     OBE_CHECK_LAUNCH("sweep_finalize");
-    argmax_fold<<<1, kBlock, 0, st>>>(w.bv, w.bi, nb, w.bk, w.out_v, w.out_i, hr);
-    OBE_CHECK_LAUNCH("argmax_fold");
+    if (!ff.counter) {
+        argmax_fold<<<1, kBlock, 0, st>>>(w.bv, w.bi, nb, w.bk, w.out_v, w.out_i, hr);
+        OBE_CHECK_LAUNCH("argmax_fold");
+    }
     rc = read_best(w, h_best, h_best_idx, st, h_kappa, hr);
     if (timed && !rc) {                       // the stream is drained: both events have completed
         float ms = 0.f;

@@ -424,6 +424,57 @@ __global__ __launch_bounds__(kBlock) void mask_renorm_kernel(const double* __res
         weights[p] = weights[p] / total;
 }
 
+// The constraint mask's second half and the first moments of the constrained cloud in ONE pass (round 4):
+// renormalise by the folded total if anything was zeroed — mask_renorm_kernel's arithmetic — and accumulate
+// sum w, sum w^2, sum w x, sum w x^2 with moments_pass1's grid and order, folded by the last workgroup to
+// arrive: what obe_mask_nonpositive() + obe_moments() leave behind, bit for bit, in two launches instead of
+// five and without a host round trip in between (the count arrives with the moments).
+struct MaskFold {
+    unsigned* counter;
+    double* mom_out;          // K3 block on the device
+    double* host_mom;         // device view of the caller's page-locked copy, or NULL
+    int64_t* host_changed;    // device view of the caller's page-locked count (stored last), or NULL
+};
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void mask_renorm_moments_kernel(const double* __restrict__ psum,
+                                                                     const double* __restrict__ pcount, int nb_in,
+                                                                     const double* __restrict__ x, int64_t ld,
+                                                                     int64_t n, double* __restrict__ weights,
+                                                                     double* partials_mom, MaskFold mf) {
+    __shared__ double red[kBlock / kWave];
+    const double total = block_sum_array(psum, nb_in, red);
+    __syncthreads();
+    const double count = block_sum_array(pcount, nb_in, red);
+    const bool renorm = count != 0.0;
+    double v[2 + 2 * D];
+#pragma unroll
+    for (int k = 0; k < 2 + 2 * D; ++k) v[k] = 0.0;
+    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (int64_t)gridDim.x * kBlock) {
+        double xi[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) xi[i] = x[(int64_t)i * ld + p];
+        double w = weights[p];
+        if (renorm) {
+            w = w / total;
+            weights[p] = w;
+        }
+        accumulate_first_moments<D>(v, w, xi);
+    }
+    store_block_partials<2 + 2 * D, true>(v, partials_mom);
+    __shared__ int last;
+    if (!arrive_last<false>(mf.counter, &last)) return;
+    __shared__ double raw[kMaxMomentValues];
+    fold_values_block<kBlock, true, 8>(partials_mom, gridDim.x, 2 + 2 * D, raw);
+    if (threadIdx.x < kWave) {
+        derive_first_moments(raw, D, mf.mom_out, mf.host_mom);
+        if (mf.host_changed) {
+            host_results_before_flag();
+            if (threadIdx.x == 0) *mf.host_changed = (int64_t)count;
+        }
+    }
+}
+
 // good_setting(): p = nan_to_num(u ** pickiness)  (obe_base.py:781-783)
 __global__ __launch_bounds__(kBlock) void power_kernel(const double* __restrict__ u, int64_t n, double k,
                                                        double* __restrict__ p, double* __restrict__ partials) {
@@ -774,6 +825,54 @@ int obe_mask_nonpositive(const double* d_particles, int64_t ld_p, int64_t n_part
             *h_changed = (int64_t)sc[1];
         }
     }
+    return 0;
+}
+
+int obe_mask_nonpositive_moments(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t n_particles,
+                                 const int32_t* h_rows, int32_t n_rows, double* d_weights, double* d_moments,
+                                 double* h_moments, int64_t* h_changed, void* d_ws, int64_t ws_bytes, void* stream) {
+    if (!d_particles || !d_weights || !h_rows || !d_moments || n_rows < 1 || n_rows > OBE_MAX_DIMS || n_particles <= 0)
+        return bad_arg("obe_mask_nonpositive_moments: bad pointer/size");
+    if (n_dims < 1 || n_dims > OBE_MAX_DIMS) return bad_arg("obe_mask_nonpositive_moments: n_dims must be 1..16");
+    hipStream_t st = as_stream(stream);
+    unsigned* counter = stream_control_words(st);
+    int64_t* hc = static_cast<int64_t*>(device_view_of_host(h_changed));
+    double* hm = static_cast<double*>(device_view_of_host(h_moments));
+    if (!counter || (h_changed && !hc) || (h_moments && !hm)) {
+        // no arrival counter for this stream / pageable host buffers: the two separate calls (synchronous)
+        if (int rc = obe_mask_nonpositive(d_particles, ld_p, n_particles, h_rows, n_rows, d_weights, h_changed, d_ws,
+                                          ws_bytes, stream))
+            return rc;
+        return obe_moments(d_particles, ld_p, n_dims, n_particles, d_weights, 0, d_moments, h_moments, d_ws, ws_bytes,
+                           stream);
+    }
+    UpdateWs w;
+    if (int rc = carve_update_ws(d_ws, ws_bytes, w, n_dims)) return rc;
+    RowsArg ra{};
+    ra.n = n_rows;
+    for (int k = 0; k < n_rows; ++k) {
+        if (h_rows[k] < 0 || h_rows[k] >= n_dims) return bad_arg("obe_mask_nonpositive_moments: row index out of range");
+        ra.rows[k] = h_rows[k];
+    }
+    const int nb = stream_blocks(n_particles, kBlock);
+    mask_kernel<<<nb, kBlock, 0, st>>>(ra, d_particles, ld_p, n_particles, d_weights, w.pa, w.pb);
+    OBE_CHECK_LAUNCH("mask_kernel");
+    if (hc) arm_host_word(h_changed);
+    const MaskFold mf{counter, d_moments, hm, hc};
+    const int nm = moment_blocks(n_particles, n_dims);
+#define OBE_MASK_MOM_CASE(DD)                                                                                       \
+    case DD:                                                                                                        \
+        mask_renorm_moments_kernel<DD><<<nm, kBlock, 0, st>>>(w.pa, w.pb, nb, d_particles, ld_p, n_particles,      \
+                                                              d_weights, w.mom, mf);                                \
+        break;
+    switch (n_dims) {
+        OBE_MASK_MOM_CASE(1) OBE_MASK_MOM_CASE(2) OBE_MASK_MOM_CASE(3) OBE_MASK_MOM_CASE(4) OBE_MASK_MOM_CASE(5)
+        OBE_MASK_MOM_CASE(6) OBE_MASK_MOM_CASE(7) OBE_MASK_MOM_CASE(8) OBE_MASK_MOM_CASE(9) OBE_MASK_MOM_CASE(10)
+        OBE_MASK_MOM_CASE(11) OBE_MASK_MOM_CASE(12) OBE_MASK_MOM_CASE(13) OBE_MASK_MOM_CASE(14)
+        OBE_MASK_MOM_CASE(15) OBE_MASK_MOM_CASE(16)
+    }
+#undef OBE_MASK_MOM_CASE
+    OBE_CHECK_LAUNCH("mask_renorm_moments_kernel");
     return 0;
 }
 

@@ -49,18 +49,44 @@ class OptBayesExptNoiseParameter(OptBayesExpt):
     # -- constraint: sigma > 0 (obe_noiseparam.py:57-79) ------------------------------
     def enforce_parameter_constraints(self):
         """Zero the weight of every particle whose noise parameter is <= 0 and
-        renormalise; called by ``pdf_update`` right after a resample."""
+        renormalise; called by ``pdf_update`` right after a resample.  The same two launches leave the
+        first moments of the constrained cloud behind (the next sweep's shift and noise variance need
+        them), and nothing is waited for: ``last_constraint_count`` reads the count when asked."""
         par = self._parameters.tensor()
         w = self._weights.tensor()
         changed = self.__dict__.get("_changed_pinned")
         if changed is None:
             changed = self._changed_pinned = _lib.pinned_array(1, np.int64)
-        self._lib.call("obe_mask_nonpositive", _ptr(par), par.shape[1], self.n_particles,
-                       _lib.host_ptr(self._noise_rows), self.n_channels, _ptr(w), _lib.host_ptr(changed),
-                       _ptr(self._ws), self._ws_bytes, self._stream())
-        if changed[0]:
+        fused = self._parameters is self._particles
+        if fused:
+            self._lib.call("obe_mask_nonpositive_moments", _ptr(par), par.shape[1], self.n_dims, self.n_particles,
+                           _lib.host_ptr(self._noise_rows), self.n_channels, _ptr(w), _ptr(self._moments_dev),
+                           self._hargs.ptr_keep(self._moments_host), _lib.host_ptr(changed), _ptr(self._ws),
+                           self._ws_bytes, self._stream())
+            self._constraint_pending = True
+            # (weights may have changed: a new version either way; the moments describe exactly them)
             self._weights.mark_device_written()
-        self.last_constraint_count = int(changed[0])
+            self._mom_host_key = self._mom_dev_key = (self._particles.version, self._weights.version, False)
+            self._mom_host_wait = _lib.host_ptr(changed)      # (the host copy is complete once the count has arrived)
+        else:       # a stale `parameters` alias (set_pdf between updates): the mask alone, on those rows
+            self._lib.call("obe_mask_nonpositive", _ptr(par), par.shape[1], self.n_particles,
+                           _lib.host_ptr(self._noise_rows), self.n_channels, _ptr(w), _lib.host_ptr(changed),
+                           _ptr(self._ws), self._ws_bytes, self._stream())
+            self._constraint_pending = False
+            if changed[0]:
+                self._weights.mark_device_written()
+
+    @property
+    def last_constraint_count(self):
+        """Particles the most recent enforce_parameter_constraints() gave zero weight (waits for the
+        kernel that counts them if it has not delivered yet)."""
+        changed = self.__dict__.get("_changed_pinned")
+        if changed is None:
+            return 0
+        if self.__dict__.get("_constraint_pending"):
+            self._lib.call("obe_host_word_wait", _lib.host_ptr(changed), self._stream())
+            self._constraint_pending = False
+        return int(changed[0])
 
     # -- noise model: weighted mean of sigma^2 (obe_noiseparam.py:122-136) ------------
     def yvar_noise_model(self):

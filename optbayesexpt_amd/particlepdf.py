@@ -200,6 +200,10 @@ class ParticlePDF:
         """Host copy of the K3 output block (computes it if stale); synchronises."""
         key = (self._particles.version, self._weights.version)
         hk = self._mom_host_key
+        pending = self.__dict__.get("_mom_host_wait")
+        if pending is not None:       # a call that delivers the block without being waited for (the constraint mask)
+            self._mom_host_wait = None
+            self._lib.call("obe_host_word_wait", pending, self._stream())
         if hk is not None and hk[:2] == key and (hk[2] or not want_cov):
             return self._moments_host
         p, w = self._pw_tensors()
@@ -303,13 +307,17 @@ class ParticlePDF:
             self._cdf_key = key
         return self._cdf_dev
 
-    def _device_stream(self, n_uniform, n_normal):
-        """A device-side continuation of self.rng for this many draws, or None when the
-        generator is not PCG64 / the request is small / tuning_parameters['device_rng']
-        is False (then self.rng is called on the host, as the reference does)."""
+    def _device_rng_ok(self, n_uniform, n_normal):
+        """Whether self.rng can be continued on the device for this many draws: a Generator over PCG64,
+        a request large enough to pay for the launches, tuning_parameters['device_rng'] not False."""
         if not self.tuning_parameters.get("device_rng", True):
-            return None
-        if n_uniform + n_normal < _devrng.MIN_DEVICE_DRAWS or _devrng.pcg64_state(self.rng) is None:
+            return False
+        return n_uniform + n_normal >= _devrng.MIN_DEVICE_DRAWS and _devrng.pcg64_state(self.rng) is not None
+
+    def _device_stream(self, n_uniform, n_normal):
+        """A device-side continuation of self.rng for this many draws, or None (then self.rng is
+        called on the host, as the reference does)."""
+        if not self._device_rng_ok(n_uniform, n_normal):
             return None
         return _devrng.DeviceStream(self._lib, self._device, self._stream(), self.rng, n_uniform, n_normal)
 
@@ -418,9 +426,9 @@ class ParticlePDF:
         n, d = self.n_particles, self.n_dims
         method = self.tuning_parameters.get("resample_method", "multinomial")
         if method == "multinomial":                       # the reference: N i.i.d. uniforms
+            if self._device_rng_ok(n, n * d) and self.tuning_parameters.get("pipelined_resample", True):
+                return self._resample_pipelined()
             rstream = self._device_stream(n, n * d)       # exact continuation of self.rng, or None
-            if rstream is not None and self.tuning_parameters.get("pipelined_resample", True):
-                return self._resample_pipelined(rstream)
             idx = self._draw_indices(n, rstream)
         elif method == "systematic":                      # extension: ONE uniform, draws at (i + u0)/N
             cdf = self._cdf()
@@ -447,7 +455,12 @@ class ParticlePDF:
         a = self.tuning_parameters["a_param"]
         newcov = (1 - a ** 2) * cov
         u, s, vh = np.linalg.svd(newcov)
-        if not np.allclose(np.dot(vh.T * s, vh), newcov, rtol=1e-8, atol=1e-8):
+        # numpy's check_valid='warn': allclose(dot(v.T * s, v), cov, rtol = atol = 1e-8), spelled out
+        # (np.allclose itself costs ~25 us of interpreter in every resample)
+        back = np.dot(vh.T * s, vh)
+        with np.errstate(invalid="ignore"):
+            ok = bool(np.all(np.abs(back - newcov) <= 1e-8 + 1e-8 * np.abs(newcov))) and bool(np.all(np.isfinite(newcov)))
+        if not ok:
             warnings.warn("covariance is not symmetric positive-semidefinite.", RuntimeWarning)
         return np.ascontiguousarray(u * np.sqrt(s)), mean
 
@@ -464,63 +477,83 @@ class ParticlePDF:
         self._weights.mark_device_written()
         self.last_resample_indices_device = idx
 
-    def _resample_pipelined(self, rstream):
-        """resample() with the device generator, enqueued so that the device never waits for the
-        host: CDF, uniforms, search, covariance and the ziggurat normals are launched back to back
-        with their host results (sum(w), moments, raw values consumed) copied asynchronously into
-        page-locked memory; the host waits once for the covariance, factorises it while the normals
-        are still being generated, launches the gather + nudge and only then synchronises for the
-        generator bookkeeping.  Same kernels, same numbers and the same generator state as the
-        step-by-step path."""
+    def _resample_buffers(self, n, d):
+        """Scratch of the pipelined resample, made once per cloud shape: raw PCG64 values, uniforms,
+        normals, the ziggurat workspace, page-locked landing zones and their addresses."""
+        b = self.__dict__.get("_rs_bufs")
+        if b is not None and b["shape"] == (n, d) and b["n_raw"] >= n + n * d + b["margin"]:
+            return b
+        margin = max((b or {}).get("margin", 0), (n * d) // 24 + 4096)       # ~2.2 % is consumed extra
+        n_raw = n + n * d + margin
+        dev = self._device
+        zig_bytes = int(self._lib.cdll.obe_ziggurat_workspace_bytes(n_raw - n))
+        mlen = self._lib.moments_len(d)
+        pin_f, pin_flag, pin_i = _lib.pinned_array(mlen + 8), _lib.pinned_array(2, np.uint64), _lib.pinned_array(2, np.int64)
+        b = self._rs_bufs = dict(
+            shape=(n, d), margin=margin, n_raw=n_raw,
+            raw=torch.empty(n_raw, dtype=torch.int64, device=dev), uni=torch.empty(n, dtype=torch.float64, device=dev),
+            normals=torch.empty(n * d, dtype=torch.float64, device=dev),
+            zig_ws=torch.empty(zig_bytes // 8 + 1, dtype=torch.float64, device=dev), tables=_devrng._tables(dev),
+            pin_f=pin_f, pin_flag=pin_flag, pin_i=pin_i, p_f=_lib.host_ptr(pin_f), p_flag=_lib.host_ptr(pin_flag),
+            p_i=_lib.host_ptr(pin_i), p_i1=_P(pin_i.ctypes.data + 8))
+        return b
+
+    def _resample_pipelined(self):
+        """resample() with the caller's generator continued on the device.  ONE library call
+        (obe_resample_begin) enqueues CDF, uniforms, search, covariance and the ziggurat normals back to
+        back; the host waits — by watching a page-locked word the covariance kernel stores last — for
+        the covariance, factorises it while the normals are still being generated, launches the gather
+        + nudge and then reads the generator bookkeeping the same way (no stream synchronisation, so
+        the gather runs on while the caller goes on).  Same kernels, same numbers and the same
+        generator state as the step-by-step path."""
         n, d = self.n_particles, self.n_dims
         if self._weights.shape[0] != n:
             raise ValueError("a and p must have same size")
+        st, h_state = _devrng.pcg64_state(self._rng)
         strict = bool(self.tuning_parameters.get("strict_cdf", False))
         key = (self._weights.version, strict)
         p, w = self._pw_tensors()
         if self._cdf_dev.numel() != n:
             self._cdf_dev = torch.empty(n, dtype=torch.float64, device=self._device)
-        pin_f, pin_i = self._pinned_f64, self._pinned_i64
+            self._cdf_key = None
+        b = self._resample_buffers(n, d)
         mlen = self._lib.moments_len(d)
-        stream = torch.cuda.current_stream(self._device)
         idx = torch.empty(n, dtype=torch.int64, device=self._device)
-        prev = self._lib.cdll.obe_defer_host_sync(1)
-        try:
-            if self._cdf_key != key:
-                self._lib.call("obe_weight_cdf", _ptr(w), n, 1 if strict else 0, _ptr(self._cdf_dev),
-                               _P(pin_f.data_ptr()), _ptr(self._ws), self._ws_bytes, self._stream())
-            else:
-                pin_f[0] = 1.0
-            u_dev = rstream.uniforms()
-            self._lib.call("obe_cdf_search", _ptr(self._cdf_dev), n, _ptr(u_dev), n, _ptr(idx), _ptr(self._ws),
-                           self._ws_bytes, self._stream())
-            mkey = (self._particles.version, self._weights.version)
-            have_first = self._mom_host_key is not None and self._mom_host_key[:2] == mkey \
-                and self._mom_dev_key is not None and self._mom_dev_key[:2] == mkey
-            self._lib.call("obe_moments", _ptr(p), p.shape[1], d, n, _ptr(w), 2 if have_first else 1,
-                           _ptr(self._moments_dev), _P(pin_f.data_ptr() + 8), _ptr(self._ws), self._ws_bytes,
-                           self._stream())
-            have_cov = torch.cuda.Event()
-            have_cov.record(stream)
-            z_dev = rstream.normals_deferred(pin_i)
-        finally:
-            self._lib.cdll.obe_defer_host_sync(prev)
-        have_cov.synchronize()                        # the normals are still being generated
+        mkey = (self._particles.version, self._weights.version)
+        have_first = self._mom_host_key is not None and self._mom_host_key[:2] == mkey \
+            and self._mom_dev_key is not None and self._mom_dev_key[:2] == mkey
+        stream = self._stream()
+        self._lib.call("obe_resample_begin", _ptr(p), p.shape[1], d, n, _ptr(w), _lib.host_ptr(h_state),
+                       1 if strict else 0, 1 if self._cdf_key == key else 0, 1 if have_first else 0,
+                       _ptr(b["raw"]), b["n_raw"], _ptr(self._cdf_dev), _ptr(b["uni"]), _ptr(idx), _ptr(b["tables"]),
+                       _ptr(b["normals"]), _ptr(b["zig_ws"]), b["zig_ws"].numel() * 8, _ptr(self._moments_dev),
+                       b["p_f"], b["p_flag"], b["p_i"], _ptr(self._ws), self._ws_bytes, stream)
+        self._lib.call("obe_host_word_wait", b["p_flag"], stream)      # the covariance is there; the normals still run
+        pin_f = b["pin_f"]
         self._validate_total(float(pin_f[0]))         # (raises before any generator state has moved)
         self._cdf_key = key
         first = 2 + 4 * d                              # (a covariance-only pass delivers only the covariance)
         lo = first if have_first else 0
-        self._moments_host[lo:mlen] = pin_f[1 + lo:1 + mlen].numpy()
+        self._moments_host[lo:mlen] = pin_f[1 + lo:1 + mlen]
         self._mom_host_key = self._mom_dev_key = mkey + (True,)
         factor, mean = self._nudge_factor(self._moments_host)
         self.last_draw_indices_device = idx
         before = self._particles
-        self._resample_apply(idx, z_dev, factor, mean)
-        stream.synchronize()
-        if not rstream.finish_normals(pin_i):         # unlucky stream: the raw buffer was too short
-            z_dev = rstream.normals()
+        self._resample_apply(idx, b["normals"], factor, mean)
+        self._lib.call("obe_host_word_wait", b["p_i1"], stream)        # {raw consumed, normals found}
+        consumed, found = int(b["pin_i"][0]), int(b["pin_i"][1])
+        if self._lib.cdll.obe_ziggurat_check(consumed, found, n * d, b["n_raw"] - n, 0) != 0:
+            # unlucky stream (never seen): the raw buffer was too short for N D normals — draw them
+            # again from a longer one and repeat the gather from the old cloud
+            b["margin"] = 2 * b["margin"] + 65536
+            rstream = _devrng.DeviceStream(self._lib, self._device, stream, self._rng, n, n * d)
+            rstream.margin = b["margin"]
+            rstream._generate()
+            z_dev = rstream.normals()                  # (advances the generator past uniforms + normals)
             self._particles = before
             self._resample_apply(idx, z_dev, factor, mean)
+        else:
+            _devrng.advance(self._rng, st, n + consumed)
 
     @staticmethod
     def _normalized_product(weight_array, likelihood_array):

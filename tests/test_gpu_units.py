@@ -477,7 +477,7 @@ def test_weighted_full_sweep_matches_the_reference_with_integer_multiplicities(o
         o.opt_setting()
         assert o.last_setting_index == int(np.argmax(want))
         if shift == "auto" and tag == "lornarrow":
-            assert o.last_sweep["shifted"] and o.last_sweep["kappa"] > 3000
+            assert o.last_sweep["shifted"] and o.last_sweep["kappa"] > obe.OptBayesExpt.KAPPA_ENTER
 
 
 def test_sweep_shapes_ragged(obe):
