@@ -152,7 +152,6 @@ struct MomentsOut {
     double* out;
     double* host;
     uint64_t* host_flag;
-    unsigned* counter;          // arrival counter of the stream (the fold rides in the producing launch), or NULL
 };
 
 // every storing wave has drained its stores to the host, then one thread raises the flag

@@ -14,13 +14,15 @@
 namespace obe {
 
 // values: [0] sum w, [1] sum w*w, [2+i] sum x_i*w, [2+D+i] sum (x_i*x_i)*w
-// FOLD (round 4): the workgroup that arrives last folds everybody's block partials (written through) and
-// derives mean / std in the same launch — the same sums in the same order as the separate one-workgroup
-// fold kernels (which remain for streams without an arrival counter): identical bits, one launch less.
-template <int D, bool FOLD>
+// (Round 4, measured and not kept: folding the block partials inside these kernels by the last workgroup to
+// arrive — write-through partials, arrival counter — instead of the one-workgroup fold launches below.  At
+// D = 10 the covariance pass took 32 us against 13.8 + 8.4 us: a 4-wave workgroup reads the 256 x 55
+// partials more slowly than the 16-wave fold kernel, and every workgroup drains its write-through stores
+// before it can take its ticket.  The update's normalisation pass, whose fold is 8-22 values, keeps it.)
+template <int D>
 __global__ __launch_bounds__(kBlock) void moments_pass1(const double* __restrict__ x, int64_t ld, int64_t n,
-                                                        const double* __restrict__ w, double* partials,
-                                                        MomentsOut mo) {
+                                                        const double* __restrict__ w,
+                                                        double* __restrict__ partials) {
     double v[2 + 2 * D];
 #pragma unroll
     for (int k = 0; k < 2 + 2 * D; ++k) v[k] = 0.0;
@@ -43,23 +45,15 @@ __global__ __launch_bounds__(kBlock) void moments_pass1(const double* __restrict
             if (p + u * stride < n) accumulate_first_moments<D>(v, wp[u], xi[u]);
         }
     }
-    store_block_partials<2 + 2 * D, FOLD>(v, partials);
-    if constexpr (FOLD) {
-        __shared__ int last;
-        if (!arrive_last<false>(mo.counter, &last)) return;
-        __shared__ double raw[kMaxMomentValues];
-        fold_values_block<kBlock, true, 8>(partials, gridDim.x, 2 + 2 * D, raw);
-        derive_first_moments(raw, D, mo.out, mo.host);
-        raise_host_flag(mo.host_flag);
-    }
+    store_block_partials<2 + 2 * D>(v, partials);
 }
 
 // values: upper triangle (i <= j) of sum (x_i - mu_i) * ((x_j - mu_j) * w), row-major
-template <int D, bool FOLD>
+template <int D>
 __global__ __launch_bounds__(kBlock) void moments_pass2(const double* __restrict__ x, int64_t ld, int64_t n,
                                                         const double* __restrict__ w,
-                                                        const double* out /* mean at out+2 */, double* partials,
-                                                        MomentsOut mo) {
+                                                        const double* __restrict__ out /* mean at out+2 */,
+                                                        double* __restrict__ partials) {
     constexpr int NV = D * (D + 1) / 2;
     double v[NV];
     double mu[D];
@@ -93,15 +87,7 @@ __global__ __launch_bounds__(kBlock) void moments_pass2(const double* __restrict
             }
         }
     }
-    store_block_partials<NV, FOLD>(v, partials);
-    if constexpr (FOLD) {
-        __shared__ int last;
-        if (!arrive_last<false>(mo.counter, &last)) return;
-        __shared__ double raw[kMaxMomentValues];
-        fold_values_block<kBlock, true, 8>(partials, gridDim.x, NV, raw);
-        derive_covariance(raw, D, mo.out, mo.host);
-        raise_host_flag(mo.host_flag);
-    }
+    store_block_partials<NV>(v, partials);
 }
 
 // fold + derive in one single-workgroup launch
@@ -130,26 +116,16 @@ static int launch_moments(const double* x, int64_t ld, int64_t n, const double* 
     MomentsOut first = mo;
     if (want_cov) first.host_flag = nullptr;            // (the flag belongs to the last launch of the call)
     if (want_cov != 2) {            // (2: `out` already holds the first moments of these weights)
-        if (mo.counter) {
-            moments_pass1<D, true><<<nb, kBlock, 0, st>>>(x, ld, n, w, partials, first);
-            OBE_CHECK_LAUNCH("moments_pass1");
-        } else {
-            moments_pass1<D, false><<<nb, kBlock, 0, st>>>(x, ld, n, w, partials, first);
-            OBE_CHECK_LAUNCH("moments_pass1");
-            fold_derive_pass1<<<1, kFoldThreads, 0, st>>>(partials, nb, D, first);
-            OBE_CHECK_LAUNCH("fold_derive_pass1");
-        }
+        moments_pass1<D><<<nb, kBlock, 0, st>>>(x, ld, n, w, partials);
+        OBE_CHECK_LAUNCH("moments_pass1");
+        fold_derive_pass1<<<1, kFoldThreads, 0, st>>>(partials, nb, D, first);
+        OBE_CHECK_LAUNCH("fold_derive_pass1");
     }
     if (want_cov) {
-        if (mo.counter) {
-            moments_pass2<D, true><<<nb, kBlock, 0, st>>>(x, ld, n, w, mo.out, partials, mo);
-            OBE_CHECK_LAUNCH("moments_pass2");
-        } else {
-            moments_pass2<D, false><<<nb, kBlock, 0, st>>>(x, ld, n, w, mo.out, partials, mo);
-            OBE_CHECK_LAUNCH("moments_pass2");
-            fold_derive_pass2<<<1, kFoldThreads, 0, st>>>(partials, nb, D, mo);
-            OBE_CHECK_LAUNCH("fold_derive_pass2");
-        }
+        moments_pass2<D><<<nb, kBlock, 0, st>>>(x, ld, n, w, mo.out, partials);
+        OBE_CHECK_LAUNCH("moments_pass2");
+        fold_derive_pass2<<<1, kFoldThreads, 0, st>>>(partials, nb, D, mo);
+        OBE_CHECK_LAUNCH("fold_derive_pass2");
     }
     return 0;
 }
@@ -166,8 +142,7 @@ int moments_call(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_
     double* partials = static_cast<double*>(d_ws);
     double* hv = static_cast<double*>(device_view_of_host(h_out));     // page-locked h_out: the kernels write it
     uint64_t* hf = hv ? static_cast<uint64_t*>(device_view_of_host(h_flag)) : nullptr;
-    static const bool separate = getenv("OBE_MOMENTS_FOLD") && !strcmp(getenv("OBE_MOMENTS_FOLD"), "separate");
-    const MomentsOut mo{d_out, hv, hf, separate ? nullptr : stream_control_words(st)};
+    const MomentsOut mo{d_out, hv, hf};
     if (host_written) *host_written = hv != nullptr;
     int rc = -1;
 #define OBE_MOM_CASE(DD) \

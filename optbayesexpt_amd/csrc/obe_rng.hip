@@ -286,6 +286,7 @@ __global__ __launch_bounds__(kBlock) void zig_compact_kernel(const uint8_t* __re
         sval[threadIdx.x + j * kBlock] = i < n_raw ? val[i] : 0.0;
     }
     uint32_t v[kFlagItems], f[kFlagItems];
+    int owns_last_normal = 0;           // this thread found the n-th normal (at most one thread of the grid)
     const int64_t i0 = tile0 + (int64_t)threadIdx.x * kFlagItems;
     const uint64_t packed = i0 < n_raw ? *reinterpret_cast<const uint64_t*>(flag + i0) : 0ull;   // 8 byte flags
 #pragma unroll
@@ -300,6 +301,7 @@ __global__ __launch_bounds__(kBlock) void zig_compact_kernel(const uint8_t* __re
             if (rank == n - 1) {
                 const int64_t i = i0 + k;
                 __hip_atomic_store(result, i + (int64_t)len[i] - first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                owns_last_normal = 1;
             }
         }
     }
@@ -308,12 +310,28 @@ __global__ __launch_bounds__(kBlock) void zig_compact_kernel(const uint8_t* __re
         const int64_t rank = (int64_t)off + j;
         if (rank < n) out[rank] = sout[j];
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
-        __hip_atomic_store(result + 1, (int64_t)off + total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool is_last_block = blockIdx.x == gridDim.x - 1;
+    const int64_t found = (int64_t)off + total;                  // (in the last workgroup: all starts found)
+    if (is_last_block && threadIdx.x == 0)
+        __hip_atomic_store(result + 1, found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (host) {
-        __shared__ int last;
-        if (!arrive_last<false>(counter, &last)) return;
-        if (threadIdx.x == 0) {
+        // Two workgroups hold the result: the one with the n-th normal ({consumed}) and the last one ({found});
+        // whichever of the two finishes second delivers (a counter that wraps at two arrivals — a ticket from
+        // every one of the ~2600 workgroups cost 19 us of serialised atomics).  No n-th normal (found < n, the
+        // caller's check will fail): the last workgroup delivers alone.
+        const int owner = __syncthreads_or(owns_last_normal);
+        const bool alone = is_last_block && (owner || found < n);
+        if (!alone && !owner && !is_last_block) return;
+        bool deliver = alone;
+        if (!alone) {
+            __shared__ int second;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) second = atomicInc(counter, 1u) == 1u;
+            __syncthreads();
+            deliver = second != 0;
+        }
+        if (deliver && threadIdx.x == 0) {
             host[0] = __hip_atomic_load(result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             host_results_before_flag();
             host[1] = __hip_atomic_load(result + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -376,17 +376,20 @@ __device__ __forceinline__ void block_argmax(Best b, double* bv, int64_t* bi) {
     }
 }
 
-// folds the chunk partials -> yvar, utility; first maximum and worst kappa over all settings.
-// A workgroup owns 64 consecutive settings; its 16 wavefronts each sum a sixteenth of the chunks
-// (coalesced 512-byte rows, up to 8 independent loads in flight per lane), the groups are combined in a
-// fixed order through LDS.  (One thread per setting walking all chunks serially was latency-bound: 100+ us
-// at 512 chunks; 4 wavefronts with 4 loads in flight still took 10.8 us for the 12.6 MB of a 4096 x 262 144
-// sweep — 48 dependent-latency trips per wave — as long as for the 42 MB of 65 536 x 1 048 576.)
-// Round 4: the launch also does what argmax_fold did — every workgroup publishes its {first max, index,
-// kappa} write-through and the one that arrives last folds them and delivers the result record (host
-// words included): one dependent launch less between two sweeps.
-constexpr int kFinGroups = 16;                      // chunk groups = wavefronts of a finalize workgroup
-constexpr int kFinThreads = kFinGroups * kWave;
+// folds the chunk partials -> yvar, utility; per-workgroup first maximum and worst kappa (argmax_fold finishes).
+// A workgroup owns 64 consecutive settings; its FG wavefronts each sum an FG-th of the chunks (coalesced
+// 512-byte rows, up to 8 independent loads in flight per lane), the groups are combined in a fixed order
+// through LDS.  (One thread per setting walking all chunks serially was latency-bound: 100+ us at 512
+// chunks.)  FG = 16 when there are many chunks per setting — a 4096 x 262 144 sweep has 192 of them and only
+// 64 finalize workgroups: 4 wavefronts with 4 loads in flight took 10.8 us for its 12.6 MB, 48 dependent
+// trips per wave, 16 wavefronts take 7.9 us — FG = 4 when there are few (65 536 x 1 048 576: 40 chunks,
+// 1024 workgroups, bandwidth-bound: 11.3 us with 4, 14.3 us with 16).
+// Round 4, measured and not kept: argmax_fold's work done here by the last workgroup to arrive (write-through
+// entries, arrival counter).  With 64-1024 workgroups the serialised tickets (~12 ns each) and the tail of
+// the last workgroup cost more than the launch they save: 14.3 vs 7.9 + 4.9 us (4096 x 262 144), 27.0 vs
+// 14.3 + 7.0 us (65 536 x 1 048 576), 18.1 vs 9.6 + 5.2 us (16 384 x 524 288, 10 parameters).
+constexpr int kFinGroupsMany = 16, kFinGroupsFew = 4;      // chunk groups = wavefronts of a finalize workgroup
+constexpr int kFinManyChunks = 64;
 
 // worst cancellation factor so far; a NaN (some variance is NaN) is sticky
 __device__ __forceinline__ double kappa_worst(double a, double b) {
@@ -442,23 +445,17 @@ __device__ __forceinline__ void write_result_record(double* out_v, int64_t* out_
     deliver(host, b.v, b.i, k);
 }
 
-struct FinalizeFold {
-    unsigned* counter;        // arrival counter of the stream, or NULL: argmax_fold follows in its own launch
-    double* out_v;
-    int64_t* out_i;
-    HostResult host;
-};
-
-__global__ __launch_bounds__(kFinThreads) void sweep_finalize(const double* __restrict__ part1,
-                                                              const double* __restrict__ part2, int nchunks, int nc,
-                                                              int64_t ns, const double* __restrict__ moments,
-                                                              int full_mode, UtilArgs ua,
-                                                              const double* __restrict__ cs,
-                                                              double* __restrict__ yvar,
-                                                              double* __restrict__ utility, double* bv,
-                                                              int64_t* bi, double* bk, FinalizeFold ff) {
-    __shared__ double acc1[OBE_MAX_CHANNELS][kFinGroups][kFinSettings];
-    __shared__ double acc2[OBE_MAX_CHANNELS][kFinGroups][kFinSettings];
+template <int FG>
+__global__ __launch_bounds__(FG * kWave) void sweep_finalize(const double* __restrict__ part1,
+                                                             const double* __restrict__ part2, int nchunks, int nc,
+                                                             int64_t ns, const double* __restrict__ moments,
+                                                             int full_mode, UtilArgs ua,
+                                                             const double* __restrict__ cs,
+                                                             double* __restrict__ yvar,
+                                                             double* __restrict__ utility, double* __restrict__ bv,
+                                                             int64_t* __restrict__ bi, double* __restrict__ bk) {
+    __shared__ double acc1[OBE_MAX_CHANNELS][FG][kFinSettings];
+    __shared__ double acc2[OBE_MAX_CHANNELS][FG][kFinSettings];
     const double W = full_mode ? moments[0] : 1.0;
     const int lane = threadIdx.x & (kWave - 1), grp = threadIdx.x / kWave;
     const int64_t s = (int64_t)blockIdx.x * kFinSettings + lane;
@@ -466,11 +463,11 @@ __global__ __launch_bounds__(kFinThreads) void sweep_finalize(const double* __re
         double a1 = 0.0, a2 = 0.0;
         if (s < ns) {
             int k = grp;
-            for (; k + 3 * kFinGroups < nchunks; k += 4 * kFinGroups) {        // 8 loads in flight
+            for (; k + 3 * FG < nchunks; k += 4 * FG) {        // 8 loads in flight
                 double t1[4], t2[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int64_t o = ((int64_t)(k + u * kFinGroups) * nc + c) * ns + s;
+                    const int64_t o = ((int64_t)(k + u * FG) * nc + c) * ns + s;
                     t1[u] = part1[o];
                     t2[u] = part2[o];
                 }
@@ -480,7 +477,7 @@ __global__ __launch_bounds__(kFinThreads) void sweep_finalize(const double* __re
                     a2 += t2[u];
                 }
             }
-            for (; k < nchunks; k += kFinGroups) {
+            for (; k < nchunks; k += FG) {
                 const int64_t o = ((int64_t)k * nc + c) * ns + s;
                 a1 += part1[o];
                 a2 += part2[o];
@@ -490,76 +487,41 @@ __global__ __launch_bounds__(kFinThreads) void sweep_finalize(const double* __re
         acc2[c][grp][lane] = a2;
     }
     __syncthreads();
-    if (grp == 0) {
-        Best best{-INFINITY, INT64_MAX};
-        double kappa = 0.0;     // worst (mean of y')^2 / var: the cancellation an UNSHIFTED sweep would suffer
-        if (s < ns) {
-            double var[OBE_MAX_CHANNELS];
-            for (int c = 0; c < nc; ++c) {
-                double a1 = 0.0, a2 = 0.0;
-#pragma unroll
-                for (int g = 0; g < kFinGroups; ++g) {
-                    a1 += acc1[c][g][lane];
-                    a2 += acc2[c][g][lane];
-                }
-                // (Measured alternative: chunk partials combined with TwoSum and S1*(S1/W) formed exactly
-                // with FMAs, plus per-tile flushing of the running sums, lowers the error of the
-                // unshifted variance from ~1e-15*kappa to ~2e-16*kappa — but the exact product then
-                // exposes the rounding of S2 itself, e.g. a non-zero variance for a single draw where
-                // the plain formula cancels to the reference's exact 0.  Not kept.)
-                const double mu = a1 / W;
-                double v = (a2 - a1 * mu) / W;
-                v = v > 0.0 ? v : (v != v ? v : 0.0);          // rounding may leave -0 / tiny negatives; NaN stays NaN (np.var)
-                var[c] = v;
-                yvar[(int64_t)c * ns + s] = v;
-                const double m = cs[(int64_t)c * ns + s] + mu;
-                const double k = v != v ? v : (v > 0.0 ? (m * m) / v : (m == 0.0 ? 0.0 : INFINITY));
-                kappa = kappa_worst(kappa, k);                 // a NaN variance is reported as kappa = NaN
-            }
-            const double u = utility_of(var, nc, s, ua);
-            utility[s] = u;
-            best = Best{u, s};
-        }
-        wave_best(best, kappa);
-        if (lane == 0) {
-            if (ff.counter) {
-                store_published(bv + blockIdx.x, best.v);
-                store_published(reinterpret_cast<double*>(bi) + blockIdx.x, __longlong_as_double(best.i));
-                store_published(bk + blockIdx.x, kappa);
-            } else {
-                bv[blockIdx.x] = best.v;
-                bi[blockIdx.x] = best.i;
-                bk[blockIdx.x] = kappa;
-            }
-        }
-    }
-    if (!ff.counter) return;
-    __shared__ int last;
-    if (!arrive_last<false>(ff.counter, &last)) return;
-    // the last workgroup to arrive: first maximum and worst kappa over every workgroup's entry
+    if (grp != 0) return;
     Best best{-INFINITY, INT64_MAX};
-    double kmax = 0.0;
-    for (int b = threadIdx.x; b < (int)gridDim.x; b += kFinThreads) {
-        const Best cand{load_published_f64(bv + b), __double_as_longlong(load_published_f64(reinterpret_cast<double*>(bi) + b))};
-        if (better(cand, best)) best = cand;
-        kmax = kappa_worst(kmax, load_published_f64(bk + b));
-    }
-    wave_best(best, kmax);
-    __shared__ double wv[kFinGroups], wk[kFinGroups];
-    __shared__ int64_t wi[kFinGroups];
-    if (lane == 0) {
-        wv[grp] = best.v;
-        wi[grp] = best.i;
-        wk[grp] = kmax;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int g = 1; g < kFinGroups; ++g) {
-            const Best y{wv[g], wi[g]};
-            if (better(y, best)) best = y;
-            kmax = kappa_worst(kmax, wk[g]);
+    double kappa = 0.0;     // worst (mean of y')^2 / var: the cancellation an UNSHIFTED sweep would suffer
+    if (s < ns) {
+        double var[OBE_MAX_CHANNELS];
+        for (int c = 0; c < nc; ++c) {
+            double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+            for (int g = 0; g < FG; ++g) {
+                a1 += acc1[c][g][lane];
+                a2 += acc2[c][g][lane];
+            }
+            // (Measured alternative: chunk partials combined with TwoSum and S1*(S1/W) formed exactly
+            // with FMAs, plus per-tile flushing of the running sums, lowers the error of the
+            // unshifted variance from ~1e-15*kappa to ~2e-16*kappa — but the exact product then
+            // exposes the rounding of S2 itself, e.g. a non-zero variance for a single draw where
+            // the plain formula cancels to the reference's exact 0.  Not kept.)
+            const double mu = a1 / W;
+            double v = (a2 - a1 * mu) / W;
+            v = v > 0.0 ? v : (v != v ? v : 0.0);          // rounding may leave -0 / tiny negatives; NaN stays NaN (np.var)
+            var[c] = v;
+            yvar[(int64_t)c * ns + s] = v;
+            const double m = cs[(int64_t)c * ns + s] + mu;
+            const double k = v != v ? v : (v > 0.0 ? (m * m) / v : (m == 0.0 ? 0.0 : INFINITY));
+            kappa = kappa_worst(kappa, k);                 // a NaN variance is reported as kappa = NaN
         }
-        write_result_record(ff.out_v, ff.out_i, best, kmax, ff.host);
+        const double u = utility_of(var, nc, s, ua);
+        utility[s] = u;
+        best = Best{u, s};
+    }
+    wave_best(best, kappa);
+    if (lane == 0) {
+        bv[blockIdx.x] = best.v;
+        bi[blockIdx.x] = best.i;
+        bk[blockIdx.x] = kappa;
     }
 }
 
@@ -930,7 +892,9 @@ int obe_sweep_utility(const obe_model* m, const double* d_settings, int64_t ld_s
         if (rc) return rc;
         return read_best(w, h_best, h_best_idx, st, h_kappa, hr);
     }
-    const bool timed = g_timing.on && (h_best || h_best_idx || h_kappa);
+    // (a call without host outputs — a sharded rank reads the record itself — is timed too: it waits for the
+    // sweep kernel's end event instead of for the result)
+    const bool timed = g_timing.on;
     if (timed) {
         int dev = 0;
         OBE_HIP_TRY(hipGetDevice(&dev));
@@ -952,16 +916,19 @@ int obe_sweep_utility(const obe_model* m, const double* d_settings, int64_t ld_s
     if (rc) return rc;
     const int nb = static_cast<int>((n_settings + kFinSettings - 1) / kFinSettings);
     if (nb > kFinMaxBlocks) return bad_arg("obe_sweep_utility: more than 4 194 304 settings per call");
-    static const bool separate = getenv("OBE_SWEEP_FOLD") && !strcmp(getenv("OBE_SWEEP_FOLD"), "separate");   // A/B aid
-    const FinalizeFold ff{separate ? nullptr : stream_control_words(st), w.out_v, w.out_i, hr};
-    sweep_finalize<<<nb, kFinThreads, 0, st>>>(w.part1, w.part2, plan.nchunks, mm.n_channels, n_settings, d_moments,
-                                               d_draw_idx == nullptr, ua, w.cs, d_yvar, d_utility, w.bv, w.bi, w.bk, ff);
+    if (plan.nchunks >= kFinManyChunks)
+        sweep_finalize<kFinGroupsMany><<<nb, kFinGroupsMany * kWave, 0, st>>>(
+            w.part1, w.part2, plan.nchunks, mm.n_channels, n_settings, d_moments, d_draw_idx == nullptr, ua, w.cs,
+            d_yvar, d_utility, w.bv, w.bi, w.bk);
+    else
+        sweep_finalize<kFinGroupsFew><<<nb, kFinGroupsFew * kWave, 0, st>>>(
+            w.part1, w.part2, plan.nchunks, mm.n_channels, n_settings, d_moments, d_draw_idx == nullptr, ua, w.cs,
+            d_yvar, d_utility, w.bv, w.bi, w.bk);
     OBE_CHECK_LAUNCH("sweep_finalize");
-    if (!ff.counter) {
-        argmax_fold<<<1, kBlock, 0, st>>>(w.bv, w.bi, nb, w.bk, w.out_v, w.out_i, hr);
-        OBE_CHECK_LAUNCH("argmax_fold");
-    }
+    argmax_fold<<<1, kBlock, 0, st>>>(w.bv, w.bi, nb, w.bk, w.out_v, w.out_i, hr);
+    OBE_CHECK_LAUNCH("argmax_fold");
     rc = read_best(w, h_best, h_best_idx, st, h_kappa, hr);
+    if (timed && !rc && !(h_best || h_best_idx || h_kappa)) rc = (int)hipEventSynchronize(g_timing.e1);
     if (timed && !rc) {                       // the stream is drained: both events have completed
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, g_timing.e0, g_timing.e1) == hipSuccess) {
