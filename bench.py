@@ -19,13 +19,16 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                   ``valu_issue`` prices the kernel in FP64 issue slots counted in its ISA
                   (tools/count_isa.py) against the chip's issue rate — the flop roofline
                   treats every slot as an FMA, the kernel's mix is half mul/add.
-  roofline_update — the HBM-bound Bayes update with the posterior's first moments (K2 + K3 pass 1, the three
+  roofline_update — the HBM-bound Bayes update with the posterior's first moments (K2 + K3 pass 1, the two
                   launches of pdf_update()), bytes / time.
   cpu_baseline  — the NumPy oracle on one host core, on a bounded sub-grid (N = 1 only);
                   for c1 the oracle class itself through whole reference-semantics cycles.
   cpu_baseline_allcores — the plain C + OpenMP restatement on every host core (full-sweep configs).
   published_workload — the loop behind the only timing the reference publishes for this path (200 settings x
                   30 draws, 50 000 particles: 4.37 ms per cycle, hardware unstated), through this package.
+  other_configs — (default c3 run, N = 1) the cycle loops of c1, c2 and c5 after the timed region.
+With --gpus N > 1 and no launcher around it (no WORLD_SIZE in the environment) the script starts its N
+ranks itself, as fresh child processes, before anything here touches the GPU.
 """
 import argparse
 import ctypes
@@ -91,7 +94,7 @@ def build_obe(cfg, shard, settings, prior, cons):
                                           settings_shard=shard)
 
 
-def cpu_baseline(cfg, settings, prior, cons, true, sigma, target_s=10.0):
+def cpu_baseline(cfg, settings, prior, cons, true, sigma, target_s=8.0):
     """The oracle (NumPy, one core) on a bounded sample of the same workload: the full
     particle cloud against a sub-grid of evenly spaced settings for the sweep, plus the
     full update.  A short probe sizes the sub-grid for ~``target_s`` seconds of CPU work.
@@ -121,27 +124,34 @@ def cpu_baseline(cfg, settings, prior, cons, true, sigma, target_s=10.0):
                           f"{o.N_DRAWS} draws + {n_p}-particle update each), {dt:.1f} s, {1e3 * dt / n_cycles:.3f} ms per cycle",
                 "host_cpus": os.cpu_count()}
 
-    def cycle(n_sub):
-        sub = (np.ascontiguousarray(settings[0][:: max(1, ns // n_sub)][:n_sub]),)
-        t0 = time.perf_counter()
+    # evenly spaced sub-grids of 64 settings each, one full cycle per sub-grid (sweep of the sub-grid over the
+    # whole cloud + the full update), until the time budget is used: the sample is bounded by the clock, not
+    # by an extrapolation from a probe (round 3's probe undershot: 20.8 s for a 10 s target)
+    step = min(64, ns)
+    n_blocks = ns // step
+    n_used, t0 = 0, time.perf_counter()
+    for b in range(0, n_blocks, max(1, n_blocks // 16)):           # up to 16 blocks, evenly spaced over the grid
+        block = slice(b * step, (b + 1) * step)
+        sub = (np.ascontiguousarray(settings[0][block]),)
         yvar = oracle.yvar_full_sweep(fn, oracle.flatten_settings(sub), prior, w, cons, chunk=4096)
         util = oracle.utility_from_yvar(yvar, sigma ** 2, 1.0)
         x = (sub[0][int(np.argmax(util))],)
         lik = oracle.gauss_likelihood(fn(x, prior, cons), float(fn(x, true, cons)), sigma)
         oracle.effective_particles(oracle.normalized_product(w, lik))
-        return len(sub[0]), time.perf_counter() - t0
-
-    n0, dt0 = cycle(min(32, ns))
-    n_sub = int(min(ns, max(n0, n0 * target_s / max(dt0, 1e-3))))
-    n_used, dt = cycle(n_sub)
-    evals = n_used * n_p + n_p
+        n_used += step
+        if time.perf_counter() - t0 >= target_s:
+            break
+    dt = time.perf_counter() - t0
+    n_cycles = n_used // step
+    evals = n_used * n_p + n_cycles * n_p
     return {"value": evals / dt, "unit": "model-evals/s", "cores": 1, "kind": "port",
-            "sample": f"{n_used} of {ns} settings x all {n_p} particles (two-pass weighted variance, "
-                      f"chunked) + full {n_p}-particle update, {dt:.1f} s; NumPy ufuncs are single-threaded",
+            "sample": f"{n_used} of {ns} settings (in {n_cycles} evenly spaced blocks of {step}) x all {n_p} particles "
+                      f"(two-pass weighted variance, chunked) + {n_cycles} full {n_p}-particle updates, {dt:.1f} s; "
+                      f"NumPy ufuncs are single-threaded",
             "host_cpus": os.cpu_count()}
 
 
-def cpu_baseline_allcores(cfg, settings, prior, cons, true, sigma, target_s=8.0):
+def cpu_baseline_allcores(cfg, settings, prior, cons, true, sigma, target_s=6.0):
     """The same cycle as a plain-C restatement (oracle/csweep.c) on every host core
     (OpenMP over settings): what the host of this box can do at best, next to the faithful
     single-threaded NumPy figure.  Lorentzian configs only."""
@@ -150,20 +160,21 @@ def cpu_baseline_allcores(cfg, settings, prior, cons, true, sigma, target_s=8.0)
     k = 1 if model == "lorentzian" else 7
     w = np.full(n_p, 1.0 / n_p)
 
-    def cycle(n_sub):
-        sub = np.ascontiguousarray(settings[0][:: max(1, ns // n_sub)][:n_sub])
-        t0 = time.perf_counter()
+    step = max(64, 8 * csweep.threads())
+    n_used, n_cycles, t0 = 0, 0, time.perf_counter()
+    for lo in range(0, ns - step + 1, step):
+        sub = np.ascontiguousarray(settings[0][lo:lo + step])
         yvar = csweep.lorentz_yvar(sub, prior, w, cons[0], k)
         x = sub[int(np.argmax(yvar))]
         csweep.lorentz_update(x, 49500.0, sigma, prior, w, cons[0], k)
-        return len(sub), time.perf_counter() - t0
-
-    n0, dt0 = cycle(min(ns, 4 * csweep.threads()))
-    n_sub = int(min(ns, max(n0, n0 * target_s / max(dt0, 1e-3))))
-    n_used, dt = cycle(n_sub)
-    return {"value": (n_used * n_p + n_p) / dt, "unit": "model-evals/s", "cores": csweep.threads(),
+        n_used += step
+        n_cycles += 1
+        if time.perf_counter() - t0 >= target_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": (n_used * n_p + n_cycles * n_p) / dt, "unit": "model-evals/s", "cores": csweep.threads(),
             "kind": "port", "implementation": "plain C + OpenMP (oracle/csweep.c), two-pass weighted variance",
-            "sample": f"{n_used} of {ns} settings x all {n_p} particles + full update, {dt:.1f} s"}
+            "sample": f"{n_used} of {ns} settings (blocks of {step}) x all {n_p} particles + {n_cycles} full updates, {dt:.1f} s"}
 
 
 def published_workload(cycles=1500, warm=100):
@@ -255,6 +266,60 @@ def launch_ranks(n, argv):
     return 0
 
 
+def other_config(cfg, steps, warmup):
+    """One of the other single-GPU BASELINE configs through the same cycle loop, after (outside) the main
+    timed region: the driver's line then carries every config, not just the headline one.  The same
+    measures as the headline: steps of opt_setting() + pdf_update() incl. the resamples the data trigger,
+    K1 timed by HIP events inside those cycles."""
+    import torch
+    ns, n_p, model, _ = CONFIGS[cfg]
+    settings, prior, cons, true, sigma = make_workload(cfg)
+    obe = build_obe(cfg, None, settings, prior.copy(), cons)
+    obe.rng = np.random.default_rng(1234)
+    sim = np.random.default_rng(4321)
+    fn = obe.model_function
+    noise_rec = model == "lorentzian"
+    step_ms, res = [], []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        for c in range(warmup + steps):
+            if c == warmup:
+                torch.cuda.synchronize()
+                obe._mlib.call("obe_sweep_timing", 1, None, None)
+                t_all = time.perf_counter()
+            ts = time.perf_counter()
+            x = obe.opt_setting()
+            y = float(fn(x, true, cons)) + sigma * sim.standard_normal()
+            obe.pdf_update((x, y, sigma) if noise_rec else (x, y))
+            if c >= warmup:
+                step_ms.append(1e3 * (time.perf_counter() - ts))
+                res.append(bool(obe.just_resampled))
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_all
+    k1_ms, k1_n = ctypes.c_double(0.0), ctypes.c_int64(0)
+    obe._mlib.call("obe_sweep_timing", 0, ctypes.byref(k1_ms), ctypes.byref(k1_n))
+    full = obe.utility_method == "variance_full"
+    n_draws = n_p if full else obe.N_DRAWS
+    step_ms, res = np.array(step_ms), np.array(res)
+    out = {"workload": CONFIGS[cfg][3], "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
+           "value": steps * (ns * n_draws + n_p) / elapsed, "unit": "model-evals/s", "resamples": int(res.sum()),
+           "median_ms_plain_cycle": float(np.median(step_ms[~res])) if (~res).any() else None,
+           "median_ms_resample_cycle": float(np.median(step_ms[res])) if res.any() else None}
+    if full and k1_n.value:
+        k1 = k1_ms.value / k1_n.value
+        out["k1_ms"] = k1
+        out["roofline_frac"] = FLOP_PER_EVAL[model] * ns * n_p / (k1 * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS
+        shifted, safe = bool(obe.last_sweep["shifted"]), bool(obe.last_sweep.get("safe"))
+        slots = ISSUE_SLOTS_SAFE_FORM.get(model, ISSUE_SLOTS_PER_EVAL[model][1]) if safe \
+            else ISSUE_SLOTS_PER_EVAL[model][1 if shifted else 0]
+        out["valu_issue_frac"] = slots * ns * n_p / (k1 * 1e-3) / VALU_ISSUE_PEAK
+        out["variant"] = ("safe " if safe else "") + ("shifted" if shifted else "unshifted")
+    else:       # reference semantics: a one-workgroup sweep of N_DRAWS draws, latency-bound (no roofline to speak of)
+        out["k1_ms"] = None
+        out["roofline_frac"] = None
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -262,6 +327,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the c1 / c2 / c5 cycles that follow the timed region of the default (c3) run")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even with one rank (exercises the N > 1 code path)")
     args = ap.parse_args()
@@ -408,6 +475,10 @@ def main():
                 "launch_ms_back_to_back": k1_back_to_back_ms,
                 "variant": "shifted" if shifted else "unshifted", "form": "safe" if safe_form else "fast",
                 "kappa": obe.last_sweep["kappa"], "traffic": traffic,
+                "traffic_source": (None if traffic is None else
+                                   "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an "
+                                   "EARLIER run of this command (tools/profile_rocprof.sh), with the guide's gfx950 "
+                                   "corrections; read from that committed file, NOT measured in this run"),
                 "valu_issue": (lambda slots: {
                     "slots_per_eval": slots, "achieved": slots * n_local * n_p / k1_s, "peak": VALU_ISSUE_PEAK,
                     "unit": "FP64 lane-instructions/s", "frac": slots * n_local * n_p / k1_s / VALU_ISSUE_PEAK,
@@ -419,7 +490,7 @@ def main():
                                     "note": "compute-bound kernel: ~1e4 flop per compulsory byte"}}
 
     # ---- the HBM-bound update as pdf_update() issues it (K2 + the first moments of the posterior:
-    #      3 launches), events around the whole call ----
+    #      2 launches), events around the whole call ----
     timer = ctypes.c_void_p()
     lib.call("obe_timer_create", ctypes.byref(timer))
     wcopy = w.clone()
@@ -475,8 +546,8 @@ def main():
     # pass A: (n_read + 1) rows read, t written; pass B': t and all D rows read, w' written
     k2_bytes = 8 * (n_read + 1) * n_p + 8 * n_p + 8 * (d + 1) * n_p + 8 * n_p
     k2_s = float(np.median(round_us)) * 1e-6
-    roofline_update = {"kernel": "update_model_kernel + normalize_moments_kernel + fold_update_moments_kernel "
-                                 "(K2 + K3 pass 1: what pdf_update() launches)", "bound": "hbm",
+    roofline_update = {"kernel": "update_model_kernel + normalize_moments_kernel (whose last workgroup folds) "
+                                 "(K2 + K3 pass 1: the two launches of pdf_update())", "bound": "hbm",
                        "achieved": k2_bytes / k2_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": k2_bytes / k2_s / 1e9 / HBM_PEAK_GBS, "bytes": k2_bytes,
                        "bytes_note": "8(n_read+1)N + 8N (likelihood pass) + 8(D+1)N + 8N (normalisation + first moments)",
@@ -488,7 +559,7 @@ def main():
         roofline_update["large_cloud"] = {"n_particles": big[0], "bytes": b_bytes, "call_us": big[1],
                                           "achieved": b_bytes / (big[1] * 1e-6) / 1e9, "unit": "GB/s",
                                           "frac": b_bytes / (big[1] * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                          "note": "same three launches on the cloud tiled 16 x: bandwidth-bound "
+                                          "note": "the same launches on the cloud tiled 16 x: bandwidth-bound "
                                                   "instead of launch-bound"}
 
     out = {"metric": "model-evals/sec (settings x particles) per opt_setting+update cycle, fp64",
@@ -518,6 +589,17 @@ def main():
             out["published_workload"] = published_workload()
         except Exception as exc:
             out["published_workload"] = {"error": str(exc)[:200]}
+    if rank == 0 and world == 1 and cfg == "c3" and not args.no_other_configs:
+        # every other single-GPU config of BASELINE.json on the same line (outside the timed region above)
+        del obe
+        torch.cuda.empty_cache()
+        others = {}
+        for name, k, wu in (("c1", 400, 20), ("c2", 40, 5), ("c5", 12, 3)):
+            try:
+                others[name] = other_config(name, k, wu)
+            except Exception as exc:
+                others[name] = {"error": str(exc)[:200]}
+        out["other_configs"] = others
     if rank == 0:
         print(json.dumps(out))
     if use_dist:
