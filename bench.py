@@ -130,7 +130,7 @@ def cpu_baseline(cfg, settings, prior, cons, true, sigma, target_s=8.0):
     step = min(64, ns)
     n_blocks = ns // step
     n_used, t0 = 0, time.perf_counter()
-    for b in range(0, n_blocks, max(1, n_blocks // 16)):           # up to 16 blocks, evenly spaced over the grid
+    for b in range(0, n_blocks, max(1, n_blocks // 32)):           # up to 32 blocks, evenly spaced over the grid
         block = slice(b * step, (b + 1) * step)
         sub = (np.ascontiguousarray(settings[0][block]),)
         yvar = oracle.yvar_full_sweep(fn, oracle.flatten_settings(sub), prior, w, cons, chunk=4096)

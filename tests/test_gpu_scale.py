@@ -157,6 +157,85 @@ def test_update_and_resample_at_one_million_particles(obe):
         assert_array_equal(a2.particle_weights, b2.particle_weights)
 
 
+def test_c5_update_resample_and_constraint_at_full_size(obe):
+    """VERDICT r3 #4 / #5b: config c5 itself — 524 288 particles, 10 parameters, the noise-parameter class —
+    through three pdf_update()s, a forced resample and enforce_parameter_constraints(), against
+    OracleOptBayesExptNoiseParameter from the same seeds (obe_noiseparam.py:57-120,
+    particlepdf.py:260-310): resample indices and constrained particles exact, weights / mean /
+    covariance 1e-10 (16 settings: this test is about the cloud)."""
+    settings, prior, cons, true, sigma = bench.make_workload("c5")
+    sv = (np.ascontiguousarray(settings[0][::1024]),)
+    kw = dict(scale=False, noise_parameter_index=9)
+    a = obe.OptBayesExptNoiseParameter(obe.models.lorentzian(7), sv, prior.copy(), cons, **kw)
+    b = oracle.OracleOptBayesExptNoiseParameter(omodels.multi_lorentzian(7), sv, prior.copy(), cons, n_channels=1, **kw)
+    for o in (a, b):
+        o.rng = np.random.default_rng(515)
+        o.tuning_parameters["auto_resample"] = False
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        for x, y in (((3.05,), 1700.0), ((2.5,), 1900.0), ((3.6,), 1500.0)):
+            for o in (a, b):
+                o.pdf_update((x, y))
+        wa, wb = np.array(a.particle_weights), np.array(b.particle_weights)
+        assert_allclose(wa, wb, rtol=RTOL, atol=1e-13 * wb.max())
+        assert 0.0 < 1.0 / np.sum(wb * wb) / wb.size < 0.9      # (this workload's filter collapses fast: sigma ~ Exp(500))
+        assert_allclose(a.mean(), b.mean(), rtol=RTOL)
+        assert_allclose(a.covariance(), b.covariance(), rtol=RTOL, atol=1e-10 * np.abs(b.covariance()).max())
+        assert_allclose(a.yvar_noise_model(), b.yvar_noise_model(), rtol=1e-12)
+        # one more update, this time with the resample test on and a threshold that forces the resample,
+        # so that pdf_update() itself runs resample() + enforce_parameter_constraints()
+        for o in (a, b):
+            o.tuning_parameters["auto_resample"] = True
+            o.tuning_parameters["resample_threshold"] = 1.0
+            o.pdf_update(((3.1,), 1500.0))
+    assert a.just_resampled and b.just_resampled
+    assert_array_equal(a.last_resample_indices_device.cpu().numpy(), b.last_draw_indices)      # 524 288 exact indices
+    wa, wb = np.array(a.particle_weights), np.array(b.particle_weights)
+    assert_array_equal(wa == 0.0, wb == 0.0)                   # the same particles constrained (sigma <= 0 after the nudge)
+    n_zero = int(np.sum(wb == 0.0))
+    assert n_zero > 0 and a.last_constraint_count == n_zero
+    assert_allclose(wa, wb, rtol=RTOL)
+    pa, pb = np.array(a.particles), np.array(b.particles)
+    cov_scale = np.sqrt(np.max(np.linalg.eigvalsh(np.cov(prior))))
+    for i in range(10):
+        # (the SVD nudge carries an absolute LAPACK round-off of ~eps * sqrt(largest eigenvalue): tests/_replay.py)
+        assert_allclose(pa[i], pb[i], rtol=RTOL, atol=2048 * 2.3e-16 * cov_scale, err_msg=f"row {i}")
+    assert_allclose(a.mean(), b.mean(), rtol=RTOL)
+    assert_allclose(a.std(), b.std(), rtol=1e-8)
+    assert_allclose(a.yvar_noise_model(), b.yvar_noise_model(), rtol=1e-11)
+    assert a.rng.bit_generator.state == b.rng.bit_generator.state       # 5.8 M draws later, the same generator state
+
+
+def test_c1_literal_workload_forty_cycles(obe):
+    """The exact make_workload("c1") (201 settings x 5 000 particles, reference semantics: 30 weighted draws)
+    for 40 cycles against the oracle class from the same seeds: draws, chosen setting and resample decision
+    exact in every cycle, utility / weights / moments 1e-10."""
+    settings, prior, cons, true, sigma = bench.make_workload("c1")
+    a = bench.build_obe("c1", None, settings, prior.copy(), cons)
+    b = oracle.OracleOptBayesExpt(omodels.lorentzian, settings, prior.copy(), cons, scale=False,
+                                  default_noise_std=sigma, n_channels=1)
+    a.rng, b.rng = np.random.default_rng(1234), np.random.default_rng(1234)
+    sim = np.random.default_rng(4321)
+    resamples = 0
+    for cyc in range(40):
+        xa, xb = a.opt_setting(), b.opt_setting()
+        assert_array_equal(a.last_draw_indices, b.last_draw_indices, err_msg=f"draws, cycle {cyc}")
+        assert a.last_setting_index == b.last_setting_index and xa == xb, cyc
+        assert_allclose(a._utility_dev.cpu().numpy(), b.last_utility, rtol=RTOL)
+        y = float(omodels.lorentzian(xb, true, cons)) + sigma * sim.standard_normal()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            a.pdf_update((xa, y, sigma))
+            b.pdf_update((xb, y, sigma))
+        assert a.just_resampled == b.just_resampled, cyc
+        resamples += a.just_resampled
+        assert_allclose(a.particle_weights, b.particle_weights, rtol=RTOL, atol=1e-13 * np.max(b.particle_weights))
+        assert_allclose(a.mean(), b.mean(), rtol=RTOL)
+        assert_allclose(a.std(), b.std(), rtol=1e-8)
+    assert resamples >= 2
+    assert a.rng.bit_generator.state == b.rng.bit_generator.state
+
+
 def test_sharded_path_through_rccl_world_of_one(obe):
     """The sharded opt_setting code path with a real NCCL (= RCCL) process group of one rank:
     the device-side all-gather of the result record, the row gather and the barrier run on

@@ -1211,3 +1211,60 @@ def test_negative_probabilities_are_refused_like_numpy(obe, n):
         with pytest.raises(ValueError, match="contain NaN"):
             pdf.randdraw(7)
         assert pdf.rng.bit_generator.state == before
+
+
+def test_expression_model_is_compiled_on_this_box_or_refused_clearly(obe, tmp_path, monkeypatch):
+    """every plugin library the suite loads was prebuilt in the build container, so
+    `build.build_plugin` (hipcc for a generated model) had never run where it will be used.  A formula with
+    a constant nobody has compiled before, into a fresh plugin directory: where hipcc is present the kernels
+    are compiled here and now and must agree with NumPy (evaluation bit for bit, the full sweep and a Bayes
+    update at 1e-10); where it is not, the error must name the missing compiler, and a plain Python model
+    function under AUTO_TRANSLATE must fall back — with a warning — to host-callable mode and still work."""
+    import os
+    import time
+    import warnings as _w
+    from optbayesexpt_amd import build, models
+    monkeypatch.setattr(build, "PLUGIN_DIR", str(tmp_path))
+    salt = 1.0 + (time.time_ns() % 1000003) * 1e-9                # a literal no cached library was built for
+    formula = f"b + a / (((x - x0) / d)**2 + {salt!r})"
+    g = np.random.default_rng(31)
+    n = 3000
+    prior = np.array([g.uniform(2, 4, n), g.uniform(-2000, -400, n), g.normal(50000, 1000, n)])
+    sv = (np.linspace(1.5, 4.5, 300),)
+
+    def fn(sets, pars, cons):
+        x, = sets
+        x0, a, b = pars
+        d, = cons
+        return b + a / (((x - x0) / d) ** 2 + salt)
+
+    if os.path.exists(build.HIPCC):
+        t0 = time.time()
+        model = models.from_expression(formula, settings=("x",), parameters=("x0", "a", "b"), constants=("d",))
+        assert model.plugin_path.startswith(str(tmp_path)) and os.path.exists(model.plugin_path)
+        print(f"plugin compiled on this box in {time.time() - t0:.1f} s: {os.path.basename(model.plugin_path)}")
+        o = obe.OptBayesExpt(model, sv, prior.copy(), (0.1,), utility_method="variance_full", auto_resample=False,
+                             default_noise_std=500.0)
+        assert o._mlib is not o._lib
+        assert_array_equal(o.eval_over_all_parameters((3.1,))[0], fn((3.1,), prior, (0.1,)))
+        w = g.exponential(1.0, n)
+        w /= w.sum()
+        o.particle_weights = w
+        ref = oracle.yvar_full_sweep(fn, oracle.flatten_settings(sv), prior, w, (0.1,))
+        assert_allclose(o.yvar_from_parameter_draws(), ref, rtol=RTOL, atol=1e-13 * ref.max())
+        o.pdf_update(((3.1,), 49500.0, 500.0))
+        want = oracle.normalized_product(w, oracle.gauss_likelihood(fn((3.1,), prior, (0.1,)), 49500.0, 500.0))
+        assert_allclose(o.particle_weights, want, rtol=RTOL, atol=1e-13 * want.max())
+    else:
+        with pytest.raises(RuntimeError, match="hipcc"):
+            models.from_expression(formula, settings=("x",), parameters=("x0", "a", "b"), constants=("d",))
+        monkeypatch.setattr(models, "AUTO_TRANSLATE", True)
+        with _w.catch_warnings(record=True) as caught:
+            _w.simplefilter("always")
+            o = obe.OptBayesExpt(fn, sv, prior.copy(), (0.1,), default_noise_std=500.0)
+        assert o._device_model is None                       # host-callable mode
+        assert any("kept on the host" in str(c.message) for c in caught)
+        o.rng = np.random.default_rng(3)
+        x = o.opt_setting()
+        o.pdf_update((x, 49500.0, 500.0))
+        assert np.isfinite(o.mean()).all()
