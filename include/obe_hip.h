@@ -128,7 +128,13 @@ int obe_bayes_update_model(const obe_model* m,
  * obe_base.py:340-399 + mean()/std() of particlepdf.py:173-214, which every caller's cycle asks for
  * next, and the sweep's per-setting shift).  d_moments receives the K3 block without the covariance
  * (layout of obe_moments, bit-identical to calling it afterwards); h_out (nullable; sync) receives
- * [0] = sum t, [1] = sum w'^2, [2 .. 2 + 2 + 4 n_params) = that block.  n_dims = m->n_params. */
+ * [0] = sum t, [1] = sum w'^2, [2 .. 2 + 2 + 4 n_params) = that block.  n_dims = m->n_params.
+ * Two launches: the workgroup of the normalisation pass that finishes last folds everyone's partial sums
+ * (write-through partials, an arrival counter the library keeps per stream).  The weights and the moments
+ * are the bits of obe_bayes_update_model() + obe_moments(); h_out[1] is summed from this pass's own
+ * workgroup partials (one per CU) and can differ from obe_bayes_update_model()'s h_out[1] in the last
+ * few ulp — never in a resample decision over the experiments tested
+ * (tests/test_gpu_units.py::test_fused_and_unfused_update_take_the_same_resample_decisions). */
 int obe_bayes_update_model_moments(const obe_model* m,
                                    const double* d_particles, int64_t ld_p, int64_t n_particles,
                                    double* d_weights,
@@ -338,7 +344,17 @@ int obe_power_normalize(const double* d_u, int64_t n, double exponent, double* d
  * model's fast sweep form batches its divisions without a branch and poisons (NaN) a batch
  * whose denominators leave the range in which that is exact; a NaN variance comes back as
  * *h_kappa = NaN, and the caller repeats the sweep with OBE_SWEEP_SAFE (one IEEE
- * reciprocal per element, implies the shift).  Built-in models ignore OBE_SWEEP_SAFE. */
+ * reciprocal per element, implies the shift).  Of the built-in models the coil and the Lorentzian with 3
+ * or more peaks have such a pair of forms; the latter's safe form still shares one reciprocal among the
+ * 16 denominators of two particles x 8 settings of ONE peak and is exact for |x - x0| / d up to ~2e9
+ * (tested to 2.5e7, tests/test_gpu_units.py::test_multi_peak_lorentzian_sweep_forms); the others ignore
+ * OBE_SWEEP_SAFE.
+ *
+ * Completion of the "(sync)" entry points: the HOST results of a call are complete when it returns — they
+ * are written by the call's last kernel into page-locked memory and waited for there — while device outputs
+ * (weights, moments, utility ...) are ordered on the caller's stream like any kernel's: consume them on the
+ * same stream, or synchronise it first.  obe_mask_nonpositive() in particular returns as soon as the count
+ * is known, while the renormalisation it implies may still be running. */
 #define OBE_SWEEP_SHIFTED 1
 #define OBE_SWEEP_SAFE 2
 /* Settings one lane of the sweep kernel owns for a grid of n_settings (1, 2, 4 or 8): the number

@@ -42,7 +42,11 @@ class DeviceModel:
         #: True / False: a cheap host-side *prediction* of whether the fast sweep form stays inside
         #: its exact range on this grid and cloud.  False makes the first sweep start with the safe
         #: form instead of discovering it by a poisoned fast attempt; the kernel's own range check
-        #: stays the guarantee either way.
+        #: stays the guarantee either way.  (Range of the safe forms themselves: generated models and the
+        #: coil invert element by element — any finite denominator; the multi-peak Lorentzian's safe form
+        #: inverts the 16 denominators of two particles x 8 settings of one peak together and is exact for
+        #: |x - x0| / d up to ~2e9 — a peak 10^9 times narrower than the settings span — beyond which the
+        #: utility of the affected settings is NaN, where the reference returns ~0.)
         self.range_hint = range_hint
         #: path of the per-model plugin library (expression models), else None
         self.plugin_path = plugin_path

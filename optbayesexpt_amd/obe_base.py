@@ -53,12 +53,14 @@ _OVERRIDDEN = {}
 def _overridden(obj, name, *owners):
     """True if ``obj``'s class replaces method ``name`` defined by one of ``owners`` (answered once
     per class: the hooks are looked up several times in every cycle)."""
+    if name in obj.__dict__:            # replaced on the instance (obe.cost_estimate = f)
+        return True
     key = (type(obj), name, owners)
+    impl = getattr(type(obj), name)
     hit = _OVERRIDDEN.get(key)
-    if hit is None:
-        impl = getattr(type(obj), name)
-        hit = _OVERRIDDEN[key] = all(impl is not getattr(o, name) for o in owners)
-    return hit
+    if hit is None or hit[0] is not impl:       # (a method patched onto the class later is seen too)
+        hit = _OVERRIDDEN[key] = (impl, all(impl is not getattr(o, name) for o in owners))
+    return hit[1]
 
 
 class _LazyState:
@@ -368,7 +370,8 @@ class OptBayesExpt(ParticlePDF):
         return n, yy, s
 
     def _likelihood_inputs(self, measurement_record):
-        """(n_lik_channels, y_meas[4], sigma[4] or None, noise_rows[4] or None)."""
+        """(n_lik_channels, y_meas[4], sigma[4] or None, noise_rows[4] or None).  The arrays are this object's
+        record buffers (filled in place, addresses made once): valid until the next call — copy them to keep."""
         _, y_meas, sigma = measurement_record
         n, yy, s = self._record_channels(y_meas, sigma)
         return n, yy, s, None
@@ -469,7 +472,7 @@ class OptBayesExpt(ParticlePDF):
         """(tensor, ld): noise variance on the device — one value per channel (ld = 0)
         or, for an overriding yvar_noise_model() that returns per-setting values, a
         (C, n_local) array (ld = n_local)."""
-        if type(self).yvar_noise_model is OptBayesExpt.yvar_noise_model and self._noise_cache is not None:
+        if not _overridden(self, "yvar_noise_model", OptBayesExpt) and self._noise_cache is not None:
             dns = self.default_noise_std
             if isinstance(dns, np.ndarray) and dns.tobytes() == self._noise_src:
                 return self._noise_dev, 0        # the class's own model of an unchanged default_noise_std
@@ -490,7 +493,7 @@ class OptBayesExpt(ParticlePDF):
         return t, t.shape[1]
 
     def _cost_device(self):
-        if type(self).cost_estimate is OptBayesExpt.cost_estimate:
+        if not _overridden(self, "cost_estimate", OptBayesExpt):
             return None, 1.0
         cost = self.cost_estimate()
         if np.ndim(cost) == 0:

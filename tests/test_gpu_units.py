@@ -1268,3 +1268,100 @@ def test_expression_model_is_compiled_on_this_box_or_refused_clearly(obe, tmp_pa
         x = o.opt_setting()
         o.pdf_update((x, 49500.0, 500.0))
         assert np.isfinite(o.mean()).all()
+
+
+def test_instance_level_hooks_are_honoured(obe):
+    """a hook replaced on the INSTANCE (obe.cost_estimate = f), or patched onto the class after the
+    first cycle, must be called like one overridden in a subclass (the per-class cache of hook look-ups and
+    the cost / noise shortcuts used to miss both)."""
+    g = np.random.default_rng(8)
+    n = 2000
+    prior = np.array([g.uniform(2, 4, n), g.uniform(-2000, -400, n), g.normal(50000, 1000, n)])
+    sv = (np.linspace(1.5, 4.5, 90),)
+
+    class Mine(obe.OptBayesExpt):
+        pass
+
+    o = Mine(obe.models.lorentzian(), sv, prior.copy(), (0.1,), utility_method="variance_full", auto_resample=False,
+             default_noise_std=500.0)
+    base = np.array(o.utility())
+    o.cost_estimate = lambda: 2.0                                   # on the instance
+    assert_allclose(o.utility(), base / 2.0, rtol=1e-15)
+    del o.cost_estimate
+    assert_allclose(o.utility(), base, rtol=1e-15)
+    o.yvar_noise_model = lambda: np.full((1, 1), 4.0 * 500.0 ** 2)   # on the instance
+    assert_allclose(o.utility(), base / 4.0, rtol=1e-15)
+    del o.yvar_noise_model
+    Mine.cost_estimate = lambda self: np.linspace(1.0, 3.0, 90)      # on the class, after it has been looked up
+    try:
+        assert_allclose(o.utility(), base / np.linspace(1.0, 3.0, 90), rtol=1e-15)
+    finally:
+        del Mine.cost_estimate
+    assert_allclose(o.utility(), base, rtol=1e-15)
+
+
+def test_fused_and_unfused_update_take_the_same_resample_decisions(obe):
+    """pdf_update()'s fused route (update + first moments, sum w'^2 folded from 256 workgroup
+    partials) and the plain route (768 partials) deliver sum w'^2 with different summation orders — equal to
+    a few ulp, which include/obe_hip.h states.  Over a whole experiment that must never flip a resample
+    decision: two objects, one on each route, through 150 cycles of the find-peak loop from the same seeds."""
+    g = np.random.default_rng(77)
+    n = 20000
+    prior = np.array([g.uniform(2, 4, n), g.uniform(-2000, -400, n), g.normal(50000, 1000, n)])
+    sv = (np.linspace(1.5, 4.5, 201),)
+    objs = []
+    for fused in (True, False):
+        o = obe.OptBayesExpt(obe.models.lorentzian(), sv, prior.copy(), (0.1,), scale=False, default_noise_std=500.0)
+        o.tuning_parameters["fused_moments"] = fused
+        o.rng = np.random.default_rng(5)
+        objs.append(o)
+    sim = np.random.default_rng(6)
+    resamples, worst = 0, 0.0
+    for cyc in range(150):
+        xs = [o.opt_setting() for o in objs]
+        assert xs[0] == xs[1], cyc
+        y = float(omodels.lorentzian(xs[0], (3.0, -1000.0, 50000.0), (0.1,))) + 500.0 * sim.standard_normal()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            for o in objs:
+                o.pdf_update((xs[0], y, 500.0))
+        assert objs[0].just_resampled == objs[1].just_resampled, cyc
+        resamples += objs[0].just_resampled
+        worst = max(worst, abs(objs[0].last_n_eff / objs[1].last_n_eff - 1.0))
+        assert_array_equal(objs[0].particle_weights, objs[1].particle_weights)      # the weights are the same bits
+    assert resamples >= 5 and worst < 1e-14
+
+
+def test_shifted_sweep_accuracy_on_a_converged_posterior(obe):
+    """the batched reciprocal of the sweep carries one Newton step (relative error <= 2e-15 on
+    every inverse).  Late in an experiment the posterior is narrow and (mean y)^2 / var reaches 1e5-1e7: the
+    shifted one-pass variance must still agree with the oracle's two-pass weighted variance at 1e-10 — single
+    Lorentzian and the 7-peak model (combined-fraction form)."""
+    g = np.random.default_rng(2)
+    n = 40000
+    sv = (np.linspace(1.5, 4.5, 4100),)
+    w = g.exponential(1.0, n)
+    w /= w.sum()
+    for scale in (1e-2, 1e-3, 1e-4):
+        narrow = np.array([g.normal(3.0, 0.02 * scale * 10, n), g.normal(-1000.0, 30.0 * scale * 10, n),
+                           g.normal(50000.0, 50.0 * scale * 10, n)])
+        o = obe.OptBayesExpt(obe.models.lorentzian(), sv, narrow.copy(), (0.1,), utility_method="variance_full",
+                             auto_resample=False, default_noise_std=500.0)
+        o.particle_weights = w
+        got = o.yvar_from_parameter_draws()
+        ref = oracle.yvar_full_sweep(omodels.lorentzian, oracle.flatten_settings(sv), narrow, w, (0.1,))
+        assert o.last_sweep["shifted"] and o.last_sweep["kappa"] > 1e4, o.last_sweep
+        assert_allclose(got, ref, rtol=RTOL, atol=1e-13 * ref.max(), err_msg=f"scale {scale}, kappa {o.last_sweep['kappa']:.3g}")
+    centres = np.array([2.2, 2.5, 2.8, 3.1, 3.4, 3.7, 3.9])
+    n7 = 12000
+    w7 = g.exponential(1.0, n7)
+    w7 /= w7.sum()
+    narrow7 = np.vstack([centres[:, None] + g.normal(0, 2e-4, (7, n7)), g.normal(1000.0, 0.5, (1, n7)),
+                         g.normal(500.0, 0.5, (1, n7))])
+    o = obe.OptBayesExpt(obe.models.lorentzian(7), sv, narrow7.copy(), (0.1,), utility_method="variance_full",
+                         auto_resample=False, default_noise_std=500.0)
+    o.particle_weights = w7
+    got = o.yvar_from_parameter_draws()
+    ref = oracle.yvar_full_sweep(omodels.multi_lorentzian(7), oracle.flatten_settings(sv), narrow7, w7, (0.1,))
+    assert o.last_sweep["kappa"] > 1e4
+    assert_allclose(got, ref, rtol=RTOL, atol=1e-13 * ref.max(), err_msg=f"7 peaks, kappa {o.last_sweep['kappa']:.3g}")
