@@ -87,14 +87,20 @@ int obe_defer_host_sync(int32_t on);
  * only a few values — the index of obe_draw_indices for good_setting() — may be given as this
  * address: the kernel then delivers the result to the host itself, with no copy back. */
 int obe_host_device_pointer(const void* h_pinned, void** d_out);
-/* Waiting for such a result by watching it: obe_host_word_arm stores a bit pattern no result has
- * (0x7ff8c0dec0dec0de: a NaN payload / an impossible index) into one 8-byte page-locked word, the call
- * whose last kernel writes that word is enqueued, and obe_host_word_wait spins until the word changes
- * (bounded: after 400 us it synchronises `stream` instead, which also reports a kernel that failed).
- * 5.9 us per round trip of a short kernel instead of 11.1 us through hipStreamSynchronize
- * (tools/microbench_sync.hip).  The entry points that deliver host results into page-locked memory
- * (obe_sweep_utility, obe_utility_argmax, obe_argmax, obe_bayes_update_*, obe_weight_sums) wait this
- * way themselves. */
+/* Waiting for such results by watching them: obe_host_words_arm stores a bit pattern no result has
+ * (0x7ff8c0dec0dec0de: a NaN payload / an impossible index) into EVERY 8-byte word of a page-locked result
+ * block, the call whose kernels write those words is enqueued, and obe_host_words_wait spins until none of
+ * the words carries the pattern any more (bounded: after 400 us it synchronises `stream` instead, which also
+ * reports a kernel that failed).  An 8-byte store arrives whole, so no ordering between the kernel's stores
+ * is relied upon — watching one "last" word behind a system-scope fence was not safe for blocks that span
+ * several 128-byte lines ("Waiting for a result by watching it").  5.9 us per round trip
+ * of a short kernel instead of 11.1 us through hipStreamSynchronize (tools/microbench_sync.hip).  The entry
+ * points that deliver host results into page-locked memory (obe_sweep_utility, obe_utility_argmax,
+ * obe_argmax, obe_bayes_update_*, obe_weight_sums) wait this way themselves; obe_resample_begin and
+ * obe_mask_nonpositive_moments arm their result words and leave the waiting to the caller.
+ * obe_host_word_arm / _wait: the same for a single word. */
+int obe_host_words_arm(void* h_pinned_words, int64_t n_words);
+int obe_host_words_wait(const void* h_pinned_words, int64_t n_words, void* stream);
 int obe_host_word_arm(void* h_pinned_word);
 int obe_host_word_wait(const void* h_pinned_word, void* stream);
 /* Name, CU count and memory of the current device; returns 0 if a gfx950 device is current. */
@@ -270,19 +276,19 @@ int obe_resample_particles(const double* d_old, int64_t ld_old, int32_t n_dims, 
  * 4096 raw values into d_raw), the weight CDF into d_cdf (skipped when cdf_is_fresh), the N uniforms, the
  * search of the N draws (d_idx), the covariance of the PRE-resample cloud (have_first_moments: d_moments
  * already holds mean / std of these weights) and the N x D ziggurat normals (d_normals; d_zig_ws of
- * obe_ziggurat_workspace_bytes(n_raw - N) bytes).  Nothing is waited for.  All three host buffers must be
- * page-locked: h_f64[0] = sum(w) for numpy's validation of p (1.0 when the CDF was fresh), h_f64[1..] =
- * the K3 block incl. the covariance; h_flags[0] is armed here and stored last by the covariance kernel —
- * obe_host_word_wait(h_flags) returns when the block is there; h_i64[0..1] = {raw values the normals
- * consumed, normals found}, h_i64[1] armed and stored last — obe_host_word_wait(h_i64 + 1), then
- * obe_ziggurat_check().  Same kernels, same numbers as the calls one by one. */
+ * obe_ziggurat_workspace_bytes(n_raw - N) bytes).  Nothing is waited for.  Both host buffers must be
+ * page-locked; every result word is armed here and the caller waits with obe_host_words_wait():
+ *   h_f64[0]     sum(w) for numpy's validation of p (1.0, stored at once, when the CDF was fresh);
+ *   h_f64[1..]   the K3 block: the covariance and, unless have_first_moments, the first moments — wait for
+ *                the words h_f64 + 1 + lo .. h_f64 + 1 + obe_moments_len(D), lo = have_first ? 2 + 4 D : 0;
+ *   h_i64[0..1]  {raw values the normals consumed, normals found}: wait for both, then obe_ziggurat_check().
+ * Same kernels, same numbers as the calls one by one. */
 int obe_resample_begin(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t n_particles,
                        const double* d_weights, const uint64_t* h_pcg_state4, int32_t strict_cdf,
                        int32_t cdf_is_fresh, int32_t have_first_moments, uint64_t* d_raw, int64_t n_raw,
                        double* d_cdf, double* d_uniforms, int64_t* d_idx, const void* d_zig_tables,
                        double* d_normals, void* d_zig_ws, int64_t zig_ws_bytes, double* d_moments,
-                       double* h_f64, uint64_t* h_flags, int64_t* h_i64, void* d_ws, int64_t ws_bytes,
-                       void* stream);
+                       double* h_f64, int64_t* h_i64, void* d_ws, int64_t ws_bytes, void* stream);
 
 /* ---- K6: OptBayesExptNoiseParameter extras ----
  * enforce_parameter_constraints (obe_noiseparam.py:57-79): zero the weight of every
@@ -295,9 +301,9 @@ int obe_mask_nonpositive(const double* d_particles, int64_t ld_p, int64_t n_part
 /* The same mask AND the first moments of the constrained cloud (what obe_moments(want_cov = 0) would
  * compute next: every cycle needs them for the sweep's shift and the noise-parameter variance), bit for
  * bit, in two launches without a host round trip in between (obe_noiseparam.py:57-79 + particlepdf.py:
- * 173-214).  Does not wait: with page-locked h_changed / h_moments (either may be NULL) the count is armed
- * here and stored last by the second kernel — obe_host_word_wait(h_changed) — and h_moments receives the
- * K3 block's 2 + 4 n_dims first-moment values.  Pageable host buffers: the two calls above, synchronously. */
+ * 173-214).  Does not wait: page-locked h_changed (1 word) and h_moments (the K3 block's 2 + 4 n_dims
+ * first-moment values; either may be NULL) are armed here and written by the second kernel — the caller
+ * waits with obe_host_words_wait() on each.  Pageable host buffers: the two calls above, synchronously. */
 int obe_mask_nonpositive_moments(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t n_particles,
                                  const int32_t* h_rows, int32_t n_rows, double* d_weights, double* d_moments,
                                  double* h_moments, int64_t* h_changed, void* d_ws, int64_t ws_bytes,

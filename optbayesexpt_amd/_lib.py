@@ -81,7 +81,7 @@ _SIGNATURES = {
     "obe_mask_nonpositive_moments": (c_int, [_P, c_int64, c_int32, c_int64, _P, c_int32, _P, _P, _P, _P, _P, c_int64,
                                              _P]),
     "obe_resample_begin": (c_int, [_P, c_int64, c_int32, c_int64, _P, _P, c_int32, c_int32, c_int32, _P, c_int64,
-                                   _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, c_int64, _P]),
+                                   _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, c_int64, _P]),
     "obe_noise_var_from_moments": (c_int, [_P, c_int32, _P, c_int32, _P, _P]),
     "obe_cumsum": (c_int, [_P, c_int64, c_int32, _P, _P, c_int64, _P]),
     "obe_interval_utility": (c_int, [_P, c_int64, _P, c_int64, _P, c_double, _P, _P]),
@@ -109,6 +109,8 @@ _SIGNATURES = {
     "obe_timer_destroy": (c_int, [_P]),
     "obe_sweep_settings_per_lane": (c_int, [c_int64]),
     "obe_host_device_pointer": (c_int, [_P, ctypes.POINTER(c_void_p)]),
+    "obe_host_words_arm": (c_int, [_P, c_int64]),
+    "obe_host_words_wait": (c_int, [_P, c_int64, _P]),
     "obe_host_word_arm": (c_int, [_P]),
     "obe_host_word_wait": (c_int, [_P, _P]),
     "obe_sweep_timing": (c_int, [c_int32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64)]),

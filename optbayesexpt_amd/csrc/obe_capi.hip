@@ -12,12 +12,14 @@
 
 namespace obe {
 
-int wait_host_word(const void* h_word, hipStream_t st) {
-    const volatile uint64_t* p = static_cast<const volatile uint64_t*>(h_word);
+int wait_host_words(const void* h_words, int64_t n, hipStream_t st) {
+    const volatile uint64_t* p = static_cast<const volatile uint64_t*>(h_words);
     const auto t0 = std::chrono::steady_clock::now();
+    int64_t next = n - 1;            // words are checked from the last one down; `next` is the highest still armed
     for (;;) {
         for (int i = 0; i < 64; ++i) {
-            if (*p != kHostSentinel) {
+            while (next >= 0 && p[next] != kHostSentinel) --next;
+            if (next < 0) {
                 std::atomic_thread_fence(std::memory_order_acquire);
                 return 0;
             }
@@ -30,6 +32,8 @@ int wait_host_word(const void* h_word, hipStream_t st) {
     OBE_HIP_TRY(hipStreamSynchronize(st));       // long kernel, or one that never delivered: the stream knows
     return 0;
 }
+
+int wait_host_word(const void* h_word, hipStream_t st) { return wait_host_words(h_word, 1, st); }
 
 // Arrival counters for "the last workgroup to finish folds the partials" (obe_moments.h: arrive_last):
 // one zeroed 128-byte slot of device memory per (device, stream), allocated in one small block per device
@@ -147,6 +151,17 @@ int obe_host_word_arm(void* h_pinned_word) {
 int obe_host_word_wait(const void* h_pinned_word, void* stream) {
     if (!h_pinned_word) return bad_arg("obe_host_word_wait: null pointer");
     return wait_host_word(h_pinned_word, as_stream(stream));
+}
+
+int obe_host_words_arm(void* h_pinned_words, int64_t n) {
+    if (!h_pinned_words || n < 1) return bad_arg("obe_host_words_arm: null pointer / empty block");
+    arm_host_words(h_pinned_words, n);
+    return 0;
+}
+
+int obe_host_words_wait(const void* h_pinned_words, int64_t n, void* stream) {
+    if (!h_pinned_words || n < 1) return bad_arg("obe_host_words_wait: null pointer / empty block");
+    return wait_host_words(h_pinned_words, n, as_stream(stream));
 }
 
 int obe_host_device_pointer(const void* h_pinned, void** d_out) {

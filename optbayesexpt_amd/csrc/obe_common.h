@@ -64,8 +64,27 @@ constexpr uint64_t kHostSentinel = 0x7ff8c0dec0dec0deULL;
 constexpr double kHostWaitSpinUs = 400.0;        // (longer kernels: the stream's own wait; its 5 us no longer matter)
 inline void arm_host_word(void* h_word) { *reinterpret_cast<volatile uint64_t*>(h_word) = kHostSentinel; }
 int wait_host_word(const void* h_word, hipStream_t st);      // obe_capi.hip
+// Round 4: results of more than one word are waited for WORD BY WORD — every word of the block is armed and
+// the host spins until none carries the pattern any more.  An 8-byte store arrives whole, so that needs no
+// ordering between the stores at all.  The earlier form (arm one word, store it last behind a system-scope
+// fence) was not safe for blocks that span several 128-byte lines: about once in 3000 resamples the host saw
+// the watched word while the covariance entries of ANOTHER line still held the previous resample's values
+// (per-thread fences, an explicit s_waitcnt after the fence and delivery by a single wave did not close it;
+// found by tools/fuzz_parity.py's sweeper recipes, pinned down with tools/diag_host_delivery.py).
+inline void arm_host_words(void* h_words, int64_t n) {
+    volatile uint64_t* p = reinterpret_cast<volatile uint64_t*>(h_words);
+    for (int64_t i = 0; i < n; ++i) p[i] = kHostSentinel;
+}
+int wait_host_words(const void* h_words, int64_t n, hipStream_t st);      // obe_capi.hip
 // device side: everything stored to the host before this call is visible there before what follows
-__device__ __forceinline__ void host_results_before_flag() { __threadfence_system(); }
+// (the explicit wait restates the one that belongs behind the fence's L2 write-back: ROCm 7.2's compiler drops
+// it when its scoreboard says this wave has nothing outstanding, and the flag store that follows can then
+// overtake the write-back of the results — cdna_hip_programming.md, Guideline 16 pitfall 12; seen here as a
+// host copy of the covariance with entries of the previous resample, about once in 3000 resamples)
+__device__ __forceinline__ void host_results_before_flag() {
+    __threadfence_system();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 
 // ---- "the last workgroup to arrive folds": arrival counter + write-through partials ----
 // Zeroed device words owned by the library, one slot per (device, stream) (obe_capi.hip); nullptr: none.

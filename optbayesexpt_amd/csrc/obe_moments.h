@@ -145,25 +145,13 @@ __device__ __forceinline__ void fold_values_block(const double* partials, int nb
     __syncthreads();
 }
 
-// Where a folding workgroup delivers: the K3 block on the device, the device view of the caller's
-// page-locked copy (or NULL) and, optionally, one more page-locked word that is stored LAST, behind a
-// system-scope fence (the host watches it instead of synchronising the stream: obe_common.h).
+// Where a folding workgroup delivers: the K3 block on the device and the device view of the caller's
+// page-locked copy (or NULL).  A caller that does not synchronise the stream arms the words it expects and
+// waits for each of them (obe_common.h: arm_host_words / wait_host_words).
 struct MomentsOut {
     double* out;
     double* host;
-    uint64_t* host_flag;
 };
-
-// every storing wave has drained its stores to the host, then one thread raises the flag
-__device__ __forceinline__ void raise_host_flag(uint64_t* host_flag) {
-    if (!host_flag) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        host_results_before_flag();
-        *host_flag = 1;
-    }
-}
 
 // cov = S * (1 / (W - W2/W))  (np.cov scales by the reciprocal); raw = the folded upper triangle
 __device__ __forceinline__ void derive_covariance(const double* raw, int d, double* __restrict__ out,
@@ -218,11 +206,11 @@ __device__ __forceinline__ void derive_first_moments(const double* raw, int d, d
     }
 }
 
-// obe_moments() with an optional page-locked word that the call's last kernel raises (set to 1) behind its
-// host stores; *host_written tells whether h_out was page-locked, i.e. written by the kernels themselves
+// obe_moments() without the final synchronisation (the caller arms and watches the host words it expects,
+// or synchronises); *host_written tells whether h_out was page-locked, i.e. written by the kernels themselves
 int moments_call(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t n_particles, const double* d_weights,
-                 int32_t want_cov, double* d_out, double* h_out, uint64_t* h_flag, void* d_ws, int64_t ws_bytes,
-                 hipStream_t st, bool* host_written);
+                 int32_t want_cov, double* d_out, double* h_out, void* d_ws, int64_t ws_bytes, hipStream_t st,
+                 bool* host_written);
 
 // Grid of the moment passes (and of the update's normalisation pass that shares them): one workgroup per CU
 // up to 2 M particles; beyond that a wave per SIMD with only D + 1 loads in flight no longer fills HBM

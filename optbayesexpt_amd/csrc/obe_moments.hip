@@ -98,7 +98,6 @@ __global__ __launch_bounds__(kFoldThreads) void fold_derive_pass1(const double* 
     __shared__ double raw[kMaxMomentValues];
     fold_values_block(partials, nb, 2 + 2 * d, raw);
     derive_first_moments(raw, d, mo.out, mo.host);
-    raise_host_flag(mo.host_flag);
 }
 
 __global__ __launch_bounds__(kFoldThreads) void fold_derive_pass2(const double* __restrict__ partials, int nb, int d,
@@ -106,19 +105,16 @@ __global__ __launch_bounds__(kFoldThreads) void fold_derive_pass2(const double* 
     __shared__ double raw[kMaxMomentValues];
     fold_values_block(partials, nb, d * (d + 1) / 2, raw);
     derive_covariance(raw, d, mo.out, mo.host);
-    raise_host_flag(mo.host_flag);
 }
 
 template <int D>
 static int launch_moments(const double* x, int64_t ld, int64_t n, const double* w, int want_cov, double* partials,
                           const MomentsOut& mo, hipStream_t st) {
     const int nb = moment_blocks(n, D);
-    MomentsOut first = mo;
-    if (want_cov) first.host_flag = nullptr;            // (the flag belongs to the last launch of the call)
     if (want_cov != 2) {            // (2: `out` already holds the first moments of these weights)
         moments_pass1<D><<<nb, kBlock, 0, st>>>(x, ld, n, w, partials);
         OBE_CHECK_LAUNCH("moments_pass1");
-        fold_derive_pass1<<<1, kFoldThreads, 0, st>>>(partials, nb, D, first);
+        fold_derive_pass1<<<1, kFoldThreads, 0, st>>>(partials, nb, D, mo);
         OBE_CHECK_LAUNCH("fold_derive_pass1");
     }
     if (want_cov) {
@@ -130,10 +126,10 @@ static int launch_moments(const double* x, int64_t ld, int64_t n, const double* 
     return 0;
 }
 
-// obe_moments with an optional page-locked flag word that the call's last kernel raises (obe_resample_begin)
+// obe_moments without the final synchronisation (obe_resample_begin arms and watches the host words)
 int moments_call(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t n_particles, const double* d_weights,
-                 int32_t want_cov, double* d_out, double* h_out, uint64_t* h_flag, void* d_ws, int64_t ws_bytes,
-                 hipStream_t st, bool* host_written) {
+                 int32_t want_cov, double* d_out, double* h_out, void* d_ws, int64_t ws_bytes, hipStream_t st,
+                 bool* host_written) {
     if (!d_particles || !d_weights || !d_out || n_particles <= 0) return bad_arg("obe_moments: bad pointer/size");
     if (n_dims < 1 || n_dims > OBE_MAX_DIMS) return bad_arg("obe_moments: n_dims must be 1..16");
     const int64_t nv_max = std::max<int64_t>(2 + 2 * n_dims, (int64_t)n_dims * (n_dims + 1) / 2);
@@ -141,8 +137,7 @@ int moments_call(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_
     if (!d_ws || ws_bytes < need) return bad_arg("obe_moments: workspace too small");
     double* partials = static_cast<double*>(d_ws);
     double* hv = static_cast<double*>(device_view_of_host(h_out));     // page-locked h_out: the kernels write it
-    uint64_t* hf = hv ? static_cast<uint64_t*>(device_view_of_host(h_flag)) : nullptr;
-    const MomentsOut mo{d_out, hv, hf};
+    const MomentsOut mo{d_out, hv};
     if (host_written) *host_written = hv != nullptr;
     int rc = -1;
 #define OBE_MOM_CASE(DD) \
@@ -169,8 +164,8 @@ int obe_moments(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t
                 int64_t ws_bytes, void* stream) {
     hipStream_t st = as_stream(stream);
     bool host_written = false;
-    if (int rc = moments_call(d_particles, ld_p, n_dims, n_particles, d_weights, want_cov, d_out, h_out, nullptr, d_ws,
-                              ws_bytes, st, &host_written))
+    if (int rc = moments_call(d_particles, ld_p, n_dims, n_particles, d_weights, want_cov, d_out, h_out, d_ws, ws_bytes,
+                              st, &host_written))
         return rc;
     if (h_out) {
         const int64_t len = want_cov ? obe_moments_len(n_dims) : 2 + 4 * (int64_t)n_dims;

@@ -633,27 +633,29 @@ int obe_resample_particles(const double* d_old, int64_t ld_old, int32_t n_dims, 
 // The device side of ParticlePDF.resample() up to the point where the host must factorise the covariance
 // (particlepdf.py:260-301), enqueued by ONE call: the caller's PCG64 stream continued on the device (raw
 // values, N uniforms), the weight CDF (unless the caller's is fresh), the N-draw search, the covariance of
-// the pre-resample cloud and the N x D ziggurat normals.  Nothing is waited for: h_f64[0] receives sum(w)
-// for numpy's validation of p (1.0 is stored when the CDF was fresh), h_f64[1..] the K3 block incl. the
-// covariance, h_flags[0] is raised (set to 1) when that block is complete, h_i64[0..1] = {raw values the
-// normals consumed, normals found} with h_i64[1] stored last (armed here with a pattern no count has) —
-// all three page-locked; the caller watches h_flags[0], factorises, calls obe_resample_particles(), then
-// watches h_i64[1] for the generator bookkeeping (obe_host_word_wait).  Python issued these ~12 launches one
-// library call at a time (5-15 us of interpreter between two launches: the GPU idled for most of a
-// resample cycle at 262 144 particles).
+// the pre-resample cloud and the N x D ziggurat normals.  Nothing is waited for.  The host results land in
+// page-locked memory, every word of which is ARMED here and watched by the caller
+// (obe_host_words_wait: returns when none of the words carries the armed pattern any more):
+//   h_f64[0]      sum(w) for numpy's validation of p   (1.0 is stored at once when the CDF was fresh)
+//   h_f64[1 ..]   the K3 block; the kernels deliver the covariance (and, unless have_first_moments, the
+//                 first moments): wait for h_f64 + 1 + lo .. h_f64 + 1 + obe_moments_len(D), lo = 2 + 4 D or 0
+//   h_i64[0..1]   {raw values the normals consumed, normals found}
+// The caller factorises, calls obe_resample_particles(), then waits for h_i64 and does its generator
+// bookkeeping (obe_ziggurat_check).  Python issued these ~12 launches one library call at a time (5-15 us of
+// interpreter between two launches: the GPU idled for most of a resample cycle at 262 144 particles).
 int obe_resample_begin(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t n_particles,
                        const double* d_weights, const uint64_t* h_pcg_state4, int32_t strict_cdf,
                        int32_t cdf_is_fresh, int32_t have_first_moments, uint64_t* d_raw, int64_t n_raw,
                        double* d_cdf, double* d_uniforms, int64_t* d_idx, const void* d_zig_tables,
                        double* d_normals, void* d_zig_ws, int64_t zig_ws_bytes, double* d_moments, double* h_f64,
-                       uint64_t* h_flags, int64_t* h_i64, void* d_ws, int64_t ws_bytes, void* stream) {
+                       int64_t* h_i64, void* d_ws, int64_t ws_bytes, void* stream) {
     if (!d_particles || !d_weights || !h_pcg_state4 || !d_raw || !d_cdf || !d_uniforms || !d_idx || !d_zig_tables ||
-        !d_normals || !d_zig_ws || !d_moments || !h_f64 || !h_flags || !h_i64 || n_particles <= 0)
+        !d_normals || !d_zig_ws || !d_moments || !h_f64 || !h_i64 || n_particles <= 0)
         return bad_arg("obe_resample_begin: bad pointer/size");
     if (n_dims < 1 || n_dims > OBE_MAX_DIMS) return bad_arg("obe_resample_begin: n_dims must be 1..16");
     const int64_t n = n_particles, n_normal = n * n_dims;
     if (n_raw < n + n_normal + 4096) return bad_arg("obe_resample_begin: raw buffer shorter than the draws");
-    if (!device_view_of_host(h_f64) || !device_view_of_host(h_flags) || !device_view_of_host(h_i64))
+    if (!device_view_of_host(h_f64) || !device_view_of_host(h_i64))
         return bad_arg("obe_resample_begin: the host result buffers must be page-locked");
     hipStream_t st = as_stream(stream);
     const int prev = obe_defer_host_sync(1);
@@ -661,16 +663,18 @@ int obe_resample_begin(const double* d_particles, int64_t ld_p, int32_t n_dims, 
     do {
         if ((rc = obe_pcg64_raw(h_pcg_state4, n_raw, d_raw, stream))) break;
         if (!cdf_is_fresh) {
+            arm_host_word(h_f64);
             if ((rc = obe_weight_cdf(d_weights, n, strict_cdf, d_cdf, h_f64, d_ws, ws_bytes, stream))) break;
         } else {
             h_f64[0] = 1.0;
         }
         if ((rc = obe_pcg64_uniform(d_raw, n, d_uniforms, stream))) break;
         if ((rc = obe_cdf_search(d_cdf, n, d_uniforms, n, d_idx, d_ws, ws_bytes, stream))) break;
-        arm_host_word(h_flags);
+        const int64_t lo = have_first_moments ? 2 + 4 * (int64_t)n_dims : 0;
+        arm_host_words(h_f64 + 1 + lo, obe_moments_len(n_dims) - lo);
         bool host_written = false;
         if ((rc = moments_call(d_particles, ld_p, n_dims, n, d_weights, have_first_moments ? 2 : 1, d_moments,
-                               h_f64 + 1, h_flags, d_ws, ws_bytes, st, &host_written)))
+                               h_f64 + 1, d_ws, ws_bytes, st, &host_written)))
             break;
         if ((rc = obe_ziggurat_normal(d_raw + n, n_raw - n, 0, d_zig_tables, n_normal, d_normals, h_i64, d_zig_ws,
                                       zig_ws_bytes, stream)))

@@ -398,10 +398,10 @@ int obe_ziggurat_normal(const uint64_t* d_raw, int64_t n_raw, int64_t offset, co
     flag_scan_offsets<<<1, kBlock, 0, st>>>(sums, nb);
     OBE_CHECK_LAUNCH("flag_scan_offsets");
     // deferred + page-locked h_consumed: the kernel delivers {consumed, found} itself and the caller watches
-    // h_consumed[1] (armed here: no count of normals has that bit pattern)
+    // both words (armed here: no count has that bit pattern)
     int64_t* hv = defer_host_sync() ? static_cast<int64_t*>(device_view_of_host(h_consumed)) : nullptr;
     unsigned* counter = hv ? stream_control_words(st) : nullptr;
-    if (hv) arm_host_word(h_consumed + 1);        // (also when the copy node below delivers: it overwrites the word)
+    if (hv) arm_host_words(h_consumed, 2);        // (also when the copy node below delivers: it overwrites the words)
     if (!counter) hv = nullptr;
     zig_compact_kernel<<<(unsigned)nb, kBlock, 0, st>>>(flag, sums, val, len, n_raw, offset, n, d_out, result, hv,
                                                         counter);

@@ -403,8 +403,7 @@ struct HostResult {
     int64_t* idx;
     double* kappa;
 };
-// (the word the host watches is stored last, behind a system-scope fence: the index if it is asked for,
-// else kappa, else the value — host_flag_of() names the same one)
+// (every word is armed by the host and waited for on its own: the order of the stores does not matter)
 __device__ __forceinline__ void deliver(const HostResult& h, double v, int64_t i, double k) {
     if (h.idx) {
         if (h.best) *h.best = v;
@@ -723,25 +722,27 @@ static int carve_sweep_ws(void* d_ws, int64_t ws_bytes, int64_t part_doubles, in
     return 0;
 }
 
-// the host word deliver() stores last
-static void* host_flag_of(double* h_best, int64_t* h_best_idx, double* h_kappa) {
-    return h_best_idx ? static_cast<void*>(h_best_idx) : (h_kappa ? static_cast<void*>(h_kappa) : static_cast<void*>(h_best));
-}
-
-// the device views of the caller's host outputs if every one that is asked for is page-locked
+// the device views of the caller's host outputs if every one that is asked for is page-locked; each such
+// word is armed (before any launch) and read_best() waits for each of them
 static HostResult host_result(double* h_best, int64_t* h_best_idx, double* h_kappa) {
     HostResult r{static_cast<double*>(device_view_of_host(h_best)), static_cast<int64_t*>(device_view_of_host(h_best_idx)),
                  static_cast<double*>(device_view_of_host(h_kappa))};
     if ((h_best && !r.best) || (h_best_idx && !r.idx) || (h_kappa && !r.kappa)) r = HostResult{nullptr, nullptr, nullptr};
-    if (r.best || r.idx || r.kappa) arm_host_word(host_flag_of(h_best, h_best_idx, h_kappa));      // (before any launch)
+    if (r.best) arm_host_word(h_best);
+    if (r.idx) arm_host_word(h_best_idx);
+    if (r.kappa) arm_host_word(h_kappa);
     return r;
 }
 
 static int read_best(const SweepWs& w, double* h_best, int64_t* h_best_idx, hipStream_t st,
                      double* h_kappa = nullptr, const HostResult& delivered = HostResult{nullptr, nullptr, nullptr}) {
     if (!h_best && !h_best_idx && !h_kappa) return 0;
-    if (delivered.best || delivered.idx || delivered.kappa)        // the kernel writes them: watch its last word
-        return wait_host_word(host_flag_of(h_best, h_best_idx, h_kappa), st);
+    if (delivered.best || delivered.idx || delivered.kappa) {       // the kernel writes them: watch every word
+        if (h_best_idx) if (int rc = wait_host_word(h_best_idx, st)) return rc;
+        if (h_kappa) if (int rc = wait_host_word(h_kappa, st)) return rc;
+        if (h_best) if (int rc = wait_host_word(h_best, st)) return rc;
+        return 0;
+    }
     double tmp[9];
     OBE_HIP_TRY(hipMemcpyAsync(tmp, w.out_v, 9 * sizeof(double), hipMemcpyDeviceToHost, st));
     OBE_HIP_TRY(hipStreamSynchronize(st));

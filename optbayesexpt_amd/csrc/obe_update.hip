@@ -286,11 +286,11 @@ __global__ __launch_bounds__(kBlock) void fold2_kernel(const double* __restrict_
 // fold + delivery of {sum t, sum w'^2} to h_out: written by the kernel itself when h_out is page-locked
 static int fold2_to_host(const double* pa, const double* pb, int nb, double* scalars, double* h_out, hipStream_t st) {
     double* hv = static_cast<double*>(device_view_of_host(h_out));
-    if (hv) arm_host_word(h_out + 1);
+    if (hv) arm_host_words(h_out, 2);
     fold2_kernel<<<1, kBlock, 0, st>>>(pa, pb, nb, scalars, hv);
     OBE_CHECK_LAUNCH("fold2_kernel");
     if (h_out) {
-        if (hv) return wait_host_word(h_out + 1, st);
+        if (hv) return wait_host_words(h_out, 2, st);
         OBE_HIP_TRY(hipMemcpyAsync(h_out, scalars, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
         OBE_HIP_TRY(hipStreamSynchronize(st));
     }
@@ -618,7 +618,7 @@ int obe_bayes_update_model_moments(const obe_model* m, const double* d_particles
     if (rc) return rc;
     const int nm = moment_blocks(n_particles, d);
     double* hv = static_cast<double*>(device_view_of_host(h_out));
-    if (hv) arm_host_word(h_out + 1);
+    if (hv) arm_host_words(h_out, 2 + 2 + 4 * (int64_t)d);      // every word of the result block is watched
     // the fold rides in the normalisation launch (its last workgroup to arrive) unless there is no counter
     // for this stream or OBE_UPDATE_FOLD=separate asks for the round-3 shape (A/B measurements)
     static const bool separate = getenv("OBE_UPDATE_FOLD") && !strcmp(getenv("OBE_UPDATE_FOLD"), "separate");
@@ -646,7 +646,7 @@ int obe_bayes_update_model_moments(const obe_model* m, const double* d_particles
         OBE_CHECK_LAUNCH("fold_update_moments_kernel");
     }
     if (h_out) {
-        if (hv) return wait_host_word(h_out + 1, st);
+        if (hv) return wait_host_words(h_out, 2 + 2 + 4 * (int64_t)d, st);
         {
             OBE_HIP_TRY(hipMemcpyAsync(h_out, w.scalars, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
             OBE_HIP_TRY(hipMemcpyAsync(h_out + 2, d_moments, (2 + 4 * (int64_t)d) * sizeof(double),
@@ -858,6 +858,7 @@ int obe_mask_nonpositive_moments(const double* d_particles, int64_t ld_p, int32_
     mask_kernel<<<nb, kBlock, 0, st>>>(ra, d_particles, ld_p, n_particles, d_weights, w.pa, w.pb);
     OBE_CHECK_LAUNCH("mask_kernel");
     if (hc) arm_host_word(h_changed);
+    if (hm) arm_host_words(h_moments, 2 + 4 * (int64_t)n_dims);
     const MaskFold mf{counter, d_moments, hm, hc};
     const int nm = moment_blocks(n_particles, n_dims);
 #define OBE_MASK_MOM_CASE(DD)                                                                                       \

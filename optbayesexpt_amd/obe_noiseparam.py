@@ -67,7 +67,9 @@ class OptBayesExptNoiseParameter(OptBayesExpt):
             # (weights may have changed: a new version either way; the moments describe exactly them)
             self._weights.mark_device_written()
             self._mom_host_key = self._mom_dev_key = (self._particles.version, self._weights.version, False)
-            self._mom_host_wait = _lib.host_ptr(changed)      # (the host copy is complete once the count has arrived)
+            # (the host copy is complete once every word of it — and the count — has arrived: armed by the call)
+            self._mom_host_wait = ((self._hargs.ptr_keep(self._moments_host), 2 + 4 * self.n_dims),
+                                   (_lib.host_ptr(changed), 1))
         else:       # a stale `parameters` alias (set_pdf between updates): the mask alone, on those rows
             self._lib.call("obe_mask_nonpositive", _ptr(par), par.shape[1], self.n_particles,
                            _lib.host_ptr(self._noise_rows), self.n_channels, _ptr(w), _lib.host_ptr(changed),

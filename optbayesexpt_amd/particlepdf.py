@@ -200,10 +200,7 @@ class ParticlePDF:
         """Host copy of the K3 output block (computes it if stale); synchronises."""
         key = (self._particles.version, self._weights.version)
         hk = self._mom_host_key
-        pending = self.__dict__.get("_mom_host_wait")
-        if pending is not None:       # a call that delivers the block without being waited for (the constraint mask)
-            self._mom_host_wait = None
-            self._lib.call("obe_host_word_wait", pending, self._stream())
+        self._await_host_moments()
         if hk is not None and hk[:2] == key and (hk[2] or not want_cov):
             return self._moments_host
         p, w = self._pw_tensors()
@@ -216,6 +213,15 @@ class ParticlePDF:
                        _lib.host_ptr(self._moments_host), _ptr(self._ws), self._ws_bytes, self._stream())
         self._mom_host_key = self._mom_dev_key = key + (bool(want_cov),)
         return self._moments_host
+
+    def _await_host_moments(self):
+        """A call that delivers the K3 block to the host without being waited for (the constraint mask with its
+        first moments) leaves the armed words to wait for here, before the host copy is read."""
+        pending = self.__dict__.get("_mom_host_wait")
+        if pending is not None:
+            self._mom_host_wait = None
+            for ptr, n_words in pending:
+                self._lib.call("obe_host_words_wait", ptr, n_words, self._stream())
 
     def _moments_on_device(self):
         """Device copy of the first moments, current for the present cloud (no sync)."""
@@ -488,20 +494,19 @@ class ParticlePDF:
         dev = self._device
         zig_bytes = int(self._lib.cdll.obe_ziggurat_workspace_bytes(n_raw - n))
         mlen = self._lib.moments_len(d)
-        pin_f, pin_flag, pin_i = _lib.pinned_array(mlen + 8), _lib.pinned_array(2, np.uint64), _lib.pinned_array(2, np.int64)
+        pin_f, pin_i = _lib.pinned_array(mlen + 8), _lib.pinned_array(2, np.int64)
         b = self._rs_bufs = dict(
             shape=(n, d), margin=margin, n_raw=n_raw,
             raw=torch.empty(n_raw, dtype=torch.int64, device=dev), uni=torch.empty(n, dtype=torch.float64, device=dev),
             normals=torch.empty(n * d, dtype=torch.float64, device=dev),
             zig_ws=torch.empty(zig_bytes // 8 + 1, dtype=torch.float64, device=dev), tables=_devrng._tables(dev),
-            pin_f=pin_f, pin_flag=pin_flag, pin_i=pin_i, p_f=_lib.host_ptr(pin_f), p_flag=_lib.host_ptr(pin_flag),
-            p_i=_lib.host_ptr(pin_i), p_i1=_P(pin_i.ctypes.data + 8))
+            pin_f=pin_f, pin_i=pin_i, p_f=_lib.host_ptr(pin_f), p_i=_lib.host_ptr(pin_i))
         return b
 
     def _resample_pipelined(self):
         """resample() with the caller's generator continued on the device.  ONE library call
         (obe_resample_begin) enqueues CDF, uniforms, search, covariance and the ziggurat normals back to
-        back; the host waits — by watching a page-locked word the covariance kernel stores last — for
+        back; the host waits — by watching the page-locked words of the covariance block — for
         the covariance, factorises it while the normals are still being generated, launches the gather
         + nudge and then reads the generator bookkeeping the same way (no stream synchronisation, so
         the gather runs on while the caller goes on).  Same kernels, same numbers and the same
@@ -522,25 +527,28 @@ class ParticlePDF:
         mkey = (self._particles.version, self._weights.version)
         have_first = self._mom_host_key is not None and self._mom_host_key[:2] == mkey \
             and self._mom_dev_key is not None and self._mom_dev_key[:2] == mkey
+        self._await_host_moments()
         stream = self._stream()
         self._lib.call("obe_resample_begin", _ptr(p), p.shape[1], d, n, _ptr(w), _lib.host_ptr(h_state),
                        1 if strict else 0, 1 if self._cdf_key == key else 0, 1 if have_first else 0,
                        _ptr(b["raw"]), b["n_raw"], _ptr(self._cdf_dev), _ptr(b["uni"]), _ptr(idx), _ptr(b["tables"]),
                        _ptr(b["normals"]), _ptr(b["zig_ws"]), b["zig_ws"].numel() * 8, _ptr(self._moments_dev),
-                       b["p_f"], b["p_flag"], b["p_i"], _ptr(self._ws), self._ws_bytes, stream)
-        self._lib.call("obe_host_word_wait", b["p_flag"], stream)      # the covariance is there; the normals still run
+                       b["p_f"], b["p_i"], _ptr(self._ws), self._ws_bytes, stream)
         pin_f = b["pin_f"]
-        self._validate_total(float(pin_f[0]))         # (raises before any generator state has moved)
-        self._cdf_key = key
         first = 2 + 4 * d                              # (a covariance-only pass delivers only the covariance)
         lo = first if have_first else 0
+        # every word of the block is watched (the call armed them): the covariance is there, the normals still run
+        self._lib.call("obe_host_words_wait", _P(pin_f.ctypes.data + 8 * (1 + lo)), mlen - lo, stream)
+        self._lib.call("obe_host_words_wait", b["p_f"], 1, stream)     # sum(w), from an earlier kernel
+        self._validate_total(float(pin_f[0]))         # (raises before any generator state has moved)
+        self._cdf_key = key
         self._moments_host[lo:mlen] = pin_f[1 + lo:1 + mlen]
         self._mom_host_key = self._mom_dev_key = mkey + (True,)
         factor, mean = self._nudge_factor(self._moments_host)
         self.last_draw_indices_device = idx
         before = self._particles
         self._resample_apply(idx, b["normals"], factor, mean)
-        self._lib.call("obe_host_word_wait", b["p_i1"], stream)        # {raw consumed, normals found}
+        self._lib.call("obe_host_words_wait", b["p_i"], 2, stream)     # {raw consumed, normals found}
         consumed, found = int(b["pin_i"][0]), int(b["pin_i"][1])
         if self._lib.cdll.obe_ziggurat_check(consumed, found, n * d, b["n_raw"] - n, 0) != 0:
             # unlucky stream (never seen): the raw buffer was too short for N D normals — draw them

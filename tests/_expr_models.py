@@ -25,6 +25,11 @@ def expression_models():
         # sin / cos / sqrt / hypot at the inner level of the sweep (the fast elementary functions)
         "trig": models.from_expression("a*sin(w*t + p) + b*cos(w*t)*sqrt(t + c) + hypot(a*t, b)", settings=("t",),
                                        parameters=("w", "p", "a", "b"), constants=("c",)),
+        # 11 parameters: five Lorentzian peaks with their own amplitudes on one background (the fuzz recipes'
+        # many-parameter expression model: tools/fuzz_parity.py)
+        "peaks11": models.from_expression(
+            "b + " + " + ".join(f"a{k} / (((x - c{k}) / d)**2 + 1)" for k in range(5)), settings=("x",),
+            parameters=tuple(f"c{k}" for k in range(5)) + tuple(f"a{k}" for k in range(5)) + ("b",), constants=("d",)),
         # a model with a true pole (tests the NaN semantics of the sweep)
         "pole": models.from_expression("a / (x - x0)", settings=("x",), parameters=("x0", "a")),
         # demos/find_peak/sequentialLorentzian.py:53-75 as a formula

@@ -45,7 +45,7 @@ def numpy_rejects(p):
 
 
 def make_case(g):
-    kind = g.choice(["lorentz1", "lorentz2", "lorentz3", "line_mb", "line_ab", "first", "rabi", "coil"])
+    kind = g.choice(["lorentz1", "lorentz2", "lorentz3", "lorentz7", "peaks11", "line_mb", "line_ab", "first", "rabi", "coil"])
     n = int(np.exp(g.uniform(np.log(2), np.log(20000))))
     case = dict(kind=str(kind), n=n, seed=int(g.integers(1 << 30)))
     case["full"] = bool(g.random() < 0.5)
@@ -62,9 +62,11 @@ def make_case(g):
     case["cycles"] = int(g.integers(2, 7))
     case["threshold"] = float(g.choice([0.5, 0.9, 0.999]))          # high thresholds force resamples
     case["ns"] = int(np.exp(g.uniform(0, np.log(6000))))
-    case["noise_param"] = bool(kind in ("line_mb", "lorentz1", "coil") and g.random() < 0.5)
+    case["noise_param"] = bool(kind in ("line_mb", "lorentz1", "lorentz7", "peaks11", "coil") and g.random() < 0.5)
     # the same formula as a generated expression model (a plugin library: the kernels compiled for the formula)
-    case["expression"] = bool(kind in ("lorentz1", "rabi", "coil") and g.random() < 0.3)
+    case["expression"] = bool(kind == "peaks11" or (kind in ("lorentz1", "rabi", "coil") and g.random() < 0.3))
+    if kind in ("lorentz7", "peaks11"):         # 9-12 parameter rows: the covariance of a 2-particle cloud is no test
+        case["n"] = max(case["n"], 64)
     return case
 
 
@@ -78,6 +80,12 @@ def build(case):
         dm, fn = obe.models.lorentzian(k), (om.lorentzian if k == 1 else om.multi_lorentzian(k))
         sv, cons = (np.linspace(1.5, 4.5, ns),), (0.1,)
         true = tuple([3.0 + 0.1 * i for i in range(k)] + [1000.0, 500.0])
+        sigma = 200.0
+    elif kind == "peaks11":
+        rows = [g.uniform(2, 4, n) for _ in range(5)] + [g.uniform(400, 2000, n) for _ in range(5)] + [g.normal(500, 300, n)]
+        dm = fn = None                                   # the expression model, below; its NumPy form is the oracle's model
+        sv, cons = (np.linspace(1.5, 4.5, ns),), (0.1,)
+        true = (2.3, 2.7, 3.0, 3.3, 3.8, 900.0, 1200.0, 700.0, 1500.0, 1000.0, 500.0)
         sigma = 200.0
     elif kind in ("line_mb", "line_ab"):
         rows = [g.normal(1.0, 0.5, n), g.normal(-0.5, 0.5, n)]
@@ -104,7 +112,9 @@ def build(case):
         global _EXPR
         if _EXPR is None:
             _EXPR = _expr_models.expression_models()          # (pre-built by __graft_entry__.build())
-        dm = _EXPR[{"lorentz1": "lorentzian", "rabi": "rabi", "coil": "coil"}[kind]]
+        dm = _EXPR[{"lorentz1": "lorentzian", "rabi": "rabi", "coil": "coil", "peaks11": "peaks11"}[kind]]
+        if fn is None:
+            fn = dm
     n_model_rows = len(rows)
     if case["noise_param"]:
         n_ch = 2 if kind == "coil" else 1
