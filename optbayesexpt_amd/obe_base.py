@@ -486,7 +486,9 @@ class OptBayesExpt(ParticlePDF):
                 self._noise_dev.copy_(torch.from_numpy(flat))
                 self._noise_cache = key
             dns = self.default_noise_std
-            self._noise_src = dns.tobytes() if isinstance(dns, np.ndarray) else None
+            # (the shortcut above is only for the class's own model: a replaced yvar_noise_model leaves no source)
+            own = not _overridden(self, "yvar_noise_model", OptBayesExpt)
+            self._noise_src = dns.tobytes() if own and isinstance(dns, np.ndarray) else None
             return self._noise_dev, 0
         full = np.broadcast_to(nv, (c, ns))[:, self._s_begin:self._s_end]
         t = torch.from_numpy(np.array(full)).to(self._device)
