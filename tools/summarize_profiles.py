@@ -25,7 +25,7 @@ def short(name):
 c = sqlite3.connect(os.path.join(SRC, "trace", "bench_results.db"))
 rows = list(c.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
 with open(os.path.join(DST, f"{tag}_kernel_stats_{cfg}.txt"), "w") as f:
-    f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline ({cfg})\n")
+    f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs ({cfg})\n")
     f.write("# durations in microseconds; bench.py's own JSON line for this profiled run follows the table\n")
     f.write(f"{'kernel':70s} {'calls':>6s} {'total_us':>12s} {'avg_us':>12s} {'pct':>7s}\n")
     for name, calls, total, avg, pct in rows:
