@@ -35,8 +35,8 @@ int wait_host_words(const void* h_words, int64_t n, hipStream_t st) {
 
 int wait_host_word(const void* h_word, hipStream_t st) { return wait_host_words(h_word, 1, st); }
 
-// Arrival counters for "the last workgroup to finish folds the partials" (obe_moments.h: arrive_last):
-// one zeroed 128-byte slot of device memory per (device, stream), allocated in one small block per device
+// Arrival counters for "the last workgroup to finish folds the partials" (obe_common.h: arrive_last):
+// one zeroed 1152-byte slot of device memory per (device, stream), allocated in one small block per device
 // on first use and never freed.  Kernels on one stream never overlap, the counter wraps back to zero with
 // the last arrival (atomicInc), so a slot is always zero between launches — no per-call memset, and nothing
 // is asked of the caller's workspace.  nullptr (table full, allocation failed): callers fold in a launch
@@ -52,7 +52,7 @@ ControlTable& control_table() {
     static ControlTable* t = new ControlTable;          // (leaked on purpose: no destructor order games at exit)
     return *t;
 }
-constexpr int kControlSlots = 256, kControlSlotWords = 32;
+constexpr int kControlSlots = 256;         // (kControlSlotWords: obe_common.h, nine 128-byte lines per stream)
 }  // namespace
 
 unsigned* stream_control_words(hipStream_t st) {

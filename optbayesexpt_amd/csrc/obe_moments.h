@@ -5,6 +5,7 @@
 #pragma once
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "obe_common.h"
 
@@ -219,7 +220,8 @@ int moments_call(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_
 constexpr int kMomGridCap = 3 * kMomBlocks;
 static_assert(kMomGridCap <= 1024, "obe_workspace_bytes sizes the moment partials for at most 1024 workgroups");
 inline int moment_blocks(int64_t n, int d) {
-    const int per_cu = n < ((int64_t)1 << 21) ? 1 : (d <= 4 ? 3 : (d <= 7 ? 2 : 1));
+    static const int forced = getenv("OBE_MOM_PER_CU") ? atoi(getenv("OBE_MOM_PER_CU")) : 0;     // tuning aid (1..3)
+    const int per_cu = forced >= 1 && forced <= 3 ? forced : (n < ((int64_t)1 << 21) ? 1 : (d <= 4 ? 3 : (d <= 7 ? 2 : 1)));
     return static_cast<int>(std::min<int64_t>((int64_t)per_cu * kMomBlocks, (n + kBlock - 1) / kBlock));
 }
 
