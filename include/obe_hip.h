@@ -273,7 +273,7 @@ int obe_resample_particles(const double* d_old, int64_t ld_old, int32_t n_dims, 
 /* resample(), the device side up to the host's factorisation of the covariance, enqueued by ONE call
  * (particlepdf.py:260-301; RNG order as there: N uniforms for rng.choice, then N x D normals): the caller's
  * PCG64 stream continued on the device (h_pcg_state4 = {state hi, lo, increment hi, lo}; n_raw >= N + N D +
- * 4096 raw values into d_raw), the weight CDF into d_cdf (skipped when cdf_is_fresh), the N uniforms, the
+ * 4096 raw values are looked at, none is stored), the weight CDF into d_cdf (skipped when cdf_is_fresh), the N uniforms, the
  * search of the N draws (d_idx), the covariance of the PRE-resample cloud (have_first_moments: d_moments
  * already holds mean / std of these weights) and the N x D ziggurat normals (d_normals; d_zig_ws of
  * obe_ziggurat_workspace_bytes(n_raw - N) bytes).  Nothing is waited for.  Both host buffers must be
@@ -285,7 +285,7 @@ int obe_resample_particles(const double* d_old, int64_t ld_old, int32_t n_dims, 
  * Same kernels, same numbers as the calls one by one. */
 int obe_resample_begin(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t n_particles,
                        const double* d_weights, const uint64_t* h_pcg_state4, int32_t strict_cdf,
-                       int32_t cdf_is_fresh, int32_t have_first_moments, uint64_t* d_raw, int64_t n_raw,
+                       int32_t cdf_is_fresh, int32_t have_first_moments, int64_t n_raw,
                        double* d_cdf, double* d_uniforms, int64_t* d_idx, const void* d_zig_tables,
                        double* d_normals, void* d_zig_ws, int64_t zig_ws_bytes, double* d_moments,
                        double* h_f64, int64_t* h_i64, void* d_ws, int64_t ws_bytes, void* stream);
@@ -421,6 +421,16 @@ int obe_kld_utility(const double* d_entropy_y, int32_t n_channels, int64_t n_set
 int obe_pcg64_raw(const uint64_t* h_state4, int64_t n_raw, uint64_t* d_raw, void* stream);
 /* d_out[i] = (d_raw[i] >> 11) * 2^-53  (numpy next_double / Generator.random). */
 int obe_pcg64_uniform(const uint64_t* d_raw, int64_t n, double* d_out, void* stream);
+/* The same draws without a buffer of raw values, in two stages (what obe_resample_begin enqueues): stage 1 —
+ * ONE launch for the n_uniform uniforms of Generator.choice and the classification of the n_raw_normal raw
+ * positions behind them, every thread carrying the generator state of its position (h_state4 as for
+ * obe_pcg64_raw); stage 2 — start flags, scan and compaction of the first n normals into d_out, h_consumed as
+ * for obe_ziggurat_normal.  d_ws of obe_ziggurat_workspace_bytes(n_raw_normal) bytes, the same for both. */
+int obe_pcg64_uniforms_classify(const uint64_t* h_state4, int64_t n_uniform, int64_t n_raw_normal,
+                                double* d_uniforms, const void* d_tables, void* d_ws, int64_t ws_bytes,
+                                void* stream);
+int obe_ziggurat_finish(int64_t n_raw_normal, int64_t n, double* d_out, int64_t* h_consumed, void* d_ws,
+                        int64_t ws_bytes, void* stream);
 /* n standard normals by numpy's ziggurat from d_raw[offset...]: bit-identical values and
  * the exact number of raw values consumed (*h_consumed; sync), so the host generator can
  * be advanced to where numpy would have left it.  d_tables = ki[256] (uint64) | wi[256] |

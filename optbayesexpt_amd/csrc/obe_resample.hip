@@ -631,8 +631,9 @@ int obe_resample_particles(const double* d_old, int64_t ld_old, int32_t n_dims, 
 }
 
 // The device side of ParticlePDF.resample() up to the point where the host must factorise the covariance
-// (particlepdf.py:260-301), enqueued by ONE call: the caller's PCG64 stream continued on the device (raw
-// values, N uniforms), the weight CDF (unless the caller's is fresh), the N-draw search, the covariance of
+// (particlepdf.py:260-301), enqueued by ONE call: the caller's PCG64 stream continued on the device (the N
+// uniforms and the classification of the n_raw - N raw positions behind them, in one launch, straight from
+// the generator state), the weight CDF (unless the caller's is fresh), the N-draw search, the covariance of
 // the pre-resample cloud and the N x D ziggurat normals.  Nothing is waited for.  The host results land in
 // page-locked memory, every word of which is ARMED here and watched by the caller
 // (obe_host_words_wait: returns when none of the words carries the armed pattern any more):
@@ -645,30 +646,32 @@ int obe_resample_particles(const double* d_old, int64_t ld_old, int32_t n_dims, 
 // interpreter between two launches: the GPU idled for most of a resample cycle at 262 144 particles).
 int obe_resample_begin(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t n_particles,
                        const double* d_weights, const uint64_t* h_pcg_state4, int32_t strict_cdf,
-                       int32_t cdf_is_fresh, int32_t have_first_moments, uint64_t* d_raw, int64_t n_raw,
-                       double* d_cdf, double* d_uniforms, int64_t* d_idx, const void* d_zig_tables,
-                       double* d_normals, void* d_zig_ws, int64_t zig_ws_bytes, double* d_moments, double* h_f64,
-                       int64_t* h_i64, void* d_ws, int64_t ws_bytes, void* stream) {
-    if (!d_particles || !d_weights || !h_pcg_state4 || !d_raw || !d_cdf || !d_uniforms || !d_idx || !d_zig_tables ||
+                       int32_t cdf_is_fresh, int32_t have_first_moments, int64_t n_raw, double* d_cdf,
+                       double* d_uniforms, int64_t* d_idx, const void* d_zig_tables, double* d_normals,
+                       void* d_zig_ws, int64_t zig_ws_bytes, double* d_moments, double* h_f64, int64_t* h_i64,
+                       void* d_ws, int64_t ws_bytes, void* stream) {
+    if (!d_particles || !d_weights || !h_pcg_state4 || !d_cdf || !d_uniforms || !d_idx || !d_zig_tables ||
         !d_normals || !d_zig_ws || !d_moments || !h_f64 || !h_i64 || n_particles <= 0)
         return bad_arg("obe_resample_begin: bad pointer/size");
     if (n_dims < 1 || n_dims > OBE_MAX_DIMS) return bad_arg("obe_resample_begin: n_dims must be 1..16");
     const int64_t n = n_particles, n_normal = n * n_dims;
-    if (n_raw < n + n_normal + 4096) return bad_arg("obe_resample_begin: raw buffer shorter than the draws");
+    if (n_raw < n + n_normal + 4096) return bad_arg("obe_resample_begin: fewer raw values than the draws need");
     if (!device_view_of_host(h_f64) || !device_view_of_host(h_i64))
         return bad_arg("obe_resample_begin: the host result buffers must be page-locked");
     hipStream_t st = as_stream(stream);
     const int prev = obe_defer_host_sync(1);
     int rc = 0;
     do {
-        if ((rc = obe_pcg64_raw(h_pcg_state4, n_raw, d_raw, stream))) break;
+        // uniforms + the classification of every raw position behind them, straight from the generator state
+        if ((rc = obe_pcg64_uniforms_classify(h_pcg_state4, n, n_raw - n, d_uniforms, d_zig_tables, d_zig_ws,
+                                              zig_ws_bytes, stream)))
+            break;
         if (!cdf_is_fresh) {
             arm_host_word(h_f64);
             if ((rc = obe_weight_cdf(d_weights, n, strict_cdf, d_cdf, h_f64, d_ws, ws_bytes, stream))) break;
         } else {
             h_f64[0] = 1.0;
         }
-        if ((rc = obe_pcg64_uniform(d_raw, n, d_uniforms, stream))) break;
         if ((rc = obe_cdf_search(d_cdf, n, d_uniforms, n, d_idx, d_ws, ws_bytes, stream))) break;
         const int64_t lo = have_first_moments ? 2 + 4 * (int64_t)n_dims : 0;
         arm_host_words(h_f64 + 1 + lo, obe_moments_len(n_dims) - lo);
@@ -676,9 +679,7 @@ int obe_resample_begin(const double* d_particles, int64_t ld_p, int32_t n_dims, 
         if ((rc = moments_call(d_particles, ld_p, n_dims, n, d_weights, have_first_moments ? 2 : 1, d_moments,
                                h_f64 + 1, d_ws, ws_bytes, st, &host_written)))
             break;
-        if ((rc = obe_ziggurat_normal(d_raw + n, n_raw - n, 0, d_zig_tables, n_normal, d_normals, h_i64, d_zig_ws,
-                                      zig_ws_bytes, stream)))
-            break;
+        if ((rc = obe_ziggurat_finish(n_raw - n, n_normal, d_normals, h_i64, d_zig_ws, zig_ws_bytes, stream))) break;
     } while (false);
     obe_defer_host_sync(prev);
     return rc;

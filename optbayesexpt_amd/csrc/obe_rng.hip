@@ -24,6 +24,8 @@
 //                                    scatter value[i] to out[rank[i]].
 //   The ziggurat tables (ki, wi, fi) are data supplied by the host
 //   (optbayesexpt_amd/data/ziggurat_tables.npz, see tools/make_ziggurat_tables.py).
+#include <cstdlib>
+
 #include "obe_common.h"
 
 namespace obe {
@@ -113,47 +115,96 @@ struct ZigTables {
 
 __device__ __forceinline__ double next_double(uint64_t r) { return (double)(r >> 11) * (1.0 / 9007199254740992.0); }
 
-// numpy/random/src/distributions: random_standard_normal (ziggurat), as if a normal
-// started at raw[i].  length = raw values consumed (0 = ran off the buffer / too long).
+// numpy/random/src/distributions: random_standard_normal (ziggurat), as if a normal started at raw
+// position i.  `next()` hands out raw[i], raw[i + 1], ...; `left` = raw values from i to the end of the
+// buffer.  Returns the value; *length = raw values consumed (0 = ran off the buffer / too long).
+template <class Next>
+__device__ __forceinline__ double zig_classify_one(Next&& next, int64_t left, const ZigTables& t, uint8_t* length) {
+    int used = 0;
+    double x = 0.0;
+    bool done = false, bad = false;
+    while (!done) {
+        if (used >= left || used >= kMaxLen) { bad = true; break; }
+        uint64_t r = next();
+        ++used;
+        const int idx = (int)(r & 0xff);
+        r >>= 8;
+        const int sign = (int)(r & 0x1);
+        const uint64_t rabs = (r >> 1) & 0x000fffffffffffffULL;
+        x = (double)rabs * t.wi[idx];
+        if (sign) x = -x;
+        if (rabs < t.ki[idx]) break;                       // 99.3 %: inside the rectangle
+        if (idx == 0) {                                    // tail of the base strip
+            for (;;) {
+                if (used + 1 >= left || used + 2 > kMaxLen) { bad = true; break; }
+                const double xx = -kZigInvR * log1p(-next_double(next()));
+                const double yy = -log1p(-next_double(next()));
+                used += 2;
+                if (yy + yy > xx * xx) {
+                    x = ((rabs >> 8) & 0x1) ? -(kZigR + xx) : kZigR + xx;
+                    done = true;
+                    break;
+                }
+            }
+            if (bad) break;
+        } else {                                           // wedge
+            if (used >= left) { bad = true; break; }
+            const double u = next_double(next());
+            ++used;
+            if ((t.fi[idx - 1] - t.fi[idx]) * u + t.fi[idx] < exp(-0.5 * x * x)) done = true;
+        }
+    }
+    *length = bad ? 0 : (uint8_t)used;
+    return x;
+}
+
 __global__ __launch_bounds__(kBlock) void zig_classify_kernel(const uint64_t* __restrict__ raw, int64_t n_raw,
                                                               ZigTables t, double* __restrict__ val,
                                                               uint8_t* __restrict__ len, int64_t* __restrict__ result) {
     if (blockIdx.x == 0 && threadIdx.x == 0) result[0] = result[1] = 0;    // (what a memset node did: one launch less)
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n_raw; i += (int64_t)gridDim.x * kBlock) {
         int64_t pos = i;
-        double x = 0.0;
-        bool done = false, bad = false;
-        while (!done) {
-            if (pos >= n_raw || pos - i >= kMaxLen) { bad = true; break; }
-            uint64_t r = raw[pos++];
-            const int idx = (int)(r & 0xff);
-            r >>= 8;
-            const int sign = (int)(r & 0x1);
-            const uint64_t rabs = (r >> 1) & 0x000fffffffffffffULL;
-            x = (double)rabs * t.wi[idx];
-            if (sign) x = -x;
-            if (rabs < t.ki[idx]) break;                       // 99.3 %: inside the rectangle
-            if (idx == 0) {                                    // tail of the base strip
-                for (;;) {
-                    if (pos + 1 >= n_raw || pos + 2 - i > kMaxLen) { bad = true; break; }
-                    const double xx = -kZigInvR * log1p(-next_double(raw[pos]));
-                    const double yy = -log1p(-next_double(raw[pos + 1]));
-                    pos += 2;
-                    if (yy + yy > xx * xx) {
-                        x = ((rabs >> 8) & 0x1) ? -(kZigR + xx) : kZigR + xx;
-                        done = true;
-                        break;
-                    }
-                }
-                if (bad) break;
-            } else {                                           // wedge
-                if (pos >= n_raw) { bad = true; break; }
-                const double u = next_double(raw[pos++]);
-                if ((t.fi[idx - 1] - t.fi[idx]) * u + t.fi[idx] < exp(-0.5 * x * x)) done = true;
-            }
+        uint8_t l;
+        val[i] = zig_classify_one([&]() { return raw[pos++]; }, n_raw - i, t, &l);
+        len[i] = l;
+    }
+}
+
+// The same without a buffer of raw values (round 4): every thread carries the generator state of its
+// position — jump-ahead once, then one 128-bit multiply-add per grid stride, as pcg64_raw_kernel does — and a
+// draw that needs more than one raw value (1.2 %) steps a copy of that state.  Positions below n_uniform are
+// the uniforms of Generator.choice, (raw >> 11) * 2^-53; the rest are classified as above, indexed from
+// n_uniform.  One launch instead of three (raw values, uniforms, classify), and 8 B per position less written
+// and twice less read.
+__global__ __launch_bounds__(kBlock) void pcg_uniform_classify_kernel(PcgArgs a, U128 step_mult, int64_t n_uniform,
+                                                                      int64_t n_rel, ZigTables t,
+                                                                      double* __restrict__ uniforms,
+                                                                      double* __restrict__ val,
+                                                                      uint8_t* __restrict__ len,
+                                                                      int64_t* __restrict__ result) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) result[0] = result[1] = 0;
+    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const int64_t n = n_uniform + n_rel;
+    if (g >= n) return;
+    U128 A, C;
+    lcg_jump(a.inc, (uint64_t)g + 1, A, C);
+    U128 s = add128(mul128(A, a.state), C);
+    for (int64_t j = g; j < n; j += stride) {
+        if (j < n_uniform) {
+            uniforms[j] = next_double(pcg_output(s));
+        } else {
+            const int64_t i = j - n_uniform;
+            U128 c = s;
+            uint8_t l;
+            val[i] = zig_classify_one([&]() {
+                const uint64_t r = pcg_output(c);
+                c = add128(mul128(step_mult, c), a.inc);
+                return r;
+            }, n_rel - i, t, &l);
+            len[i] = l;
         }
-        val[i] = x;
-        len[i] = bad ? 0 : (uint8_t)(pos - i);
+        s = add128(mul128(a.strideA, s), a.strideC);
     }
 }
 
@@ -170,11 +221,28 @@ constexpr int kHalo = 2 * kMaxLen;        // room to step back over a few non-an
 __global__ __launch_bounds__(kBlock) void zig_starts_kernel(const uint8_t* __restrict__ len, int64_t n_raw,
                                                             int64_t first, uint8_t* __restrict__ flag,
                                                             uint32_t* __restrict__ sums) {
-    __shared__ uint8_t sl[kStartTile + kHalo];
+    __shared__ __attribute__((aligned(8))) uint8_t sl[kStartTile + kHalo];
     const int64_t tile0 = (int64_t)blockIdx.x * kStartTile;
-    for (int k = threadIdx.x; k < kStartTile + kHalo; k += kBlock) {
-        const int64_t g = tile0 - kHalo + k;
-        sl[k] = (g >= first && g < n_raw) ? len[g] : (uint8_t)1;      // before `first`: harmless 1s
+    // (staged 8 bytes per thread — the tile starts on a multiple of 2048 and len[] is padded to a multiple of 8:
+    // byte-wise staging was 8 dependent trips of 1-byte loads per thread, most of this kernel's 30 us)
+    {
+        const int64_t g0 = tile0 + (int64_t)threadIdx.x * 8;
+        uint64_t v = 0x0101010101010101ULL;
+        if (g0 + 8 <= n_raw && g0 >= first) {
+            v = *reinterpret_cast<const uint64_t*>(len + g0);
+        } else if (g0 < n_raw) {
+            v = 0;
+            for (int k = 0; k < 8; ++k) {
+                const int64_t g = g0 + k;
+                const uint64_t b = (g >= first && g < n_raw) ? len[g] : (uint8_t)1;
+                v |= b << (8 * k);
+            }
+        }
+        *reinterpret_cast<uint64_t*>(sl + kHalo + threadIdx.x * 8) = v;
+        if (threadIdx.x < kHalo) {
+            const int64_t g = tile0 - kHalo + threadIdx.x;
+            sl[threadIdx.x] = (g >= first && g >= 0 && g < n_raw) ? len[g] : (uint8_t)1;      // before `first`: harmless 1s
+        }
     }
     __syncthreads();
     const int base = kHalo + threadIdx.x * kStartItems;              // LDS index of my first position
@@ -371,31 +439,41 @@ int64_t obe_ziggurat_workspace_bytes(int64_t n_raw) {
     return n_raw * (8 + 1 + 1) + nb * 4 + 1024;       // candidate values, byte flags (padded to 8), lengths, block sums
 }
 
-int obe_ziggurat_normal(const uint64_t* d_raw, int64_t n_raw, int64_t offset, const void* d_tables, int64_t n,
-                        double* d_out, int64_t* h_consumed, void* d_ws, int64_t ws_bytes, void* stream) {
-    if (!d_raw || !d_tables || !d_out || !h_consumed || n <= 0 || offset < 0 || offset >= n_raw)
-        return bad_arg("obe_ziggurat_normal: bad pointer/size");
-    if (!d_ws || ws_bytes < obe_ziggurat_workspace_bytes(n_raw)) return bad_arg("obe_ziggurat_normal: workspace too small");
-    if (n_raw >= (int64_t)1 << 31) return bad_arg("obe_ziggurat_normal: n_raw must be < 2^31");
-    hipStream_t st = as_stream(stream);
-    const int64_t nb = (n_raw + kFlagTile - 1) / kFlagTile;
+struct ZigWs {
+    int64_t* result;     // [0] consumed [1] starts found
+    double* val;         // candidate value per raw position
+    uint8_t* flag;       // start flags, one byte per position (padded to 8)
+    uint32_t* sums;      // starts per tile of 2048 positions
+    uint8_t* len;        // raw values a normal starting here consumes (8-byte aligned: staged 8 at a time)
+    int64_t nb;
+};
+static ZigWs zig_carve(void* d_ws, int64_t n_raw) {
+    ZigWs w;
+    w.nb = (n_raw + kFlagTile - 1) / kFlagTile;
     char* base = static_cast<char*>(d_ws);
-    int64_t* result = reinterpret_cast<int64_t*>(base);             // [0] consumed [1] starts found
-    double* val = reinterpret_cast<double*>(base + 64);
+    w.result = reinterpret_cast<int64_t*>(base);
+    w.val = reinterpret_cast<double*>(base + 64);
     const int64_t n_pad = (n_raw + 7) / 8 * 8;
-    uint8_t* flag = reinterpret_cast<uint8_t*>(base + 64 + n_raw * 8);
-    uint32_t* sums = reinterpret_cast<uint32_t*>(flag + n_pad);
-    uint8_t* len = reinterpret_cast<uint8_t*>(sums + nb);
+    w.flag = reinterpret_cast<uint8_t*>(base + 64 + n_raw * 8);
+    w.sums = reinterpret_cast<uint32_t*>(w.flag + n_pad);
+    w.len = reinterpret_cast<uint8_t*>(w.sums + (w.nb + 1) / 2 * 2);
+    return w;
+}
+static ZigTables zig_tables(const void* d_tables) {
     ZigTables t;
     t.ki = static_cast<const uint64_t*>(d_tables);
     t.wi = reinterpret_cast<const double*>(t.ki + 256);
     t.fi = t.wi + 256;
-    zig_classify_kernel<<<stream_blocks(n_raw, kBlock), kBlock, 0, st>>>(d_raw, n_raw, t, val, len, result);
-    OBE_CHECK_LAUNCH("zig_classify_kernel");
+    return t;
+}
+
+// start flags, their scan and the compaction of the first n normals (the classification has been enqueued)
+static int zig_finish(const ZigWs& w, int64_t n_raw, int64_t offset, int64_t n, double* d_out, int64_t* h_consumed,
+                      hipStream_t st) {
     static_assert(kStartTile == kFlagTile && kStartItems == kFlagItems, "the start flags and their scan share one tiling");
-    zig_starts_kernel<<<(unsigned)nb, kBlock, 0, st>>>(len, n_raw, offset, flag, sums);
+    zig_starts_kernel<<<(unsigned)w.nb, kBlock, 0, st>>>(w.len, n_raw, offset, w.flag, w.sums);
     OBE_CHECK_LAUNCH("zig_starts_kernel");
-    flag_scan_offsets<<<1, kBlock, 0, st>>>(sums, nb);
+    flag_scan_offsets<<<1, kBlock, 0, st>>>(w.sums, w.nb);
     OBE_CHECK_LAUNCH("flag_scan_offsets");
     // deferred + page-locked h_consumed: the kernel delivers {consumed, found} itself and the caller watches
     // both words (armed here: no count has that bit pattern)
@@ -403,15 +481,15 @@ int obe_ziggurat_normal(const uint64_t* d_raw, int64_t n_raw, int64_t offset, co
     unsigned* counter = hv ? stream_control_words(st) : nullptr;
     if (hv) arm_host_words(h_consumed, 2);        // (also when the copy node below delivers: it overwrites the words)
     if (!counter) hv = nullptr;
-    zig_compact_kernel<<<(unsigned)nb, kBlock, 0, st>>>(flag, sums, val, len, n_raw, offset, n, d_out, result, hv,
-                                                        counter);
+    zig_compact_kernel<<<(unsigned)w.nb, kBlock, 0, st>>>(w.flag, w.sums, w.val, w.len, n_raw, offset, n, d_out,
+                                                          w.result, hv, counter);
     OBE_CHECK_LAUNCH("zig_compact_kernel");
-    if (defer_host_sync()) {       // {consumed, found} -> h_consumed[0..1]; the caller checks them after its sync
-        if (!hv) OBE_HIP_TRY(hipMemcpyAsync(h_consumed, result, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    if (defer_host_sync()) {       // {consumed, found} -> h_consumed[0..1]; the caller checks them after its wait
+        if (!hv) OBE_HIP_TRY(hipMemcpyAsync(h_consumed, w.result, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
         return 0;
     }
     int64_t host[2];
-    OBE_HIP_TRY(hipMemcpyAsync(host, result, sizeof(host), hipMemcpyDeviceToHost, st));
+    OBE_HIP_TRY(hipMemcpyAsync(host, w.result, sizeof(host), hipMemcpyDeviceToHost, st));
     OBE_HIP_TRY(hipStreamSynchronize(st));
     if (obe_ziggurat_check(host[0], host[1], n, n_raw, offset)) {
         *h_consumed = -1;
@@ -419,6 +497,53 @@ int obe_ziggurat_normal(const uint64_t* d_raw, int64_t n_raw, int64_t offset, co
     }
     *h_consumed = host[0];
     return 0;
+}
+
+int obe_ziggurat_normal(const uint64_t* d_raw, int64_t n_raw, int64_t offset, const void* d_tables, int64_t n,
+                        double* d_out, int64_t* h_consumed, void* d_ws, int64_t ws_bytes, void* stream) {
+    if (!d_raw || !d_tables || !d_out || !h_consumed || n <= 0 || offset < 0 || offset >= n_raw)
+        return bad_arg("obe_ziggurat_normal: bad pointer/size");
+    if (!d_ws || ws_bytes < obe_ziggurat_workspace_bytes(n_raw)) return bad_arg("obe_ziggurat_normal: workspace too small");
+    if (n_raw >= (int64_t)1 << 31) return bad_arg("obe_ziggurat_normal: n_raw must be < 2^31");
+    hipStream_t st = as_stream(stream);
+    const ZigWs w = zig_carve(d_ws, n_raw);
+    zig_classify_kernel<<<stream_blocks(n_raw, kBlock), kBlock, 0, st>>>(d_raw, n_raw, zig_tables(d_tables), w.val, w.len,
+                                                                         w.result);
+    OBE_CHECK_LAUNCH("zig_classify_kernel");
+    return zig_finish(w, n_raw, offset, n, d_out, h_consumed, st);
+}
+
+// Uniforms and normals of one resample straight from the generator state, without a buffer of raw values:
+// stage 1 (obe_pcg64_uniforms_classify) = the n_uniform uniforms and the classification of the n_raw_normal
+// raw positions behind them in ONE launch; stage 2 (obe_ziggurat_finish) = start flags, scan, compaction of
+// the first n normals.  Two calls so that a caller can enqueue what only needs the uniforms in between.
+int obe_pcg64_uniforms_classify(const uint64_t* h_state4, int64_t n_uniform, int64_t n_raw_normal, double* d_uniforms,
+                                const void* d_tables, void* d_ws, int64_t ws_bytes, void* stream) {
+    if (!h_state4 || !d_tables || !d_ws || n_uniform < 0 || n_raw_normal <= 0 || (n_uniform > 0 && !d_uniforms))
+        return bad_arg("obe_pcg64_uniforms_classify: bad pointer/size");
+    if (ws_bytes < obe_ziggurat_workspace_bytes(n_raw_normal)) return bad_arg("obe_pcg64_uniforms_classify: workspace too small");
+    if (n_raw_normal >= (int64_t)1 << 31) return bad_arg("obe_pcg64_uniforms_classify: n_raw_normal must be < 2^31");
+    PcgArgs a;
+    a.state = U128{h_state4[0], h_state4[1]};
+    a.inc = U128{h_state4[2], h_state4[3]};
+    if ((a.inc.lo & 1) == 0) return bad_arg("obe_pcg64_uniforms_classify: PCG64 increment must be odd");
+    const int64_t total = n_uniform + n_raw_normal;
+    static const int cap = getenv("OBE_RNG_BLOCKS") ? atoi(getenv("OBE_RNG_BLOCKS")) : 1024;      // tuning aid: 51 us at 1024, 59 at 2048, 71 at 256 (5.8 M positions)
+    const int blocks = static_cast<int>(std::min<int64_t>(cap, (total + kBlock - 1) / kBlock));
+    lcg_jump(a.inc, (uint64_t)blocks * kBlock, a.strideA, a.strideC);
+    const ZigWs w = zig_carve(d_ws, n_raw_normal);
+    pcg_uniform_classify_kernel<<<blocks, kBlock, 0, as_stream(stream)>>>(a, pcg_mult(), n_uniform, n_raw_normal,
+                                                                           zig_tables(d_tables), d_uniforms, w.val, w.len,
+                                                                           w.result);
+    OBE_CHECK_LAUNCH("pcg_uniform_classify_kernel");
+    return 0;
+}
+
+int obe_ziggurat_finish(int64_t n_raw_normal, int64_t n, double* d_out, int64_t* h_consumed, void* d_ws,
+                        int64_t ws_bytes, void* stream) {
+    if (!d_out || !h_consumed || !d_ws || n <= 0 || n_raw_normal <= 0) return bad_arg("obe_ziggurat_finish: bad pointer/size");
+    if (ws_bytes < obe_ziggurat_workspace_bytes(n_raw_normal)) return bad_arg("obe_ziggurat_finish: workspace too small");
+    return zig_finish(zig_carve(d_ws, n_raw_normal), n_raw_normal, 0, n, d_out, h_consumed, as_stream(stream));
 }
 
 int obe_ziggurat_check(int64_t consumed, int64_t found, int64_t n, int64_t n_raw, int64_t offset) {

@@ -497,7 +497,7 @@ class ParticlePDF:
         pin_f, pin_i = _lib.pinned_array(mlen + 8), _lib.pinned_array(2, np.int64)
         b = self._rs_bufs = dict(
             shape=(n, d), margin=margin, n_raw=n_raw,
-            raw=torch.empty(n_raw, dtype=torch.int64, device=dev), uni=torch.empty(n, dtype=torch.float64, device=dev),
+            uni=torch.empty(n, dtype=torch.float64, device=dev),
             normals=torch.empty(n * d, dtype=torch.float64, device=dev),
             zig_ws=torch.empty(zig_bytes // 8 + 1, dtype=torch.float64, device=dev), tables=_devrng._tables(dev),
             pin_f=pin_f, pin_i=pin_i, p_f=_lib.host_ptr(pin_f), p_i=_lib.host_ptr(pin_i))
@@ -531,7 +531,7 @@ class ParticlePDF:
         stream = self._stream()
         self._lib.call("obe_resample_begin", _ptr(p), p.shape[1], d, n, _ptr(w), _lib.host_ptr(h_state),
                        1 if strict else 0, 1 if self._cdf_key == key else 0, 1 if have_first else 0,
-                       _ptr(b["raw"]), b["n_raw"], _ptr(self._cdf_dev), _ptr(b["uni"]), _ptr(idx), _ptr(b["tables"]),
+                       b["n_raw"], _ptr(self._cdf_dev), _ptr(b["uni"]), _ptr(idx), _ptr(b["tables"]),
                        _ptr(b["normals"]), _ptr(b["zig_ws"]), b["zig_ws"].numel() * 8, _ptr(self._moments_dev),
                        b["p_f"], b["p_i"], _ptr(self._ws), self._ws_bytes, stream)
         pin_f = b["pin_f"]

@@ -656,6 +656,40 @@ def test_device_rng_is_bitwise_numpy(obe, hip, seed, n_uniform, n_normal):
     assert_array_equal(rng.random(5), ref.random(5))           # and the streams stay in step
 
 
+@pytest.mark.parametrize("seed,n_uniform,n_normal", [(3, 5000, 15000), (11, 262144, 786432), (12, 70001, 700010)])
+def test_generator_state_to_uniforms_and_normals_without_a_raw_buffer(obe, hip, seed, n_uniform, n_normal):
+    """Round 4: obe_pcg64_uniforms_classify + obe_ziggurat_finish produce the uniforms and normals of a
+    resample straight from the PCG64 state (every thread carries the state of its position; nothing raw is
+    stored) — the same numbers as numpy, the same count of raw values consumed."""
+    import torch
+    from optbayesexpt_amd import _devrng, _lib
+    rng = np.random.default_rng(seed)
+    rng.random(11)
+    ref = np.random.default_rng(seed)
+    ref.random(11)
+    st, h_state = _devrng.pcg64_state(rng)
+    n_rel = n_normal + n_normal // 24 + 4096
+    dev = torch.device("cuda", 0)
+    u = torch.empty(n_uniform, dtype=torch.float64, device=dev)
+    z = torch.empty(n_normal, dtype=torch.float64, device=dev)
+    ws = torch.empty(int(hip.cdll.obe_ziggurat_workspace_bytes(n_rel)) // 8 + 1, dtype=torch.float64, device=dev)
+    tables = _devrng._tables(dev)
+    consumed = np.zeros(2, dtype=np.int64)
+    P = _lib.c_void_p
+    hip.call("obe_pcg64_uniforms_classify", _lib.host_ptr(h_state), n_uniform, n_rel, P(u.data_ptr()), P(tables.data_ptr()),
+             P(ws.data_ptr()), ws.numel() * 8, None)
+    hip.call("obe_ziggurat_finish", n_rel, n_normal, P(z.data_ptr()), _lib.host_ptr(consumed), P(ws.data_ptr()),
+             ws.numel() * 8, None)
+    assert_array_equal(u.cpu().numpy(), ref.random(n_uniform))
+    zr = ref.standard_normal(n_normal)
+    zz = z.cpu().numpy()
+    body = np.abs(zr) <= 3.6541528853610088
+    assert_array_equal(zz[body], zr[body])
+    assert_allclose(zz[~body], zr[~body], rtol=2.3e-16, atol=0)
+    _devrng.advance(rng, st, n_uniform + int(consumed[0]))
+    assert rng.bit_generator.state == ref.bit_generator.state
+
+
 @pytest.mark.parametrize("d,scale", [(3, False), (10, True)])
 def test_pipelined_resample_is_the_step_by_step_resample(obe, d, scale):
     """resample() enqueued without host waits (asynchronous host results, one wait for the
