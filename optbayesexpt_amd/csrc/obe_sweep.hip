@@ -387,7 +387,10 @@ __device__ __forceinline__ void block_argmax(Best b, double* bv, int64_t* bi) {
 // Round 4, measured and not kept: argmax_fold's work done here by the last workgroup to arrive (write-through
 // entries, arrival counter).  With 64-1024 workgroups the serialised tickets (~12 ns each) and the tail of
 // the last workgroup cost more than the launch they save: 14.3 vs 7.9 + 4.9 us (4096 x 262 144), 27.0 vs
-// 14.3 + 7.0 us (65 536 x 1 048 576), 18.1 vs 9.6 + 5.2 us (16 384 x 524 288, 10 parameters).
+// 14.3 + 7.0 us (65 536 x 1 048 576), 18.1 vs 9.6 + 5.2 us (16 384 x 524 288, 10 parameters).  With the two-level
+// tickets of obe_common.h: 14.6 vs 8.1 + 5.2, 18.2 vs 10.6 + 7.9, 16.4 vs 9.7 + 5.9 us — level with the two
+// launches and their 1.7 us boundary, no better: the last workgroup's tail (drain, tickets, reading the
+// entries past L1, the host words) costs what argmax_fold costs.
 constexpr int kFinGroupsMany = 16, kFinGroupsFew = 4;      // chunk groups = wavefronts of a finalize workgroup
 constexpr int kFinManyChunks = 64;
 
