@@ -562,6 +562,7 @@ def main():
                                           "note": "the same launches on the cloud tiled 16 x: bandwidth-bound "
                                                   "instead of launch-bound"}
 
+    full_sweep_mode = obe.utility_method == "variance_full"
     out = {"metric": "model-evals/sec (settings x particles) per opt_setting+update cycle, fp64",
            "value": value, "unit": "model-evals/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
@@ -584,16 +585,10 @@ def main():
             out["published_workload"] = published_workload()
         except Exception as exc:
             out["published_workload"] = {"error": str(exc)[:200]}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(cfg, settings, prior, cons, true, sigma)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and obe.utility_method == "variance_full":
-        try:
-            out["cpu_baseline_allcores"] = cpu_baseline_allcores(cfg, settings, prior, cons, true, sigma)
-        except Exception as exc:          # no gcc/OpenMP on the box: the 1-core figure stands alone
-            out["cpu_baseline_allcores"] = {"error": str(exc)[:200]}
     if rank == 0 and world == 1 and cfg == "c3" and not args.no_other_configs:
-        # every other single-GPU config of BASELINE.json on the same line (outside the timed region above)
-        del obe
+        # every other single-GPU config of BASELINE.json on the same line (outside the timed region above; before
+        # the CPU legs, whose 128 OpenMP threads leave the host noisy for a while: c1 is ~25 us of host time per step)
+        obe = None
         torch.cuda.empty_cache()
         others = {}
         for name, k, wu in (("c1", 400, 20), ("c2", 40, 5), ("c5", 12, 3)):
@@ -602,6 +597,13 @@ def main():
             except Exception as exc:
                 others[name] = {"error": str(exc)[:200]}
         out["other_configs"] = others
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, settings, prior, cons, true, sigma)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and full_sweep_mode:
+        try:
+            out["cpu_baseline_allcores"] = cpu_baseline_allcores(cfg, settings, prior, cons, true, sigma)
+        except Exception as exc:          # no gcc/OpenMP on the box: the 1-core figure stands alone
+            out["cpu_baseline_allcores"] = {"error": str(exc)[:200]}
     if rank == 0:
         print(json.dumps(out))
     if use_dist:
