@@ -171,41 +171,125 @@ __global__ __launch_bounds__(kBlock) void zig_classify_kernel(const uint64_t* __
 }
 
 // The same without a buffer of raw values (round 4): every thread carries the generator state of its
-// position — jump-ahead once, then one 128-bit multiply-add per grid stride, as pcg64_raw_kernel does — and a
-// draw that needs more than one raw value (1.2 %) steps a copy of that state.  Positions below n_uniform are
-// the uniforms of Generator.choice, (raw >> 11) * 2^-53; the rest are classified as above, indexed from
-// n_uniform.  One launch instead of three (raw values, uniforms, classify), and 8 B per position less written
-// and twice less read.
-__global__ __launch_bounds__(kBlock) void pcg_uniform_classify_kernel(PcgArgs a, U128 step_mult, int64_t n_uniform,
-                                                                      int64_t n_rel, ZigTables t,
+// position — jump-ahead once, then one 128-bit multiply-add per grid stride, as pcg64_raw_kernel does.
+// Positions below n_uniform are the uniforms of Generator.choice, (raw >> 11) * 2^-53; the rest are
+// classified, indexed from n_uniform.  One launch instead of three (raw values, uniforms, classify), and 8 B
+// per position less written and twice less read.
+//
+// The classification is split in two: 99.3 % of the draws end inside their ziggurat rectangle after one
+// table look-up — this kernel finishes those — and the others (wedge: a second raw value and an exp; tail:
+// log1p pairs) are only QUEUED here, {relative position, 128-bit generator state}, in the workgroup's own
+// segment of a list, for zig_slow_kernel.  With 1.2 % of the lanes taking those branches, half of all
+// wavefront trips used to pay for them (49 us for 5.8 M positions; the fast part alone is bound by its 9 B
+// of stores per position).  A segment that is full (128 entries for ~40 expected) makes the lane take the
+// branches in place, as before.
+// mult^(2^b) and the matching increments, b = 0 .. 39: a thread reaches its stream position with one 128-bit
+// multiply-add per SET BIT of the distance applied to the state itself (~11 for 5.8 M positions) instead of
+// composing (A, C) with the two squarings per bit of lcg_jump() (~60): the jump-ahead, not the classification,
+// was most of the kernel with 22 positions per thread.
+constexpr int kJumpBits = 40;
+struct JumpTable {
+    U128 m[kJumpBits], p[kJumpBits];
+};
+static JumpTable make_jump_table(U128 inc) {
+    JumpTable t;
+    U128 cur_mult = pcg_mult(), cur_plus = inc;
+    for (int b = 0; b < kJumpBits; ++b) {
+        t.m[b] = cur_mult;
+        t.p[b] = cur_plus;
+        cur_plus = mul128(add128(cur_mult, U128{0, 1}), cur_plus);
+        cur_mult = mul128(cur_mult, cur_mult);
+    }
+    return t;
+}
+__device__ __forceinline__ U128 jump_state(U128 s, uint64_t delta, const JumpTable& jt) {
+    for (int b = 0; delta != 0 && b < kJumpBits; ++b, delta >>= 1)
+        if (delta & 1) s = add128(mul128(jt.m[b], s), jt.p[b]);
+    return s;
+}
+
+struct SlowEntry {
+    uint64_t state_hi, state_lo;
+    uint32_t rel;
+    uint32_t pad;
+};
+constexpr int kSlowPerBlock = 128;
+constexpr int kRngBlocksMax = 4096;
+
+__global__ __launch_bounds__(kBlock) void pcg_uniform_classify_kernel(PcgArgs a, JumpTable jt, U128 step_mult,
+                                                                      int64_t n_uniform, int64_t n_rel, ZigTables t,
                                                                       double* __restrict__ uniforms,
                                                                       double* __restrict__ val,
                                                                       uint8_t* __restrict__ len,
-                                                                      int64_t* __restrict__ result) {
+                                                                      int64_t* __restrict__ result,
+                                                                      SlowEntry* __restrict__ slow,
+                                                                      uint32_t* __restrict__ slow_count) {
+    __shared__ unsigned queued;
+    __shared__ uint64_t s_ki[256];          // the two tables every draw looks up, in LDS: a wave's 64 random
+    __shared__ double s_wi[256];            // 8-byte gathers cost ~10 us of the kernel's 28 from the vector L1
+    s_ki[threadIdx.x] = t.ki[threadIdx.x];
+    s_wi[threadIdx.x] = t.wi[threadIdx.x];
+    if (threadIdx.x == 0) queued = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) result[0] = result[1] = 0;
+    __syncthreads();
     const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     const int64_t n = n_uniform + n_rel;
-    if (g >= n) return;
-    U128 A, C;
-    lcg_jump(a.inc, (uint64_t)g + 1, A, C);
-    U128 s = add128(mul128(A, a.state), C);
-    for (int64_t j = g; j < n; j += stride) {
-        if (j < n_uniform) {
-            uniforms[j] = next_double(pcg_output(s));
-        } else {
-            const int64_t i = j - n_uniform;
-            U128 c = s;
-            uint8_t l;
-            val[i] = zig_classify_one([&]() {
-                const uint64_t r = pcg_output(c);
-                c = add128(mul128(step_mult, c), a.inc);
-                return r;
-            }, n_rel - i, t, &l);
-            len[i] = l;
+    if (g < n) {
+        U128 s = jump_state(a.state, (uint64_t)g + 1, jt);
+        for (int64_t j = g; j < n; j += stride) {
+            const uint64_t raw = pcg_output(s);
+            if (j < n_uniform) {
+                uniforms[j] = next_double(raw);
+            } else {
+                const int64_t i = j - n_uniform;
+                uint64_t r = raw;
+                const int idx = (int)(r & 0xff);
+                r >>= 8;
+                const int sign = (int)(r & 0x1);
+                const uint64_t rabs = (r >> 1) & 0x000fffffffffffffULL;
+                double x = (double)rabs * s_wi[idx];
+                if (sign) x = -x;
+                uint8_t l = 1;
+                if (!(rabs < s_ki[idx])) {
+                    const unsigned slot = atomicAdd(&queued, 1u);             // (LDS)
+                    if (slot < (unsigned)kSlowPerBlock) {
+                        slow[(int64_t)blockIdx.x * kSlowPerBlock + slot] = SlowEntry{s.hi, s.lo, (uint32_t)i, 0u};
+                    } else {                                                   // segment full: here and now
+                        U128 c = s;
+                        x = zig_classify_one([&]() {
+                            const uint64_t v = pcg_output(c);
+                            c = add128(mul128(step_mult, c), a.inc);
+                            return v;
+                        }, n_rel - i, t, &l);
+                    }
+                }
+                val[i] = x;
+                len[i] = l;
+            }
+            s = add128(mul128(a.strideA, s), a.strideC);
         }
-        s = add128(mul128(a.strideA, s), a.strideC);
     }
+    __syncthreads();
+    if (threadIdx.x == 0) slow_count[blockIdx.x] = queued < (unsigned)kSlowPerBlock ? queued : (unsigned)kSlowPerBlock;
+}
+
+// the queued draws: wedge and tail of the ziggurat, from the generator state the entry carries
+__global__ __launch_bounds__(kSlowPerBlock) void zig_slow_kernel(U128 inc, U128 step_mult, int64_t n_rel, ZigTables t,
+                                                                  const SlowEntry* __restrict__ slow,
+                                                                  const uint32_t* __restrict__ slow_count,
+                                                                  double* __restrict__ val, uint8_t* __restrict__ len) {
+    if (threadIdx.x >= slow_count[blockIdx.x]) return;
+    const SlowEntry e = slow[(int64_t)blockIdx.x * kSlowPerBlock + threadIdx.x];
+    U128 c{e.state_hi, e.state_lo};
+    const int64_t i = e.rel;
+    uint8_t l;
+    val[i] = zig_classify_one([&]() {
+        const uint64_t v = pcg_output(c);
+        c = add128(mul128(step_mult, c), inc);
+        return v;
+    }, n_rel - i, t, &l);
+    len[i] = l;
 }
 
 // flag[i] = 1 iff a normal really starts at raw position i (i >= first).
@@ -436,7 +520,9 @@ int obe_pcg64_uniform(const uint64_t* d_raw, int64_t n, double* d_out, void* str
 int64_t obe_ziggurat_workspace_bytes(int64_t n_raw) {
     if (n_raw < 1) n_raw = 1;
     const int64_t nb = (n_raw + kFlagTile - 1) / kFlagTile;
-    return n_raw * (8 + 1 + 1) + nb * 4 + 1024;       // candidate values, byte flags (padded to 8), lengths, block sums
+    // candidate values, byte flags (padded to 8), lengths, block sums + the queue of the draws that leave their
+    // ziggurat rectangle (a segment per workgroup of the classification)
+    return n_raw * (8 + 1 + 1) + nb * 4 + 1024 + (int64_t)kRngBlocksMax * (kSlowPerBlock * (int64_t)sizeof(SlowEntry) + 4) + 64;
 }
 
 struct ZigWs {
@@ -445,6 +531,8 @@ struct ZigWs {
     uint8_t* flag;       // start flags, one byte per position (padded to 8)
     uint32_t* sums;      // starts per tile of 2048 positions
     uint8_t* len;        // raw values a normal starting here consumes (8-byte aligned: staged 8 at a time)
+    SlowEntry* slow;     // kRngBlocksMax segments of kSlowPerBlock queued draws
+    uint32_t* slow_count;
     int64_t nb;
 };
 static ZigWs zig_carve(void* d_ws, int64_t n_raw) {
@@ -457,6 +545,9 @@ static ZigWs zig_carve(void* d_ws, int64_t n_raw) {
     w.flag = reinterpret_cast<uint8_t*>(base + 64 + n_raw * 8);
     w.sums = reinterpret_cast<uint32_t*>(w.flag + n_pad);
     w.len = reinterpret_cast<uint8_t*>(w.sums + (w.nb + 1) / 2 * 2);
+    uintptr_t q = (reinterpret_cast<uintptr_t>(w.len + n_pad) + 15) & ~uintptr_t(15);
+    w.slow = reinterpret_cast<SlowEntry*>(q);
+    w.slow_count = reinterpret_cast<uint32_t*>(w.slow + (int64_t)kRngBlocksMax * kSlowPerBlock);
     return w;
 }
 static ZigTables zig_tables(const void* d_tables) {
@@ -528,14 +619,20 @@ int obe_pcg64_uniforms_classify(const uint64_t* h_state4, int64_t n_uniform, int
     a.inc = U128{h_state4[2], h_state4[3]};
     if ((a.inc.lo & 1) == 0) return bad_arg("obe_pcg64_uniforms_classify: PCG64 increment must be odd");
     const int64_t total = n_uniform + n_raw_normal;
-    static const int cap = getenv("OBE_RNG_BLOCKS") ? atoi(getenv("OBE_RNG_BLOCKS")) : 1024;      // tuning aid: 51 us at 1024, 59 at 2048, 71 at 256 (5.8 M positions)
+    static const int forced = getenv("OBE_RNG_BLOCKS") ? atoi(getenv("OBE_RNG_BLOCKS")) : 0;      // tuning aid
+    const int cap = forced > 0 && forced <= kRngBlocksMax ? forced : 1024;       // 34 us at 1024 (5.8 M positions), 36 at 2048, 45 at 512
     const int blocks = static_cast<int>(std::min<int64_t>(cap, (total + kBlock - 1) / kBlock));
     lcg_jump(a.inc, (uint64_t)blocks * kBlock, a.strideA, a.strideC);
     const ZigWs w = zig_carve(d_ws, n_raw_normal);
-    pcg_uniform_classify_kernel<<<blocks, kBlock, 0, as_stream(stream)>>>(a, pcg_mult(), n_uniform, n_raw_normal,
-                                                                           zig_tables(d_tables), d_uniforms, w.val, w.len,
-                                                                           w.result);
+    const ZigTables t = zig_tables(d_tables);
+    pcg_uniform_classify_kernel<<<blocks, kBlock, 0, as_stream(stream)>>>(a, make_jump_table(a.inc), pcg_mult(), n_uniform,
+                                                                           n_raw_normal, t,
+                                                                           d_uniforms, w.val, w.len, w.result, w.slow,
+                                                                           w.slow_count);
     OBE_CHECK_LAUNCH("pcg_uniform_classify_kernel");
+    zig_slow_kernel<<<blocks, kSlowPerBlock, 0, as_stream(stream)>>>(a.inc, pcg_mult(), n_raw_normal, t, w.slow,
+                                                                      w.slow_count, w.val, w.len);
+    OBE_CHECK_LAUNCH("zig_slow_kernel");
     return 0;
 }
 
