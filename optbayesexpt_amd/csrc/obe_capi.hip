@@ -1,5 +1,6 @@
 // Library-level entry points: error reporting, model validation, device query, timers.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include <atomic>
@@ -12,9 +13,19 @@
 
 namespace obe {
 
+// How long the host spins on the result words before it hands the wait to hipStreamSynchronize (microseconds;
+// OBE_HOST_SPIN_US overrides).  While it spins it asks the stream every 50 us whether it has failed or drained
+// (hipStreamQuery, ~1 us), so a kernel that faulted or never delivered is still reported.
+static double host_spin_us() {
+    static const double us = getenv("OBE_HOST_SPIN_US") ? atof(getenv("OBE_HOST_SPIN_US")) : kHostWaitSpinUs;
+    return us;
+}
+
 int wait_host_words(const void* h_words, int64_t n, hipStream_t st) {
     const volatile uint64_t* p = static_cast<const volatile uint64_t*>(h_words);
     const auto t0 = std::chrono::steady_clock::now();
+    const double limit = host_spin_us();
+    double next_query = 50.0;
     int64_t next = n - 1;            // words are checked from the last one down; `next` is the highest still armed
     for (;;) {
         for (int i = 0; i < 64; ++i) {
@@ -27,7 +38,14 @@ int wait_host_words(const void* h_words, int64_t n, hipStream_t st) {
             __builtin_ia32_pause();
 #endif
         }
-        if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > kHostWaitSpinUs) break;
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (us > limit) break;
+        if (us > next_query) {
+            next_query = us + 50.0;
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) break;                          // drained: the words are there, or never will be
+            if (q != hipErrorNotReady) return fail(q, "kernel failed while its host results were awaited");
+        }
     }
     OBE_HIP_TRY(hipStreamSynchronize(st));       // long kernel, or one that never delivered: the stream knows
     return 0;
