@@ -148,6 +148,22 @@ int obe_bayes_update_model_moments(const obe_model* m,
                                    const double* h_sigma, const int32_t* h_noise_rows,
                                    int32_t n_lik_channels, double choke, double* d_moments,
                                    void* d_ws, int64_t ws_bytes, double* h_out, void* stream);
+
+/* The same update, enqueued only: returns without waiting.  h_pinned_out (page-locked, 5 + 4 n_params
+ * doubles) is armed here and written by the update's last kernel: [0] sum t, [1] sum w'^2, [2..) the K3
+ * first-moment block, and [4 + 4 n_params] = 1.0 if auto_resample != 0 and the resample test of
+ * particlepdf.py:236-258 on sum w'^2 (N_eff < 0.1 N or N_eff / N < resample_threshold) says "resample",
+ * else 0.0 — wait with obe_host_words_wait(h_pinned_out, 5 + 4 n_params, stream).  The same decision stays
+ * on the device for an obe_sweep_utility(OBE_SWEEP_SPECULATIVE) call enqueued next on this stream, which
+ * hides the host round trip of the update behind the sweep (the reference's cycle is update -> resample
+ * test -> next opt_setting: obe_base.py:340-399, 733-756).  Needs the library's per-stream control words
+ * (at most 256 streams per device): -1 otherwise, and the caller uses the synchronous form. */
+int obe_bayes_update_model_moments_enqueue(const obe_model* m, const double* d_particles, int64_t ld_p,
+                                           int64_t n_particles, double* d_weights, const double* h_setting,
+                                           const double* h_y_meas, const double* h_sigma,
+                                           const int32_t* h_noise_rows, int32_t n_lik_channels, double choke,
+                                           double* d_moments, void* d_ws, int64_t ws_bytes, double* h_pinned_out,
+                                           int32_t auto_resample, double resample_threshold, void* stream);
 /* A whole sweep of measurements (demos/sweeper/obe_sweeper.py:86-100: one pdf_update per point,
  * each followed by the resample test of particlepdf.py:236-258) enqueued back to back, no
  * host round trip between the points.  h_settings (n_points, OBE_MAX_SETDIMS) and h_y_meas
@@ -363,6 +379,14 @@ int obe_power_normalize(const double* d_u, int64_t n, double exponent, double* d
  * is known, while the renormalisation it implies may still be running. */
 #define OBE_SWEEP_SHIFTED 1
 #define OBE_SWEEP_SAFE 2
+/* OBE_SWEEP_SPECULATIVE (full sweeps only): the call is enqueued behind
+ * obe_bayes_update_model_moments_enqueue() on the same stream and returns at once.  Its kernels read the
+ * resample decision that update left on the device and do nothing if it was "resample" (the cloud is about
+ * to change: particlepdf.py:236-258).  Page-locked h_best / h_best_idx / h_kappa are armed, not waited
+ * for: the caller first learns from the update's host block (word 4 + 4 n_params) whether the sweep ran,
+ * and only then waits for the words with obe_host_words_wait().  An aborted call leaves them armed and the
+ * device outputs (yvar, utility, the result record) untouched. */
+#define OBE_SWEEP_SPECULATIVE 8
 /* Settings one lane of the sweep kernel owns for a grid of n_settings (1, 2, 4 or 8): the number
  * of denominators a model's fast form inverts together, which a caller that predicts whether a
  * settings grid stays inside that form's range needs (optbayesexpt_amd/models.py: range_hint). */

@@ -20,7 +20,8 @@ OBE_MAX_CHANNELS = 4
 OBE_MAX_SETDIMS = 4
 OBE_MAX_DIMS = 16
 OBE_WS_RESULT_OFFSET = 2      # doubles; include/obe_hip.h
-OBE_SWEEP_SHIFTED, OBE_SWEEP_SAFE = 1, 2      # bits of obe_sweep_utility's `shifted` argument
+HOST_SENTINEL = 0x7ff8c0dec0dec0de     # the value of an armed host result word (csrc/obe_common.h: kHostSentinel)
+OBE_SWEEP_SHIFTED, OBE_SWEEP_SAFE, OBE_SWEEP_SPECULATIVE = 1, 2, 8      # bits of obe_sweep_utility's `shifted` argument
 
 c_void_p, c_int, c_int32, c_int64, c_double = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int32,
                                                ctypes.c_int64, ctypes.c_double)
@@ -58,6 +59,9 @@ _SIGNATURES = {
                                        c_int32, c_double, _P, c_int64, _P, _P]),
     "obe_bayes_update_model_moments": (c_int, [ctypes.POINTER(ObeModelStruct), _P, c_int64, c_int64, _P, _P, _P, _P, _P,
                                                c_int32, c_double, _P, _P, c_int64, _P, _P]),
+    "obe_bayes_update_model_moments_enqueue": (c_int, [ctypes.POINTER(ObeModelStruct), _P, c_int64, c_int64, _P, _P, _P,
+                                                       _P, _P, c_int32, c_double, _P, _P, c_int64, _P, c_int32,
+                                                       c_double, _P]),
     "obe_bayes_update_sweep": (c_int, [ctypes.POINTER(ObeModelStruct), _P, c_int64, c_int64, _P, _P, _P, _P, _P,
                                        c_int32, c_double, c_int64, c_int32, c_double, _P, c_int64, _P, _P]),
     "obe_bayes_update_y": (c_int, [_P, c_int64, c_int32, _P, c_int64, c_int64, _P, _P, _P, _P, c_int32,
@@ -123,7 +127,8 @@ _SIGNATURES = {
 
 # entry points whose code depends on the model: a plugin library serves these
 MODEL_ENTRY_POINTS = ("obe_model_validate", "obe_workspace_bytes", "obe_sweep_settings_per_lane", "obe_bayes_update_model",
-                      "obe_bayes_update_model_moments", "obe_bayes_update_sweep",
+                      "obe_bayes_update_model_moments", "obe_bayes_update_model_moments_enqueue",
+                      "obe_bayes_update_sweep",
                       "obe_eval_over_particles",
                       "obe_eval_over_settings", "obe_sweep_utility", "obe_sweep_kernel_time", "obe_sweep_timing",
                       "obe_eval_draws")

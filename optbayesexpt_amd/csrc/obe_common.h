@@ -117,6 +117,10 @@ __device__ __forceinline__ double load_published_f64(const double* p) {
 constexpr int kArriveGroups = 8;
 constexpr int kArriveStride = 32;                       // words between two counters: one 128-byte line each
 constexpr int kControlSlotWords = kArriveStride * (kArriveGroups + 1);
+// a word of the top counter's line that no ticket touches: written by the enqueue form of the fused update
+// (1: this update is followed by a resample), read by the kernels of a sweep enqueued behind it
+// (obe_sweep.hip: OBE_SWEEP_SPECULATIVE), which then do nothing
+constexpr int kAbortWord = kArriveStride * kArriveGroups + 16;
 template <bool ACQUIRE = true>
 __device__ __forceinline__ bool arrive_last(unsigned* counter, int* flag) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores

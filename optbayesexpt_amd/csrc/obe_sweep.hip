@@ -123,13 +123,21 @@ struct SweepArgs {
     double* part1;
     double* part2;
     double* cs_out;            // (C, ns): the shift each setting used (0 when unshifted)
+    const unsigned* abort;     // OBE_SWEEP_SPECULATIVE: the stream's abort word (non-zero: do nothing), else NULL
 };
+
+// A speculative sweep (enqueued behind an update whose resample decision was not waited for) does nothing
+// when that update said "resample": every kernel of the call starts with this test.
+__device__ __forceinline__ bool sweep_aborted(const unsigned* abort) {
+    return abort && __builtin_amdgcn_readfirstlane(*abort) != 0u;
+}
 
 // Every draw packed once per sweep: M::pack() (per-particle divisions, sqrt(w) folded into the
 // amplitudes) and sqrt(w), one 16-byte-aligned record per draw.
 template <class M>
 __global__ __launch_bounds__(kBlock) void sweep_pack_kernel(SweepArgs a) {
     constexpr int NPK = M::NPK, NPKW = packed_width<M>();
+    if (sweep_aborted(a.abort)) return;
     const double* __restrict__ thbar = a.moments + 2;   // weighted-mean parameters (K3 output)
     for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < a.nd; p += (int64_t)gridDim.x * kBlock) {
         int64_t src = p;
@@ -190,7 +198,7 @@ __global__ __launch_bounds__(kBlock) OBE_SWEEP_OCCUPANCY void sweep_kernel(Sweep
         chunk_id = blockIdx.x / a.tiles_x;
         tile_x = blockIdx.x % a.tiles_x;
     }
-    if (chunk_id >= a.nchunks) return;
+    if (chunk_id >= a.nchunks || sweep_aborted(a.abort)) return;
     const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
 
     double xs[SPT][NXS], cs[SPT][NC], s1[SPT][NC], s2[SPT][NC];
@@ -455,9 +463,11 @@ __global__ __launch_bounds__(FG * kWave) void sweep_finalize(const double* __res
                                                              const double* __restrict__ cs,
                                                              double* __restrict__ yvar,
                                                              double* __restrict__ utility, double* __restrict__ bv,
-                                                             int64_t* __restrict__ bi, double* __restrict__ bk) {
+                                                             int64_t* __restrict__ bi, double* __restrict__ bk,
+                                                             const unsigned* abort) {
     __shared__ double acc1[OBE_MAX_CHANNELS][FG][kFinSettings];
     __shared__ double acc2[OBE_MAX_CHANNELS][FG][kFinSettings];
+    if (sweep_aborted(abort)) return;
     const double W = full_mode ? moments[0] : 1.0;
     const int lane = threadIdx.x & (kWave - 1), grp = threadIdx.x / kWave;
     const int64_t s = (int64_t)blockIdx.x * kFinSettings + lane;
@@ -556,7 +566,9 @@ __global__ __launch_bounds__(kBlock) void argmax_kernel(const double* __restrict
 __global__ __launch_bounds__(kBlock) void argmax_fold(const double* __restrict__ bv, const int64_t* __restrict__ bi,
                                                       int nb, const double* __restrict__ bk,
                                                       double* __restrict__ out_v,
-                                                      int64_t* __restrict__ out_i, HostResult host) {
+                                                      int64_t* __restrict__ out_i, HostResult host,
+                                                      const unsigned* abort = nullptr) {
+    if (sweep_aborted(abort)) return;       // (the armed host words stay armed: nobody reads this result)
     Best best{-INFINITY, INT64_MAX};
     for (int b = threadIdx.x; b < nb; b += kBlock) {
         Best cand{bv[b], bi[b]};
@@ -692,8 +704,25 @@ struct SweepTiming {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     double total_ms = 0.0;
     int64_t launches = 0;
+    bool pending = false;      // a speculative call's events have not been read yet
+    double pending_min_ms = 0.0;
 };
 static SweepTiming g_timing;
+
+// A speculative call returns before its kernels have run: its pair of events is read at the next timed call
+// or query.  An aborted sweep (its update resampled) is not a sweep: shorter than any kernel could sweep
+// that many evaluations (half of 8e12 evaluations/s, well above this chip's rate), it is left out.
+static void resolve_pending_timing() {
+    if (!g_timing.pending) return;
+    g_timing.pending = false;
+    float ms = 0.f;
+    if (hipEventSynchronize(g_timing.e1) != hipSuccess) return;
+    if (hipEventElapsedTime(&ms, g_timing.e0, g_timing.e1) != hipSuccess) return;
+    if (ms >= g_timing.pending_min_ms) {
+        g_timing.total_ms += ms;
+        g_timing.launches += 1;
+    }
+}
 
 struct SweepWs {
     double* part1;
@@ -875,6 +904,16 @@ int obe_sweep_utility(const obe_model* m, const double* d_settings, int64_t ld_s
         return rc;
     hipStream_t st = as_stream(stream);
     UtilArgs ua{d_noise_var, noise_ld, d_cost, cost_scalar};
+    const bool speculative = shifted & OBE_SWEEP_SPECULATIVE;
+    if (speculative) {
+        if (d_draw_idx) return bad_arg("obe_sweep_utility: OBE_SWEEP_SPECULATIVE is for full sweeps");
+        unsigned* control = stream_control_words(st);
+        if (!control) return bad_arg("obe_sweep_utility: no control words for this stream");
+        a.abort = control + kAbortWord;
+        if ((h_best && !device_view_of_host(h_best)) || (h_best_idx && !device_view_of_host(h_best_idx)) ||
+            (h_kappa && !device_view_of_host(h_kappa)))
+            return bad_arg("obe_sweep_utility: OBE_SWEEP_SPECULATIVE needs page-locked host outputs");
+    }
     const HostResult hr = host_result(h_best, h_best_idx, h_kappa);
     static const bool no_small = getenv("OBE_SWEEP_NO_SMALL") != nullptr;      // test / tuning aid
     if (d_draw_idx && !no_small && n_draws <= kSmallSweepDraws && n_settings * n_draws <= kSmallSweepEvals) {
@@ -900,6 +939,7 @@ int obe_sweep_utility(const obe_model* m, const double* d_settings, int64_t ld_s
     // sweep kernel's end event instead of for the result)
     const bool timed = g_timing.on;
     if (timed) {
+        resolve_pending_timing();
         int dev = 0;
         OBE_HIP_TRY(hipGetDevice(&dev));
         if (g_timing.device != dev) {
@@ -923,14 +963,21 @@ int obe_sweep_utility(const obe_model* m, const double* d_settings, int64_t ld_s
     if (plan.nchunks >= kFinManyChunks)
         sweep_finalize<kFinGroupsMany><<<nb, kFinGroupsMany * kWave, 0, st>>>(
             w.part1, w.part2, plan.nchunks, mm.n_channels, n_settings, d_moments, d_draw_idx == nullptr, ua, w.cs,
-            d_yvar, d_utility, w.bv, w.bi, w.bk);
+            d_yvar, d_utility, w.bv, w.bi, w.bk, a.abort);
     else
         sweep_finalize<kFinGroupsFew><<<nb, kFinGroupsFew * kWave, 0, st>>>(
             w.part1, w.part2, plan.nchunks, mm.n_channels, n_settings, d_moments, d_draw_idx == nullptr, ua, w.cs,
-            d_yvar, d_utility, w.bv, w.bi, w.bk);
+            d_yvar, d_utility, w.bv, w.bi, w.bk, a.abort);
     OBE_CHECK_LAUNCH("sweep_finalize");
-    argmax_fold<<<1, kBlock, 0, st>>>(w.bv, w.bi, nb, w.bk, w.out_v, w.out_i, hr);
+    argmax_fold<<<1, kBlock, 0, st>>>(w.bv, w.bi, nb, w.bk, w.out_v, w.out_i, hr, a.abort);
     OBE_CHECK_LAUNCH("argmax_fold");
+    if (speculative) {          // nobody waits here: the caller watches the armed words when it wants the result
+        if (timed) {
+            g_timing.pending = true;
+            g_timing.pending_min_ms = 0.5 * (double)n_settings * (double)n_particles / 8e9;
+        }
+        return 0;
+    }
     rc = read_best(w, h_best, h_best_idx, st, h_kappa, hr);
     if (timed && !rc && !(h_best || h_best_idx || h_kappa)) rc = (int)hipEventSynchronize(g_timing.e1);
     if (timed && !rc) {                       // the stream is drained: both events have completed
@@ -944,6 +991,7 @@ int obe_sweep_utility(const obe_model* m, const double* d_settings, int64_t ld_s
 }
 
 int obe_sweep_timing(int32_t enable, double* h_total_ms, int64_t* h_launches) {
+    resolve_pending_timing();
     if (h_total_ms) *h_total_ms = g_timing.total_ms;
     if (h_launches) *h_launches = g_timing.launches;
     if (enable >= 0) {

@@ -183,6 +183,12 @@ struct UpdateFold {
     double* scalars;            // [0] sum t, [1] sum w'^2
     double* mom_out;            // K3 block on the device
     double* host_out;           // device view of the caller's page-locked h_out, or NULL
+    // enqueue form (obe_bayes_update_model_moments_enqueue): the resample test of particlepdf.py:236-258 on
+    // sum w'^2, left in the stream's abort word for the sweep that was enqueued behind this update without
+    // waiting for it (obe_sweep.hip: OBE_SWEEP_SPECULATIVE), and in host_out[4 + 4 d] as 0.0 / 1.0
+    unsigned* abort_out;        // NULL: not the enqueue form
+    double n_particles, threshold;
+    int auto_resample;
 };
 
 template <int D, bool FOLD>
@@ -228,6 +234,11 @@ __global__ __launch_bounds__(kBlock) void normalize_moments_kernel(const double*
                 fold.scalars[0] = total;
                 fold.scalars[1] = b;
                 if (fold.host_out) fold.host_out[0] = total;
+                if (fold.abort_out) {
+                    const bool due = fold.auto_resample && resample_due(b, fold.n_particles, fold.threshold);
+                    *fold.abort_out = due ? 1u : 0u;
+                    if (fold.host_out) fold.host_out[4 + 4 * D] = due ? 1.0 : 0.0;
+                }
             }
             if (fold.host_out) {
                 host_results_before_flag();
@@ -588,11 +599,11 @@ int obe_bayes_update_model(const obe_model* m, const double* d_particles, int64_
     return finish_update(w, nb, n_particles, d_weights, h_out, st);
 }
 
-int obe_bayes_update_model_moments(const obe_model* m, const double* d_particles, int64_t ld_p, int64_t n_particles,
-                                   double* d_weights, const double* h_setting, const double* h_y_meas,
-                                   const double* h_sigma, const int32_t* h_noise_rows, int32_t n_lik_channels,
-                                   double choke, double* d_moments, void* d_ws, int64_t ws_bytes, double* h_out,
-                                   void* stream) {
+static int update_model_moments(const obe_model* m, const double* d_particles, int64_t ld_p, int64_t n_particles,
+                                double* d_weights, const double* h_setting, const double* h_y_meas,
+                                const double* h_sigma, const int32_t* h_noise_rows, int32_t n_lik_channels,
+                                double choke, double* d_moments, void* d_ws, int64_t ws_bytes, double* h_out,
+                                void* stream, bool enqueue_only, int32_t auto_resample, double resample_threshold) {
     if (!m || !d_particles || !d_weights || !d_moments || n_particles <= 0)
         return bad_arg("obe_bayes_update_model_moments: bad pointer/size");
     obe_model mm = *m;
@@ -618,12 +629,16 @@ int obe_bayes_update_model_moments(const obe_model* m, const double* d_particles
     if (rc) return rc;
     const int nm = moment_blocks(n_particles, d);
     double* hv = static_cast<double*>(device_view_of_host(h_out));
-    if (hv) arm_host_words(h_out, 2 + 2 + 4 * (int64_t)d);      // every word of the result block is watched
+    const int64_t n_words = 2 + 2 + 4 * (int64_t)d + (enqueue_only ? 1 : 0);
+    if (enqueue_only && !hv) return bad_arg("obe_bayes_update_model_moments_enqueue: h_out must be page-locked");
+    if (hv) arm_host_words(h_out, n_words);      // every word of the result block is watched
     // the fold rides in the normalisation launch (its last workgroup to arrive) unless there is no counter
     // for this stream or OBE_UPDATE_FOLD=separate asks for the round-3 shape (A/B measurements)
     static const bool separate = getenv("OBE_UPDATE_FOLD") && !strcmp(getenv("OBE_UPDATE_FOLD"), "separate");
-    unsigned* counter = separate ? nullptr : stream_control_words(st);
-    const UpdateFold fold{counter, w.scalars, d_moments, hv};
+    unsigned* counter = separate && !enqueue_only ? nullptr : stream_control_words(st);
+    if (enqueue_only && !counter) return bad_arg("obe_bayes_update_model_moments_enqueue: no control words for this stream");
+    const UpdateFold fold{counter, w.scalars, d_moments, hv, enqueue_only ? counter + kAbortWord : nullptr,
+                          (double)n_particles, resample_threshold, auto_resample};
 #define OBE_UPD_MOM_CASE(DD)                                                                                           \
     case DD:                                                                                                           \
         if (counter)                                                                                                   \
@@ -645,8 +660,9 @@ int obe_bayes_update_model_moments(const obe_model* m, const double* d_particles
         fold_update_moments_kernel<<<1, kFoldThreads, 0, st>>>(w.pa, nb, w.pb, nm, w.mom, d, w.scalars, d_moments, hv);
         OBE_CHECK_LAUNCH("fold_update_moments_kernel");
     }
+    if (enqueue_only) return 0;
     if (h_out) {
-        if (hv) return wait_host_words(h_out, 2 + 2 + 4 * (int64_t)d, st);
+        if (hv) return wait_host_words(h_out, n_words, st);
         {
             OBE_HIP_TRY(hipMemcpyAsync(h_out, w.scalars, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
             OBE_HIP_TRY(hipMemcpyAsync(h_out + 2, d_moments, (2 + 4 * (int64_t)d) * sizeof(double),
@@ -655,6 +671,28 @@ int obe_bayes_update_model_moments(const obe_model* m, const double* d_particles
         OBE_HIP_TRY(hipStreamSynchronize(st));
     }
     return 0;
+}
+
+int obe_bayes_update_model_moments(const obe_model* m, const double* d_particles, int64_t ld_p, int64_t n_particles,
+                                   double* d_weights, const double* h_setting, const double* h_y_meas,
+                                   const double* h_sigma, const int32_t* h_noise_rows, int32_t n_lik_channels,
+                                   double choke, double* d_moments, void* d_ws, int64_t ws_bytes, double* h_out,
+                                   void* stream) {
+    return update_model_moments(m, d_particles, ld_p, n_particles, d_weights, h_setting, h_y_meas, h_sigma,
+                                h_noise_rows, n_lik_channels, choke, d_moments, d_ws, ws_bytes, h_out, stream, false, 0,
+                                0.0);
+}
+
+int obe_bayes_update_model_moments_enqueue(const obe_model* m, const double* d_particles, int64_t ld_p,
+                                           int64_t n_particles, double* d_weights, const double* h_setting,
+                                           const double* h_y_meas, const double* h_sigma,
+                                           const int32_t* h_noise_rows, int32_t n_lik_channels, double choke,
+                                           double* d_moments, void* d_ws, int64_t ws_bytes, double* h_pinned_out,
+                                           int32_t auto_resample, double resample_threshold, void* stream) {
+    if (!h_pinned_out) return bad_arg("obe_bayes_update_model_moments_enqueue: h_pinned_out is NULL");
+    return update_model_moments(m, d_particles, ld_p, n_particles, d_weights, h_setting, h_y_meas, h_sigma,
+                                h_noise_rows, n_lik_channels, choke, d_moments, d_ws, ws_bytes, h_pinned_out, stream,
+                                true, auto_resample, resample_threshold);
 }
 
 int obe_bayes_update_sweep(const obe_model* m, const double* d_particles, int64_t ld_p, int64_t n_particles,

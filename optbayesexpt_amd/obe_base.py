@@ -50,6 +50,10 @@ SELECTION_METHODS = ["optimal", "good", "random"]
 _OVERRIDDEN = {}
 
 
+# default of tuning_parameters['speculative_sweep'] (A/B measurements: OBE_SPECULATIVE_SWEEP=0 / 1 / auto)
+_SPECULATIVE_DEFAULT = {"0": False, "1": True}.get(os.environ.get("OBE_SPECULATIVE_SWEEP", "auto"), "auto")
+
+
 def _overridden(obj, name, *owners):
     """True if ``obj``'s class replaces method ``name`` defined by one of ``owners`` (answered once
     per class: the hooks are looked up several times in every cycle)."""
@@ -400,9 +404,13 @@ class OptBayesExpt(ParticlePDF):
             if self._parameters is self._particles and self.tuning_parameters.get("fused_moments", True):
                 # ... and the first moments of the posterior in the same pass over the cloud: the next
                 # sweep's shift, mean(), std() and the noise-parameter variance need no launch of their own
-                self._mlib.call("obe_bayes_update_model_moments", *args, _ptr(self._moments_dev), _ptr(self._ws),
-                                self._ws_bytes, self._hargs.ptr_keep(self._upd_host), self._stream())
-                self._after_weight_update(self._upd_host[1], moments_fresh=True)
+                self._drop_speculative_sweep()
+                if self._speculation_wanted():
+                    self._update_then_speculate(args)
+                else:
+                    self._mlib.call("obe_bayes_update_model_moments", *args, _ptr(self._moments_dev), _ptr(self._ws),
+                                    self._ws_bytes, self._hargs.ptr_keep(self._upd_host), self._stream())
+                    self._after_weight_update(self._upd_host[1], moments_fresh=True)
             else:       # (a stale `parameters` alias after set_pdf, obe_base.py:185,395: not the cloud the moments describe)
                 self._mlib.call("obe_bayes_update_model", *args, _ptr(self._ws), self._ws_bytes,
                                 hp(self._host_out), self._stream())
@@ -427,7 +435,113 @@ class OptBayesExpt(ParticlePDF):
         self._parameters = self._particles
         if self.just_resampled:
             self.enforce_parameter_constraints()
+        # (the cycle pattern the speculative sweep looks for: a full sweep of exactly this cloud comes next)
+        self._updated_cloud = (self._particles.version, self._weights.version) if fused else None
+        self._resample_rate = 0.8 * self.__dict__.get("_resample_rate", 0.0) + (0.2 if self.just_resampled else 0.0)
         return _LazyState(self)
+
+    # ------------------------------------------------------- speculative sweep
+    # The reference's cycle is opt_setting -> measure -> pdf_update -> opt_setting ... (obe_base.py:733-756,
+    # 340-399): after an update the next thing the device is asked for is, almost always, the sweep over the
+    # updated cloud.  Once that pattern has been seen twice in a row, pdf_update() enqueues the update WITHOUT
+    # waiting for its sums, enqueues that sweep right behind it, and only then waits for the update: the host
+    # round trip of the update, the resample test, the caller's own work between the two calls and the launch
+    # overhead of the sweep are hidden behind the sweep's kernels.  The update kernel leaves its resample
+    # decision on the device; a sweep behind an update that resamples does nothing (the cloud is about to
+    # change) and the real sweep is launched when it is asked for.  Everything is decided again on the host
+    # from the delivered values: the speculative result is used only if the update says the sweep ran, the
+    # cloud is still the one it swept and every input of the sweep is what a fresh launch would use — the
+    # same kernels on the same data, hence the same bits.  tuning_parameters['speculative_sweep']: 'auto'
+    # (default), True (from the first update on), False (never).  Measured (MI355X, tools/spec_cycles.py,
+    # tools/shard_cycle.py): the plain cycle of 4096 settings x 262 144 particles 0.333 -> 0.314 ms, of one
+    # rank's 8192 x 1 048 576 slice 1.877 -> 1.845 ms.
+    def _speculation_wanted(self):
+        mode = self.tuning_parameters.get("speculative_sweep", _SPECULATIVE_DEFAULT)
+        if mode is False or mode == "never" or self.__dict__.get("_spec_unavailable"):
+            return False
+        # 'auto': after two update -> sweep cycles in a row, and while fewer than half of the recent updates
+        # resampled (a sweep behind a resampling update is launched for nothing: ~10-35 us of empty workgroups)
+        if not (mode is True or (self.__dict__.get("_spec_streak", 0) >= 2
+                                 and self.__dict__.get("_resample_rate", 0.0) < 0.5)):
+            return False
+        return (self.utility_method == "variance_full" and self._utility_fusable()
+                and not _overridden(self, "cost_estimate", OptBayesExpt)
+                and self._noise_token() is not None
+                and self._sweep_safe_streak < self.SAFE_STREAK
+                and self.N_DRAWS <= self._ws_draws)
+
+    def _noise_token(self):
+        """What the utility's noise variance depends on besides the cloud (hashable), or None if that cannot
+        be told without calling user code."""
+        if _overridden(self, "yvar_noise_model", OptBayesExpt):
+            return None
+        dns = self.default_noise_std
+        return dns.tobytes() if isinstance(dns, np.ndarray) else None
+
+    def _update_then_speculate(self, args):
+        tp = self.tuning_parameters
+        st = self._stream()
+        d = self.n_dims
+        p_out = self._hargs.ptr_keep(self._upd_host)
+        try:
+            self._mlib.call("obe_bayes_update_model_moments_enqueue", *args, _ptr(self._moments_dev),
+                            _ptr(self._ws), self._ws_bytes, p_out, 1 if tp["auto_resample"] else 0,
+                            float(tp["resample_threshold"]), st)
+        except _lib.ObeHipError:
+            # no control words for this stream (more than 256 streams on the device): the plain form from now on
+            self._spec_unavailable = True
+            self._mlib.call("obe_bayes_update_model_moments", *args, _ptr(self._moments_dev), _ptr(self._ws),
+                            self._ws_bytes, p_out, st)
+            self._after_weight_update(self._upd_host[1], moments_fresh=True)
+            return
+        self._weights.mark_device_written()
+        key = (self._particles.version, self._weights.version)
+        self._mom_dev_key = key + (False,)        # on the device, in stream order: what the sweep reads
+        try:
+            self._sweep_device(False, speculate=True)
+        except _lib.ObeHipError:
+            self._spec_unavailable = True         # (nothing of the sweep was enqueued: refused before any launch)
+        self._lib.call("obe_host_words_wait", p_out, 5 + 4 * d, st)
+        spec = self.__dict__.get("_spec")
+        if spec is not None:
+            spec["ran"] = self._upd_host[4 + 4 * d] == 0.0
+        self._mom_host_key = key + (False,)
+        self._sumsq, self._sumsq_key = float(self._upd_host[1]), self._weights.version
+        if tp["auto_resample"]:
+            self.resample_test()
+
+    def _drop_speculative_sweep(self):
+        """Forget a speculative sweep nobody asked for.  Its kernels may still be running and will write the
+        result words: they are waited for before anything arms those words again."""
+        spec = self.__dict__.get("_spec")
+        if spec is None:
+            return
+        self._spec = None
+        if spec.get("ran") and spec["words"] is not None:
+            self._lib.call("obe_host_words_wait", spec["words"], 3, self._stream())
+            self._spec_streak = 0         # the pattern broke: two plain cycles before the next attempt
+
+    def _take_speculative_sweep(self, shifted):
+        """The result of the speculative sweep if it is the sweep being asked for: (best, index, kappa) for an
+        unsharded object, the device record for a sharded one; None (and the speculation forgotten) if not."""
+        spec = self.__dict__.get("_spec")
+        if spec is None:
+            return None
+        ok = (spec.get("ran") and spec["cloud"] == (self._particles.version, self._weights.version)
+              and spec["shifted"] == shifted and spec["noise"] == self._noise_token()
+              and spec["settings"] == (self._s_begin, self._s_end) and self._parameters is self._particles
+              and not _overridden(self, "cost_estimate", OptBayesExpt))
+        if not ok:
+            self._drop_speculative_sweep()
+            return None
+        self._spec = None
+        if spec["words"] is None:
+            return spec["record"]
+        self._lib.call("obe_host_words_wait", spec["words"], 3, self._stream())
+        block = spec["block"]
+        if np.any(block.view(np.uint64)[:3] == _lib.HOST_SENTINEL):       # drained without delivering: not run
+            return None
+        return float(block[0]), int(block.view(np.int64)[1]), float(block[2])
 
     def _likelihood_overridden(self):
         return _overridden(self, "likelihood", OptBayesExpt)
@@ -509,10 +623,20 @@ class OptBayesExpt(ParticlePDF):
                 and not _overridden(self, "yvar_from_parameter_draws", OptBayesExpt)
                 and not _overridden(self, "eval_over_all_settings", OptBayesExpt))
 
-    def _sweep_device(self, want_best):
+    def _sweep_device(self, want_best, speculate=False):
         """K1 + K5 on this rank's settings slice.  Leaves yvar/utility on the device;
-        returns (best value, best *global* index) if ``want_best``."""
+        returns (best value, best *global* index) if ``want_best``.  ``speculate``: pdf_update()'s launch of
+        the sweep it expects to be asked for next (see _speculation_wanted) — enqueued, nothing read."""
         full = self.utility_method == "variance_full"
+        sharded = self._shard is not None     # every sweep of a sharded object gathers: ranks stay in lockstep
+        if full and not speculate:
+            # update -> full sweep of exactly that cloud, twice in a row: the next update speculates
+            cloud = (self._particles.version, self._weights.version)
+            seen = self.__dict__.get("_updated_cloud")
+            self._updated_cloud = None
+            self._spec_streak = self.__dict__.get("_spec_streak", 0) + 1 if seen == cloud else 0
+        elif not speculate:
+            self._drop_speculative_sweep()
         idx = None
         n_draws = 0
         if not full:
@@ -521,23 +645,17 @@ class OptBayesExpt(ParticlePDF):
             # consumes N_DRAWS uniforms (randdraw); its check of sum(w) waits for the sweep's own sync
             idx = self._draw_indices(self.N_DRAWS, defer_validation=True)
             n_draws = self.N_DRAWS
-        p, w = self._pw_tensors()
-        cost_t, cost_s = self._cost_device()
         n_local = self._s_end - self._s_begin
         res = self.__dict__.get("_sweep_result")
-        if res is None:               # persistent host landing zone of the sweep result, pointers made once
-            best, best_idx, kappa = _lib.pinned_array(1), _lib.pinned_array(1, np.int64), _lib.pinned_array(1)
+        if res is None:               # persistent host landing zone of the sweep result, pointers made once:
+            block = _lib.pinned_array(4)          # {best, index bits, kappa} in three consecutive words
+            best, best_idx, kappa = block[0:1], block.view(np.int64)[1:2], block[2:3]
             res = self._sweep_result = (best, best_idx, kappa, _lib.host_ptr(best), _lib.host_ptr(best_idx),
-                                        _lib.host_ptr(kappa))
-        best, best_idx, kappa, p_best, p_best_idx, p_kappa = res
+                                        _lib.host_ptr(kappa), block)
+        best, best_idx, kappa, p_best, p_best_idx, p_kappa, block = res
         s_ptr = _P(self._settings_dev.data_ptr() + 8 * self._s_begin)
-        noise, noise_ld = self._noise_var_device()
-        # last, so that the moments kernels and the sweep are enqueued back to back (every idle
-        # microsecond before the sweep kernel also costs clock ramp-up inside it)
-        mom = self._moments_on_device()
 
-        sharded = self._shard is not None     # every sweep of a sharded object gathers: ranks stay in lockstep
-        if sharded:
+        if sharded and not speculate:
             every = int(self.tuning_parameters.get("replica_check_every", 64) or 0)
             self._sharded_sweeps += 1
             if every > 0 and self._sharded_sweeps % every == 0:
@@ -549,26 +667,48 @@ class OptBayesExpt(ParticlePDF):
         # synchronise; the deferred check of sum(w) happens at the caller's own synchronisation.
         lazy = (not want_best and not full and not sharded
                 and not getattr(self._device_model, "safe_sweep", False))
+        off = _lib.OBE_WS_RESULT_OFFSET
 
-        def launch(shifted, safe=False):
+        def launch(shifted, safe=False, speculative=False):
             # sharded: no host read here — the 32-byte result record is all-gathered from
             # device memory and read back once, together with the other ranks' records
+            p, w = self._pw_tensors()
+            cost_t, cost_s = self._cost_device()
+            noise, noise_ld = self._noise_var_device()
+            # last, so that the moments kernels and the sweep are enqueued back to back (every idle
+            # microsecond before the sweep kernel also costs clock ramp-up inside it)
+            mom = self._moments_on_device()
+            no_host = sharded or lazy
             self._mlib.call("obe_sweep_utility", self._model_struct, s_ptr, self._n_settings, n_local,
                            _ptr(p), p.shape[1], self.n_particles, _ptr(w),
                            None if idx is None else _ptr(idx), n_draws, _ptr(mom),
-                           (_lib.OBE_SWEEP_SHIFTED if shifted else 0) | (_lib.OBE_SWEEP_SAFE if safe else 0),
+                           (_lib.OBE_SWEEP_SHIFTED if shifted else 0) | (_lib.OBE_SWEEP_SAFE if safe else 0)
+                           | (_lib.OBE_SWEEP_SPECULATIVE if speculative else 0),
                            _ptr(noise), noise_ld, None if cost_t is None else _ptr(cost_t), cost_s,
                            _ptr(self._yvar_dev), _ptr(self._utility_dev),
-                           None if sharded or lazy else p_best,
-                           None if sharded or lazy else p_best_idx,
-                           None if sharded or lazy else p_kappa,
+                           None if no_host else p_best,
+                           None if no_host else p_best_idx,
+                           None if no_host else p_kappa,
                            _ptr(self._ws), self._ws_bytes, self._stream())
+            if speculative:
+                record = None
+                if sharded:         # the workspace is reused by whatever is enqueued next: keep the record
+                    record = self.__dict__.get("_spec_record")
+                    if record is None:
+                        record = self._spec_record = torch.empty(4, dtype=torch.float64, device=self._device)
+                    record.copy_(self._ws[off:off + 4])
+                self._spec = dict(cloud=(self._particles.version, self._weights.version), shifted=shifted,
+                                  noise=self._noise_token(), settings=(self._s_begin, self._s_end),
+                                  words=None if sharded else p_best, block=block, record=record)
+            else:
+                deliver(None if not sharded else self._ws[off:off + 4])
+
+        def deliver(record):
             if lazy:
                 result["best"] = None
                 kappa[0] = 0.0
             elif sharded:
-                off = _lib.OBE_WS_RESULT_OFFSET
-                val, gidx, k = self._shard.combine_records(self._ws[off:off + 4], self._n_settings)
+                val, gidx, k = self._shard.combine_records(record, self._n_settings)
                 result["best"] = (val, gidx)
                 kappa[0] = k
             else:
@@ -585,6 +725,9 @@ class OptBayesExpt(ParticlePDF):
         mode = self.tuning_parameters.get("sweep_shift", "auto")
         shifted = (not full) or mode == "always" or (mode == "auto" and not self._sweep_unshifted)
         safe = False
+        if speculate:
+            launch(shifted, speculative=True)
+            return None
         self._apply_range_hint()
         if self._sweep_safe_streak >= self.SAFE_STREAK:
             self._sweep_safe_run += 1
@@ -595,7 +738,11 @@ class OptBayesExpt(ParticlePDF):
             self.last_sweep = dict(shifted=True, kappa=float("nan"), safe=False)     # kappa was not read back
             return None
         if self._sweep_safe_streak < self.SAFE_STREAK:
-            launch(shifted)
+            taken = self._take_speculative_sweep(shifted) if full else None
+            if taken is None:
+                launch(shifted)
+            else:
+                deliver(taken if sharded else None)
             self._check_pending_total()
             if full and mode == "auto":
                 if shifted:
@@ -617,6 +764,7 @@ class OptBayesExpt(ParticlePDF):
             # the fast form has left its range SAFE_STREAK sweeps in a row: that is a property of the
             # settings grid (its span against the model's width), not of one cloud — stop paying for a
             # fast attempt that is thrown away
+            self._drop_speculative_sweep()
             safe = shifted = True
             launch(True, safe=True)
             self._check_pending_total()

@@ -96,6 +96,13 @@ class OptBayesExptNoiseParameter(OptBayesExpt):
         t, _ = OptBayesExptNoiseParameter._noise_var_device(self)
         return t.cpu().numpy().reshape((self.n_channels, 1))
 
+    def _noise_token(self):
+        # (the noise variance is a function of the cloud alone: nothing else to compare)
+        if _overridden(self, "yvar_noise_model", OptBayesExpt, OptBayesExptNoiseParameter) \
+                or self._parameters is not self._particles:
+            return None
+        return "cloud"
+
     def _noise_var_device(self):
         if _overridden(self, "yvar_noise_model", OptBayesExptNoiseParameter):
             return OptBayesExpt._noise_var_device(self)

@@ -1,0 +1,198 @@
+"""The sweep that pdf_update() enqueues behind its update without waiting (obe_base.py: _speculation_wanted)
+changes WHEN the kernels run, never what they compute: every cycle of a run with it must equal, bit for bit,
+the cycle of a run without it — whatever the caller does between the update and the next sweep (GPU)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def lorentz(x, x0, a, b, d):
+    return b + a / (((x - x0) / d) ** 2 + 1.0)
+
+
+def make(obe, mode, n_particles=20000, n_settings=3000, noise_param=False, shard=None, seed=3, threshold=0.5):
+    rng = np.random.default_rng(seed)
+    x = np.linspace(1.5, 4.5, n_settings)
+    prior = [rng.uniform(2.0, 4.0, n_particles), rng.uniform(1.0, 3.0, n_particles), rng.normal(0.5, 0.3, n_particles)]
+    if noise_param:
+        prior.append(rng.uniform(0.05, 0.6, n_particles))
+        o = obe.OptBayesExptNoiseParameter(obe.models.lorentzian(1), (x,), np.array(prior), (0.1,),
+                                           noise_parameter_index=3, utility_method="variance_full",
+                                           resample_threshold=threshold, settings_shard=shard)
+    else:
+        o = obe.OptBayesExpt(obe.models.lorentzian(1), (x,), np.array(prior), (0.1,), utility_method="variance_full",
+                             resample_threshold=threshold, settings_shard=shard)
+    o.tuning_parameters["speculative_sweep"] = mode
+    o.rng = np.random.default_rng(11)
+    return o
+
+
+def snapshot(o):
+    return dict(w=o.particle_weights.copy(), p=o.particles.copy(), resampled=bool(o.just_resampled),
+                rng=o.rng.bit_generator.state["state"]["state"], mean=o.mean().copy())
+
+
+def cycles(o, n, between=None, sigma=0.3, seed=5):
+    meas = np.random.default_rng(seed)
+    log = []
+    for c in range(n):
+        s = o.opt_setting()
+        swept = dict(u=o._utility_dev.cpu().numpy().copy(), yv=o._yvar_dev.cpu().numpy().copy(),
+                     sweep=dict(o.last_sweep))
+        y = lorentz(s[0], 3.1, 2.2, 0.4, 0.1) + sigma * meas.standard_normal()
+        o.pdf_update((s, y, sigma))
+        entry = dict(snapshot(o), **swept)
+        entry["setting"] = tuple(float(v) for v in s)
+        if between is not None:
+            entry["between"] = between(o, c)
+        log.append(entry)
+    return log
+
+
+def same(a, b):
+    assert len(a) == len(b)
+    for c, (x, y) in enumerate(zip(a, b)):
+        assert x["setting"] == y["setting"], c
+        assert x["resampled"] == y["resampled"], c
+        assert x["rng"] == y["rng"], c
+        kx, ky = x["sweep"].pop("kappa"), y["sweep"].pop("kappa")
+        assert x["sweep"] == y["sweep"], c
+        assert kx == ky or (np.isnan(kx) and np.isnan(ky)), c
+        for k in ("w", "p", "u", "yv", "mean"):
+            assert np.array_equal(x[k], y[k], equal_nan=True), (c, k)
+        if "between" in x:
+            assert np.array_equal(np.asarray(x["between"]), np.asarray(y["between"]), equal_nan=True), c
+
+
+def counted(o):
+    """Counts the speculative sweeps that were used / launched / aborted by the update's resample."""
+    n = dict(taken=0, launched=0, aborted=0)
+    take, sweep = o._take_speculative_sweep, o._sweep_device
+
+    def counting_take(shifted):
+        spec = o.__dict__.get("_spec")
+        if spec is not None and not spec.get("ran"):
+            n["aborted"] += 1
+        got = take(shifted)
+        n["taken"] += got is not None
+        return got
+
+    def counting_sweep(want_best, speculate=False):
+        n["launched"] += bool(speculate)
+        return sweep(want_best, speculate=speculate)
+
+    o._take_speculative_sweep, o._sweep_device = counting_take, counting_sweep
+    return n
+
+
+@pytest.mark.parametrize("noise_param", [False, True])
+def test_cycles_with_and_without_the_speculative_sweep_are_the_same_cycles(hip, noise_param):
+    import optbayesexpt_amd as obe
+    plain = cycles(make(obe, False, noise_param=noise_param), 40)
+    assert 3 <= sum(e["resampled"] for e in plain) <= 30
+    for mode in (True, "auto"):
+        o = make(obe, mode, noise_param=noise_param)
+        n = counted(o)
+        same(cycles(o, 40), [dict(e, sweep=dict(e["sweep"])) for e in plain])
+        resamples = sum(e["resampled"] for e in plain)
+        # every update but the last one's sweep is asked for; the ones behind a resampling update did nothing
+        # ('auto' waits for two plain cycles and pauses while more than half of the recent updates resample)
+        assert n["launched"] >= (39 if mode is True else 20)
+        assert n["taken"] >= n["launched"] - n["aborted"] - 1
+        if mode is True:
+            assert n["aborted"] >= resamples - 3
+        assert n["taken"] >= 12
+
+
+def test_whatever_happens_between_the_update_and_the_sweep(hip):
+    """mean()/covariance() (workspace reuse), an extra opt_setting(), utility(), an extra update, new weights,
+    a changed noise level, a cost hook that appears: each leaves the cycles equal to the plain ones."""
+    import optbayesexpt_amd as obe
+
+    def between(o, c):
+        k = c % 8
+        if k == 0:
+            return np.concatenate([o.covariance().ravel(), o.std()])
+        if k == 1:
+            return np.asarray(o.opt_setting())              # the speculative result is this sweep's; the cycle's is fresh
+        if k == 2:
+            return o.utility().copy()
+        if k == 3:
+            o.pdf_update(((2.9,), 1.7, 0.3))               # a second update: the first one's sweep is never asked for
+            return o.mean()
+        if k == 4:
+            w = o.particle_weights.copy()
+            w[::2] *= 0.5
+            o.particle_weights = w / w.sum()
+            return o.mean()
+        if k == 5:
+            o.default_noise_std = o.default_noise_std * 1.5
+            return o.default_noise_std.ravel()
+        if k == 6 and c == 22:
+            o.cost_estimate = lambda: 2.0 + np.cos(o.allsettings[0])
+            return np.zeros(1)
+        return np.asarray(o.good_setting(pickiness=9))      # draws from self.rng on the utility of the sweep
+
+    plain = cycles(make(obe, False), 32, between)
+    o = make(obe, True)
+    n = counted(o)
+    same(cycles(o, 32, between), plain)
+    assert n["taken"] >= 8 and n["launched"] >= 20
+
+
+def test_one_rank_of_a_sharded_object_speculates_too(hip):
+    """A shard keeps no host words: the record of the speculative sweep is copied on the device before the
+    workspace is reused and gathered when the sweep is asked for."""
+    import optbayesexpt_amd as obe
+    from optbayesexpt_amd.dist import SettingsShard
+
+    def between(o, c):
+        return o.covariance().ravel() if c % 2 else o.std()
+
+    plain = cycles(make(obe, False), 24, between)
+    o = make(obe, True, shard=SettingsShard(0, 1))
+    n = counted(o)
+    same(cycles(o, 24, between), plain)
+    assert n["taken"] >= 12
+
+
+def test_resample_decision_of_the_device_is_the_hosts(hip):
+    """The flag the update kernel leaves for the sweep and the host's resample_test() agree cycle by cycle
+    (thresholds that make almost every / almost no update resample), and an overridden resample_test() that
+    disagrees with the device costs a sweep, never a wrong one."""
+    import optbayesexpt_amd as obe
+    for thr in (0.98, 0.02):
+        plain = cycles(make(obe, False, threshold=thr, n_particles=6000, n_settings=700), 25)
+        o = make(obe, True, threshold=thr, n_particles=6000, n_settings=700)
+        flags = []
+        test = o.resample_test
+
+        def checking():
+            flags.append(float(o._upd_host[4 + 4 * o.n_dims]))
+            test()
+            assert flags[-1] == float(o.just_resampled)
+
+        o.resample_test = checking
+        same(cycles(o, 25), plain)
+        assert len(flags) == 25 and (np.mean(flags) > 0.7 if thr > 0.5 else np.mean(flags) < 0.3)
+
+    class Stubborn(obe.OptBayesExpt):
+        def resample_test(self):                   # resamples every third update, whatever N_eff is
+            self._n = getattr(self, "_n", 0) + 1
+            if self._n % 3 == 0:
+                self.resample()
+                self.just_resampled = True
+            else:
+                self.just_resampled = False
+
+    def stubborn(mode):
+        rng = np.random.default_rng(3)
+        x = np.linspace(1.5, 4.5, 900)
+        prior = np.array([rng.uniform(2.0, 4.0, 8000), rng.uniform(1.0, 3.0, 8000), rng.normal(0.5, 0.3, 8000)])
+        o = Stubborn(obe.models.lorentzian(1), (x,), prior, (0.1,), utility_method="variance_full")
+        o.tuning_parameters["speculative_sweep"] = mode
+        o.rng = np.random.default_rng(11)
+        return o
+
+    same(cycles(stubborn(True), 20), cycles(stubborn(False), 20))

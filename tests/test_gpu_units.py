@@ -768,6 +768,7 @@ def test_sweep_timing_counts_the_launches_of_real_cycles(obe):
     o = obe.OptBayesExpt(obe.models.lorentzian(), (np.linspace(1.5, 4.5, ns),), prior, (0.1,),
                          utility_method="variance_full", default_noise_std=500.0, auto_resample=False)
     o.tuning_parameters["sweep_shift"] = "always"
+    o.tuning_parameters["speculative_sweep"] = False
     tot, cnt = ctypes.c_double(-1.0), ctypes.c_int64(-1)
     o._mlib.call("obe_sweep_timing", 1, None, None)
     for _ in range(3):
@@ -775,6 +776,16 @@ def test_sweep_timing_counts_the_launches_of_real_cycles(obe):
         o.pdf_update(((3.0,), 49000.0, 500.0))
     o._mlib.call("obe_sweep_timing", 0, ctypes.byref(tot), ctypes.byref(cnt))
     assert cnt.value == 3 and 0.0 < tot.value < 100.0
+    # sweeps that pdf_update() enqueues behind its update are counted when their events are read: the
+    # first opt_setting() launches its own, every update the next cycle's (the last one is never asked for)
+    o.tuning_parameters["speculative_sweep"] = True
+    o._mlib.call("obe_sweep_timing", 1, None, None)
+    for _ in range(3):
+        o.opt_setting()
+        o.pdf_update(((3.0,), 49000.0, 500.0))
+    o._mlib.call("obe_sweep_timing", 0, ctypes.byref(tot), ctypes.byref(cnt))
+    assert cnt.value == 4 and 0.0 < tot.value < 100.0
+    o.tuning_parameters["speculative_sweep"] = False
     o.opt_setting()
     o._mlib.call("obe_sweep_timing", -1, ctypes.byref(tot), ctypes.byref(cnt))
     assert cnt.value == 0 and tot.value == 0.0          # stopped: nothing accumulates

@@ -62,7 +62,11 @@ def run(cfg, shard, log, steps, warmup):
                 log.append((x, y))
             else:
                 x, y = log[c]              # the job's global choice and its measurement
-            obe.pdf_update((x, y, sigma) if noise_rec else (x, y))
+            rec = (x, y, sigma) if noise_rec else (x, y)
+            if c in (warmup - 1, warmup + steps - 1):      # no sweep enqueued across the ends of the timed region
+                bench.update_at_boundary(obe, rec)
+            else:
+                obe.pdf_update(rec)
             if c >= warmup:
                 times.append(1e3 * (time.perf_counter() - t0))
                 res.append(bool(obe.just_resampled))
