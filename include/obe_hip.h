@@ -387,6 +387,10 @@ int obe_power_normalize(const double* d_u, int64_t n, double exponent, double* d
  * and only then waits for the words with obe_host_words_wait().  An aborted call leaves them armed and the
  * device outputs (yvar, utility, the result record) untouched. */
 #define OBE_SWEEP_SPECULATIVE 8
+/* OBE_SWEEP_NOWAIT (full sweeps only): enqueued and not waited for, like OBE_SWEEP_SPECULATIVE, but
+ * unconditional — the caller knows the cloud is final (after a resample) and collects the page-locked
+ * result words later with obe_host_words_wait(). */
+#define OBE_SWEEP_NOWAIT 16
 /* Settings one lane of the sweep kernel owns for a grid of n_settings (1, 2, 4 or 8): the number
  * of denominators a model's fast form inverts together, which a caller that predicts whether a
  * settings grid stays inside that form's range needs (optbayesexpt_amd/models.py: range_hint). */

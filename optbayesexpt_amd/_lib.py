@@ -21,7 +21,7 @@ OBE_MAX_SETDIMS = 4
 OBE_MAX_DIMS = 16
 OBE_WS_RESULT_OFFSET = 2      # doubles; include/obe_hip.h
 HOST_SENTINEL = 0x7ff8c0dec0dec0de     # the value of an armed host result word (csrc/obe_common.h: kHostSentinel)
-OBE_SWEEP_SHIFTED, OBE_SWEEP_SAFE, OBE_SWEEP_SPECULATIVE = 1, 2, 8      # bits of obe_sweep_utility's `shifted` argument
+OBE_SWEEP_SHIFTED, OBE_SWEEP_SAFE, OBE_SWEEP_SPECULATIVE, OBE_SWEEP_NOWAIT = 1, 2, 8, 16      # bits of obe_sweep_utility's `shifted` argument
 
 c_void_p, c_int, c_int32, c_int64, c_double = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int32,
                                                ctypes.c_int64, ctypes.c_double)

@@ -97,6 +97,42 @@ unsigned* stream_control_words(hipStream_t st) {
     return w;
 }
 
+namespace {
+struct SideTable {
+    std::mutex mu;
+    std::unordered_map<uint64_t, SideStream> of;
+};
+SideTable& side_table() {
+    static SideTable* t = new SideTable;
+    return *t;
+}
+}  // namespace
+
+bool side_stream_of(hipStream_t st, SideStream* out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    SideTable& t = side_table();
+    const uint64_t key = ((uint64_t)dev << 56) ^ (uint64_t)reinterpret_cast<uintptr_t>(st);
+    std::lock_guard<std::mutex> lock(t.mu);
+    auto it = t.of.find(key);
+    if (it != t.of.end()) {
+        *out = it->second;
+        return out->stream != nullptr;
+    }
+    SideStream s{};
+    bool ok = t.of.size() < 256 && hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&s.entry, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&s.mid, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&s.done, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        s = SideStream{};                 // remembered: not tried again for this stream
+    }
+    t.of.emplace(key, s);
+    *out = s;
+    return ok;
+}
+
 static thread_local std::string g_last_error;
 static thread_local bool g_defer_host_sync = false;
 

@@ -90,6 +90,16 @@ __device__ __forceinline__ void host_results_before_flag() {
 // Zeroed device words owned by the library, one slot per (device, stream) (obe_capi.hip); nullptr: none.
 unsigned* stream_control_words(hipStream_t st);
 
+// A second stream (and three events) that belongs to a caller's stream: two independent kernel chains of one
+// call run side by side (obe_resample.hip: the random-number chain next to the CDF / search / covariance
+// chain) and are joined again with events before the call's results are consumed on the caller's stream.
+// Created on first use per (device, stream), never destroyed.  false: none available — one stream does both.
+struct SideStream {
+    hipStream_t stream;
+    hipEvent_t entry, mid, done;
+};
+bool side_stream_of(hipStream_t st, SideStream* out);      // obe_capi.hip
+
 // A block partial that another workgroup of the same launch will read: written through to memory
 // (a relaxed agent-scope atomic store lowers to `global_store ... sc1`), so publishing needs no release
 // fence — an agent-scope release writes back every dirty line of the XCD's L2, i.e. the weights the

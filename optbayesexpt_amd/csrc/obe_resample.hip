@@ -661,25 +661,63 @@ int obe_resample_begin(const double* d_particles, int64_t ld_p, int32_t n_dims, 
     hipStream_t st = as_stream(stream);
     const int prev = obe_defer_host_sync(1);
     int rc = 0;
+    // Two chains that share nothing but the uniforms: the generator's (raw values -> uniforms, ziggurat normals
+    // and their bookkeeping: touches d_uniforms, d_normals, d_zig_ws, h_i64) and the cloud's (CDF, search,
+    // covariance: d_ws, d_cdf, d_idx, d_moments, h_f64).  They run side by side on two streams — the random
+    // chain on a stream of the library's own — and the host factorises the covariance while the normals are
+    // still being made.  The caller's stream waits for the uniforms before the search and for the normals at
+    // the end, so whatever the caller enqueues next (the gather + nudge) is ordered behind both, and the stream
+    // is not drained before the side stream's host words have been written (wait_host_words relies on that).
+    // OBE_RESAMPLE_STREAMS=1: everything on the caller's stream, in the round-3 order (A/B measurements).
+    static const bool one_stream = getenv("OBE_RESAMPLE_STREAMS") && atoi(getenv("OBE_RESAMPLE_STREAMS")) == 1;
+    SideStream side{};
+    const bool split = !one_stream && side_stream_of(st, &side);
+    void* rs = split ? static_cast<void*>(side.stream) : stream;
+    const int64_t lo = have_first_moments ? 2 + 4 * (int64_t)n_dims : 0;
+    auto ev = [](hipError_t e) { return e == hipSuccess ? 0 : fail(e, "obe_resample_begin: stream / event call"); };
     do {
+        // (split: the cloud's chain is enqueued first — the host waits for the covariance, and every launch costs
+        // it a few microseconds; the kernels of the random chain arrive while the scan is already running)
+        if (split && (rc = ev(hipEventRecord(side.entry, st)))) break;
+        auto cdf_and_covariance = [&]() -> int {
+            if (!cdf_is_fresh) {
+                arm_host_word(h_f64);
+                if (int e = obe_weight_cdf(d_weights, n, strict_cdf, d_cdf, h_f64, d_ws, ws_bytes, stream)) return e;
+            } else {
+                h_f64[0] = 1.0;
+            }
+            if (!split) return 0;       // (one stream: the round-3 order, covariance after the search)
+            arm_host_words(h_f64 + 1 + lo, obe_moments_len(n_dims) - lo);
+            bool host_written = false;
+            return moments_call(d_particles, ld_p, n_dims, n, d_weights, have_first_moments ? 2 : 1, d_moments, h_f64 + 1,
+                                d_ws, ws_bytes, st, &host_written);
+        };
+        if (split && (rc = cdf_and_covariance())) break;
+        // the buffers of the random chain may still be read by earlier work of the caller's stream
+        if (split && (rc = ev(hipStreamWaitEvent(side.stream, side.entry, 0)))) break;
         // uniforms + the classification of every raw position behind them, straight from the generator state
         if ((rc = obe_pcg64_uniforms_classify(h_pcg_state4, n, n_raw - n, d_uniforms, d_zig_tables, d_zig_ws,
-                                              zig_ws_bytes, stream)))
+                                              zig_ws_bytes, rs)))
             break;
-        if (!cdf_is_fresh) {
-            arm_host_word(h_f64);
-            if ((rc = obe_weight_cdf(d_weights, n, strict_cdf, d_cdf, h_f64, d_ws, ws_bytes, stream))) break;
-        } else {
-            h_f64[0] = 1.0;
+        if (split) {
+            if ((rc = ev(hipEventRecord(side.mid, side.stream)))) break;
+            if ((rc = obe_ziggurat_finish(n_raw - n, n_normal, d_normals, h_i64, d_zig_ws, zig_ws_bytes, rs))) break;
+            if ((rc = ev(hipEventRecord(side.done, side.stream)))) break;
+            if ((rc = ev(hipStreamWaitEvent(st, side.mid, 0)))) break;
+        } else if ((rc = cdf_and_covariance())) {
+            break;
         }
         if ((rc = obe_cdf_search(d_cdf, n, d_uniforms, n, d_idx, d_ws, ws_bytes, stream))) break;
-        const int64_t lo = have_first_moments ? 2 + 4 * (int64_t)n_dims : 0;
-        arm_host_words(h_f64 + 1 + lo, obe_moments_len(n_dims) - lo);
-        bool host_written = false;
-        if ((rc = moments_call(d_particles, ld_p, n_dims, n, d_weights, have_first_moments ? 2 : 1, d_moments,
-                               h_f64 + 1, d_ws, ws_bytes, st, &host_written)))
-            break;
-        if ((rc = obe_ziggurat_finish(n_raw - n, n_normal, d_normals, h_i64, d_zig_ws, zig_ws_bytes, stream))) break;
+        if (split) {
+            if ((rc = ev(hipStreamWaitEvent(st, side.done, 0)))) break;
+        } else {
+            arm_host_words(h_f64 + 1 + lo, obe_moments_len(n_dims) - lo);
+            bool host_written = false;
+            if ((rc = moments_call(d_particles, ld_p, n_dims, n, d_weights, have_first_moments ? 2 : 1, d_moments,
+                                   h_f64 + 1, d_ws, ws_bytes, st, &host_written)))
+                break;
+            if ((rc = obe_ziggurat_finish(n_raw - n, n_normal, d_normals, h_i64, d_zig_ws, zig_ws_bytes, stream))) break;
+        }
     } while (false);
     obe_defer_host_sync(prev);
     return rc;

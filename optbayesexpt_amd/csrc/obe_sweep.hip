@@ -905,14 +905,17 @@ int obe_sweep_utility(const obe_model* m, const double* d_settings, int64_t ld_s
     hipStream_t st = as_stream(stream);
     UtilArgs ua{d_noise_var, noise_ld, d_cost, cost_scalar};
     const bool speculative = shifted & OBE_SWEEP_SPECULATIVE;
-    if (speculative) {
-        if (d_draw_idx) return bad_arg("obe_sweep_utility: OBE_SWEEP_SPECULATIVE is for full sweeps");
-        unsigned* control = stream_control_words(st);
-        if (!control) return bad_arg("obe_sweep_utility: no control words for this stream");
-        a.abort = control + kAbortWord;
+    const bool nowait = speculative || (shifted & OBE_SWEEP_NOWAIT);
+    if (nowait) {
+        if (d_draw_idx) return bad_arg("obe_sweep_utility: OBE_SWEEP_SPECULATIVE / OBE_SWEEP_NOWAIT are for full sweeps");
+        if (speculative) {
+            unsigned* control = stream_control_words(st);
+            if (!control) return bad_arg("obe_sweep_utility: no control words for this stream");
+            a.abort = control + kAbortWord;
+        }
         if ((h_best && !device_view_of_host(h_best)) || (h_best_idx && !device_view_of_host(h_best_idx)) ||
             (h_kappa && !device_view_of_host(h_kappa)))
-            return bad_arg("obe_sweep_utility: OBE_SWEEP_SPECULATIVE needs page-locked host outputs");
+            return bad_arg("obe_sweep_utility: OBE_SWEEP_SPECULATIVE / OBE_SWEEP_NOWAIT need page-locked host outputs");
     }
     const HostResult hr = host_result(h_best, h_best_idx, h_kappa);
     static const bool no_small = getenv("OBE_SWEEP_NO_SMALL") != nullptr;      // test / tuning aid
@@ -971,7 +974,7 @@ int obe_sweep_utility(const obe_model* m, const double* d_settings, int64_t ld_s
     OBE_CHECK_LAUNCH("sweep_finalize");
     argmax_fold<<<1, kBlock, 0, st>>>(w.bv, w.bi, nb, w.bk, w.out_v, w.out_i, hr, a.abort);
     OBE_CHECK_LAUNCH("argmax_fold");
-    if (speculative) {          // nobody waits here: the caller watches the armed words when it wants the result
+    if (nowait) {               // nobody waits here: the caller watches the armed words when it wants the result
         if (timed) {
             g_timing.pending = true;
             g_timing.pending_min_ms = 0.5 * (double)n_settings * (double)n_particles / 8e9;

@@ -57,6 +57,7 @@ class SettingsShard:
             rank, world_size = dist.get_rank(group), dist.get_world_size(group)
         self.rank, self.world_size = int(rank), int(world_size)
         self._record_bufs = {}        # device -> (all-gather receive buffer, page-locked host copy)
+        self._starts = {}             # n_settings -> first global index of every rank's slice
 
     def bounds(self, n_settings):
         return shard_bounds(n_settings, self.rank, self.world_size)
@@ -80,7 +81,10 @@ class SettingsShard:
         g = self._gather_records(record)
         vals = g[:, 0].numpy()
         local = g[:, 1].contiguous().view(torch.int64).numpy()
-        starts = np.array([shard_bounds(n_settings, r, w)[0] for r in range(w)], dtype=np.int64)
+        starts = self._starts.get(n_settings)
+        if starts is None:
+            starts = self._starts[n_settings] = np.array([shard_bounds(n_settings, r, w)[0] for r in range(w)],
+                                                         dtype=np.int64)
         gidx = local + starts
         k = first_max(vals, gidx)
         kappas = g[:, 2].numpy()

@@ -438,6 +438,14 @@ class OptBayesExpt(ParticlePDF):
         # (the cycle pattern the speculative sweep looks for: a full sweep of exactly this cloud comes next)
         self._updated_cloud = (self._particles.version, self._weights.version) if fused else None
         self._resample_rate = 0.8 * self.__dict__.get("_resample_rate", 0.0) + (0.2 if self.just_resampled else 0.0)
+        if fused and self.just_resampled and self._speculation_wanted(after_resample=True):
+            # the cloud is final (resampled, constrained): its sweep goes out now, behind the gather and the
+            # moments, instead of after the caller's way back through opt_setting()
+            self._drop_speculative_sweep()
+            try:
+                self._sweep_device(False, speculate="after_resample")
+            except _lib.ObeHipError:
+                self._spec_unavailable = True
         return _LazyState(self)
 
     # ------------------------------------------------------- speculative sweep
@@ -455,14 +463,17 @@ class OptBayesExpt(ParticlePDF):
     # (default), True (from the first update on), False (never).  Measured (MI355X, tools/spec_cycles.py,
     # tools/shard_cycle.py): the plain cycle of 4096 settings x 262 144 particles 0.333 -> 0.314 ms, of one
     # rank's 8192 x 1 048 576 slice 1.877 -> 1.845 ms.
-    def _speculation_wanted(self):
+    def _speculation_wanted(self, after_resample=False):
         mode = self.tuning_parameters.get("speculative_sweep", _SPECULATIVE_DEFAULT)
         if mode is False or mode == "never" or self.__dict__.get("_spec_unavailable"):
             return False
         # 'auto': after two update -> sweep cycles in a row, and while fewer than half of the recent updates
         # resampled (a sweep behind a resampling update is launched for nothing: ~10-35 us of empty workgroups)
+        # (the sweep enqueued after a resample has nothing to guess: the cloud is final)
         if not (mode is True or (self.__dict__.get("_spec_streak", 0) >= 2
-                                 and self.__dict__.get("_resample_rate", 0.0) < 0.5)):
+                                 and (after_resample or self.__dict__.get("_resample_rate", 0.0) < 0.5))):
+            return False
+        if after_resample and self._parameters is not self._particles:
             return False
         return (self.utility_method == "variance_full" and self._utility_fusable()
                 and not _overridden(self, "cost_estimate", OptBayesExpt)
@@ -683,7 +694,8 @@ class OptBayesExpt(ParticlePDF):
                            _ptr(p), p.shape[1], self.n_particles, _ptr(w),
                            None if idx is None else _ptr(idx), n_draws, _ptr(mom),
                            (_lib.OBE_SWEEP_SHIFTED if shifted else 0) | (_lib.OBE_SWEEP_SAFE if safe else 0)
-                           | (_lib.OBE_SWEEP_SPECULATIVE if speculative else 0),
+                           | (0 if not speculative else _lib.OBE_SWEEP_NOWAIT if speculative == "after_resample"
+                              else _lib.OBE_SWEEP_SPECULATIVE),
                            _ptr(noise), noise_ld, None if cost_t is None else _ptr(cost_t), cost_s,
                            _ptr(self._yvar_dev), _ptr(self._utility_dev),
                            None if no_host else p_best,
@@ -700,6 +712,8 @@ class OptBayesExpt(ParticlePDF):
                 self._spec = dict(cloud=(self._particles.version, self._weights.version), shifted=shifted,
                                   noise=self._noise_token(), settings=(self._s_begin, self._s_end),
                                   words=None if sharded else p_best, block=block, record=record)
+                if speculative == "after_resample":
+                    self._spec["ran"] = True
             else:
                 deliver(None if not sharded else self._ws[off:off + 4])
 
@@ -726,7 +740,7 @@ class OptBayesExpt(ParticlePDF):
         shifted = (not full) or mode == "always" or (mode == "auto" and not self._sweep_unshifted)
         safe = False
         if speculate:
-            launch(shifted, speculative=True)
+            launch(shifted, speculative=speculate)
             return None
         self._apply_range_hint()
         if self._sweep_safe_streak >= self.SAFE_STREAK:

@@ -67,7 +67,7 @@ def same(a, b):
 
 def counted(o):
     """Counts the speculative sweeps that were used / launched / aborted by the update's resample."""
-    n = dict(taken=0, launched=0, aborted=0)
+    n = dict(taken=0, launched=0, aborted=0, after_resample=0)
     take, sweep = o._take_speculative_sweep, o._sweep_device
 
     def counting_take(shifted):
@@ -80,6 +80,7 @@ def counted(o):
 
     def counting_sweep(want_best, speculate=False):
         n["launched"] += bool(speculate)
+        n["after_resample"] += speculate == "after_resample"
         return sweep(want_best, speculate=speculate)
 
     o._take_speculative_sweep, o._sweep_device = counting_take, counting_sweep
@@ -96,13 +97,13 @@ def test_cycles_with_and_without_the_speculative_sweep_are_the_same_cycles(hip, 
         n = counted(o)
         same(cycles(o, 40), [dict(e, sweep=dict(e["sweep"])) for e in plain])
         resamples = sum(e["resampled"] for e in plain)
-        # every update but the last one's sweep is asked for; the ones behind a resampling update did nothing
-        # ('auto' waits for two plain cycles and pauses while more than half of the recent updates resample)
-        assert n["launched"] >= (39 if mode is True else 20)
-        assert n["taken"] >= n["launched"] - n["aborted"] - 1
+        # True: every sweep but the first was enqueued by the update before it — behind the update itself, or,
+        # when that update resampled (and the sweep behind it did nothing), behind the resample.
+        # 'auto' waits for two plain cycles, and does not guess while more than half of the recent updates resample
         if mode is True:
-            assert n["aborted"] >= resamples - 3
-        assert n["taken"] >= 12
+            assert n["taken"] == 39 and n["after_resample"] == resamples and n["launched"] == 40 + resamples
+        else:
+            assert n["taken"] >= 30 and n["after_resample"] >= resamples - 3
 
 
 def test_whatever_happens_between_the_update_and_the_sweep(hip):
