@@ -391,9 +391,10 @@ int obe_power_normalize(const double* d_u, int64_t n, double exponent, double* d
  * unconditional — the caller knows the cloud is final (after a resample) and collects the page-locked
  * result words later with obe_host_words_wait(). */
 #define OBE_SWEEP_NOWAIT 16
-/* Settings one lane of the sweep kernel owns for a grid of n_settings (1, 2, 4 or 8): the number
- * of denominators a model's fast form inverts together, which a caller that predicts whether a
- * settings grid stays inside that form's range needs (optbayesexpt_amd/models.py: range_hint). */
+/* Settings one lane of the sweep kernel owns at most for a grid of n_settings (1, 2, 4 or 8; a sweep of
+ * few draws may use fewer): the number of denominators a model's fast form inverts together, which a
+ * caller that predicts whether a settings grid stays inside that form's range needs
+ * (optbayesexpt_amd/models.py: range_hint). */
 int obe_sweep_settings_per_lane(int64_t n_settings);
 int obe_sweep_utility(const obe_model* m,
                       const double* d_settings, int64_t ld_s, int64_t n_settings,

@@ -452,23 +452,33 @@ class ParticlePDF:
             z_dev = torch.from_numpy(self.rng.standard_normal((n, d))).to(self._device)
         self._resample_apply(idx, z_dev, factor, mean)
 
-    def _nudge_factor(self, m):
+    def _nudge_factor(self, m, defer_check=False):
         """(F, mean) for the nudge of resample(): Generator.multivariate_normal(method='svd') draws
-        x = z @ (u * sqrt(s)).T from the SVD of (1 - a^2) cov."""
+        x = z @ (u * sqrt(s)).T from the SVD of (1 - a^2) cov.  ``defer_check``: (F, mean, check) — numpy's
+        validity test of the covariance only warns, so the pipelined resample runs it (``check()``) after
+        the gather has been launched instead of before (25 of the 40-55 us this function takes)."""
         d = self.n_dims
         mean = m[2:2 + d].copy()
         cov = m[2 + 4 * d:2 + 4 * d + d * d].reshape((d, d))
         a = self.tuning_parameters["a_param"]
         newcov = (1 - a ** 2) * cov
         u, s, vh = np.linalg.svd(newcov)
-        # numpy's check_valid='warn': allclose(dot(v.T * s, v), cov, rtol = atol = 1e-8), spelled out
-        # (np.allclose itself costs ~25 us of interpreter in every resample)
-        back = np.dot(vh.T * s, vh)
-        with np.errstate(invalid="ignore"):
-            ok = bool(np.all(np.abs(back - newcov) <= 1e-8 + 1e-8 * np.abs(newcov))) and bool(np.all(np.isfinite(newcov)))
-        if not ok:
-            warnings.warn("covariance is not symmetric positive-semidefinite.", RuntimeWarning)
-        return np.ascontiguousarray(u * np.sqrt(s)), mean
+
+        def check():
+            # numpy's check_valid='warn': allclose(dot(v.T * s, v), cov, rtol = atol = 1e-8), spelled out
+            # (np.allclose itself costs ~25 us of interpreter in every resample)
+            back = np.dot(vh.T * s, vh)
+            with np.errstate(invalid="ignore"):
+                ok = bool(np.all(np.abs(back - newcov) <= 1e-8 + 1e-8 * np.abs(newcov))) \
+                    and bool(np.all(np.isfinite(newcov)))
+            if not ok:
+                warnings.warn("covariance is not symmetric positive-semidefinite.", RuntimeWarning)
+
+        factor = np.ascontiguousarray(u * np.sqrt(s))
+        if defer_check:
+            return factor, mean, check
+        check()
+        return factor, mean
 
     def _resample_apply(self, idx, z_dev, factor, mean):
         n, d = self.n_particles, self.n_dims
@@ -544,10 +554,11 @@ class ParticlePDF:
         self._cdf_key = key
         self._moments_host[lo:mlen] = pin_f[1 + lo:1 + mlen]
         self._mom_host_key = self._mom_dev_key = mkey + (True,)
-        factor, mean = self._nudge_factor(self._moments_host)
+        factor, mean, check_covariance = self._nudge_factor(self._moments_host, defer_check=True)
         self.last_draw_indices_device = idx
         before = self._particles
         self._resample_apply(idx, b["normals"], factor, mean)
+        check_covariance()
         self._lib.call("obe_host_words_wait", b["p_i"], 2, stream)     # {raw consumed, normals found}
         consumed, found = int(b["pin_i"][0]), int(b["pin_i"][1])
         if self._lib.cdll.obe_ziggurat_check(consumed, found, n * d, b["n_raw"] - n, 0) != 0:
