@@ -371,6 +371,7 @@ struct Lorentz {
     static constexpr int NS = 1, NC = 1, NREAD = K + 2, NCONST = 1;
     static constexpr int NXS = 1;        // prepared setting: x/d
     static constexpr int NPK = K + 2;    // packed particle: x0_k/d ..., sw*a, sw*(b - bbar)
+    static constexpr int kSweepCost = K; // evaluation time relative to the one-peak model (grid planning)
 
     __device__ static void eval(const double* x, const ParamRef& th, const obe_model& m, double* y) {
         const double d = m.consts[0];
@@ -713,6 +714,12 @@ struct Coil {
         }
     }
 };
+
+// relative cost of one sweep evaluation (1 unless the model says otherwise): the sweep plans its grid by time
+template <class M, class = void>
+struct sweep_cost { static constexpr int value = 1; };
+template <class M>
+struct sweep_cost<M, std::void_t<decltype(M::kSweepCost)>> { static constexpr int value = M::kSweepCost; };
 
 template <class M, class = void>
 struct has_pair_eval { static constexpr bool value = false; };

@@ -71,7 +71,12 @@ struct SweepPlan {
 // and the launch is fastest with about six work items per resident slot (4608: within 0.5 % of
 // the best; 1536 is 2 % slower).  Smaller grids get fewer (down to 1536: 4 096 x 262 144 takes
 // 0.27 ms with 1536 or 4608 items, 0.30 ms with 896), so that the chunk partials stay small.
-static SweepPlan plan_sweep(int64_t ns, int64_t nd) {
+// "Smaller" is measured in time, not evaluations: `cost` is the model's evaluation time relative to the one-peak
+// Lorentzian (sweep_cost<M>).  One rank's 2048 x 524 288 slice of the 7-peak config is as many evaluations as
+// 4096 x 262 144 of the one-peak model but runs 1.1 ms: with 1536 items (two rounds of 0.55 ms workgroups) the
+// uneven tail costs 5 % — 1.145 / 1.146 ms against 1.093 / 1.083 ms with 4096 (same box, in cycles; 6144 and
+// 8192 no better); the one-peak 4096 x 262 144 is indifferent (0.252 vs 0.250-0.254 ms).
+static SweepPlan plan_sweep(int64_t ns, int64_t nd, int cost = 1) {
     static const int force_spt = getenv("OBE_SWEEP_SPT") ? atoi(getenv("OBE_SWEEP_SPT")) : 0;         // tuning aids
     static const int force_blocks = getenv("OBE_SWEEP_BLOCKS") ? atoi(getenv("OBE_SWEEP_BLOCKS")) : 0;
     SweepPlan p;
@@ -80,7 +85,7 @@ static SweepPlan plan_sweep(int64_t ns, int64_t nd) {
     p.spt = ns >= 4096 || (ns >= 2048 && nd >= 131072) ? 8 : (ns >= 1024 ? 4 : (ns >= 512 ? 2 : 1));
     if (force_spt == 1 || force_spt == 2 || force_spt == 4 || force_spt == 8) p.spt = force_spt;
     p.tiles_x = static_cast<int>((ns + (int64_t)kWave * p.spt - 1) / ((int64_t)kWave * p.spt));
-    const int64_t by_work = static_cast<int64_t>((double)ns * (double)nd / 1.25e6);
+    const int64_t by_work = static_cast<int64_t>((double)ns * (double)nd * (double)cost / 1.25e6);
     const int64_t target_blocks = force_blocks > 0 ? force_blocks : std::max<int64_t>(1536, std::min<int64_t>(4608, by_work));
     int64_t want = (target_blocks + p.tiles_x - 1) / p.tiles_x;
     if (want > 8) want = (want + 7) / 8 * 8;          // whole groups of 8 chunks: one per XCD
@@ -96,7 +101,7 @@ static SweepPlan plan_sweep(int64_t ns, int64_t nd) {
 }
 
 static int64_t sweep_ws_doubles(int64_t ns, int64_t nd, int nc, int packed_w) {
-    const SweepPlan p = plan_sweep(ns, nd);
+    const SweepPlan p = plan_sweep(ns, nd, 1 << 20);       // (the grid of the costliest model: the most chunks)
     // (sized by the monotone bound: the chunk count itself is not monotone in nd after the rounding
     // of the chunk length, and a sweep of N_DRAWS < n_particles draws runs in the same workspace)
     return 2 * (int64_t)p.nchunks_bound * nc * ns  // partial S1, S2
@@ -837,10 +842,15 @@ static int prepare_sweep(const obe_model* m, obe_model& mm, const double* d_sett
     if (int rc = obe_model_validate(&mm)) return rc;
     const int64_t nd = d_draw_idx ? n_draws : np;
     if (nd <= 0) return bad_arg("sweep: n_draws must be positive");
-    plan = plan_sweep(ns, nd);
+    int packed_w = 0, cost = 1;
+    if (int rc = dispatch_model(mm, [&](auto M) -> int {
+            packed_w = packed_width<decltype(M)>();
+            cost = sweep_cost<decltype(M)>::value;
+            return 0;
+        }))
+        return rc;
+    plan = plan_sweep(ns, nd, cost);
     const int64_t part = (int64_t)plan.nchunks * mm.n_channels * ns;
-    int packed_w = 0;
-    if (int rc = dispatch_model(mm, [&](auto M) -> int { packed_w = packed_width<decltype(M)>(); return 0; })) return rc;
     if (int rc = carve_sweep_ws(d_ws, ws_bytes, part, (int64_t)mm.n_channels * ns, w, argmax_slots(ns), nd * packed_w))
         return rc;
     a.cs_out = w.cs;
