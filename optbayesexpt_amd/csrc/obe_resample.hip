@@ -669,9 +669,13 @@ int obe_resample_begin(const double* d_particles, int64_t ld_p, int32_t n_dims, 
     // the end, so whatever the caller enqueues next (the gather + nudge) is ordered behind both, and the stream
     // is not drained before the side stream's host words have been written (wait_host_words relies on that).
     // OBE_RESAMPLE_STREAMS=1: everything on the caller's stream, in the round-3 order (A/B measurements).
-    static const bool one_stream = getenv("OBE_RESAMPLE_STREAMS") && atoi(getenv("OBE_RESAMPLE_STREAMS")) == 1;
+    // Only where the chains are long: joining two streams costs two cross-queue waits.  Same box, resample cycle
+    // with one / two streams: 5000 particles x 3 (15 000 normals) 0.172 / 0.21 ms; 262 144 x 3 level (0.49 / 0.46,
+    // 0.50 / 0.54); 524 288 x 10 (5.2 M normals) 1.518 / 1.494 ms.  OBE_RESAMPLE_STREAMS=2 forces it (tests).
+    static const int streams_env = getenv("OBE_RESAMPLE_STREAMS") ? atoi(getenv("OBE_RESAMPLE_STREAMS")) : 0;
     SideStream side{};
-    const bool split = !one_stream && side_stream_of(st, &side);
+    const bool split = (streams_env == 2 || (streams_env != 1 && n_normal >= ((int64_t)1 << 21))) &&
+                       side_stream_of(st, &side);
     void* rs = split ? static_cast<void*>(side.stream) : stream;
     const int64_t lo = have_first_moments ? 2 + 4 * (int64_t)n_dims : 0;
     auto ev = [](hipError_t e) { return e == hipSuccess ? 0 : fail(e, "obe_resample_begin: stream / event call"); };

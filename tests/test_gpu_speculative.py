@@ -197,3 +197,105 @@ def test_resample_decision_of_the_device_is_the_hosts(hip):
         return o
 
     same(cycles(stubborn(True), 20), cycles(stubborn(False), 20))
+
+
+def test_enqueue_form_and_sweep_flags_through_the_abi(hip):
+    """obe_bayes_update_model_moments_enqueue + obe_sweep_utility(OBE_SWEEP_SPECULATIVE / OBE_SWEEP_NOWAIT) called
+    the way include/obe_hip.h describes them, against the synchronous calls: same host block, same weights, same
+    sweep result; a sweep behind an update that resamples leaves its words armed and its outputs untouched; the
+    refusals (draws mode, pageable result words) are errors, not silent synchronous calls."""
+    import torch
+    import optbayesexpt_amd as obe
+    from optbayesexpt_amd import _lib
+    from optbayesexpt_amd.particlepdf import _ptr, _P
+    g = np.random.default_rng(8)
+    n, ns, d = 30000, 2500, 3
+    prior = np.array([g.uniform(2, 4, n), g.uniform(1, 3, n), g.normal(0.5, 0.3, n)])
+    w0 = g.exponential(1.0, n)
+    w0 /= w0.sum()
+    o = obe.OptBayesExpt(obe.models.lorentzian(1), (np.linspace(1.5, 4.5, ns),), prior, (0.1,),
+                         utility_method="variance_full")
+    lib, st = o._mlib, o._stream()
+    par = o._particles.tensor()
+    w = o._weights.tensor()
+    mom = torch.zeros_like(o._moments_dev)
+    noise = torch.full((1,), 0.09, dtype=torch.float64, device=w.device)
+    yvar, util = torch.zeros((1, ns), dtype=torch.float64, device=w.device), torch.zeros(ns, dtype=torch.float64, device=w.device)
+    hp = _lib.host_ptr
+    # (a mild measurement: N_eff stays above 0.1 N, the other clause of particlepdf.py:236-258's test)
+    setting, y_meas, sigma = np.array([3.05, 0, 0, 0]), np.array([1.9, 0, 0, 0]), np.array([2.0, 1, 1, 1])
+    upd = (o._model_struct, _ptr(par), par.shape[1], n, _ptr(w), hp(setting), hp(y_meas), hp(sigma), None, 1, float("nan"))
+
+    def sweep(flags, best, idx, kappa):
+        return lib.cdll.obe_sweep_utility(o._model_struct, _P(o._settings_dev.data_ptr()), ns, ns, _ptr(par), par.shape[1], n,
+                                          _ptr(w), None, 0, _ptr(mom), _lib.OBE_SWEEP_SHIFTED | flags, _ptr(noise), 0, None, 1.0,
+                                          _ptr(yvar), _ptr(util), best, idx, kappa, _ptr(o._ws), o._ws_bytes, st)
+
+    def reset():
+        w.copy_(torch.from_numpy(w0))
+        util.fill_(-1.0)
+        torch.cuda.synchronize()
+
+    # the synchronous pair
+    reset()
+    out = _lib.pinned_array(5 + 4 * d)
+    lib.call("obe_bayes_update_model_moments", *upd, _ptr(mom), _ptr(o._ws), o._ws_bytes, hp(out), st)
+    res = _lib.pinned_array(4)
+    best, idx, kappa = res[0:1], res.view(np.int64)[1:2], res[2:3]
+    assert sweep(0, hp(best), hp(idx), hp(kappa)) == 0
+    torch.cuda.synchronize()
+    ref = dict(out=out[:4 + 4 * d].copy(), w=w.cpu().numpy(), res=res[:3].copy(), util=util.cpu().numpy(), mom=mom.cpu().numpy())
+
+    # enqueued update + speculative sweep, no resample (threshold 0: N_eff / N is never below it)
+    reset()
+    out2, res2 = _lib.pinned_array(5 + 4 * d), _lib.pinned_array(4)
+    b2, i2, k2 = res2[0:1], res2.view(np.int64)[1:2], res2[2:3]
+    lib.call("obe_bayes_update_model_moments_enqueue", *upd, _ptr(mom), _ptr(o._ws), o._ws_bytes, hp(out2), 1, 0.0, st)
+    assert sweep(_lib.OBE_SWEEP_SPECULATIVE, hp(b2), hp(i2), hp(k2)) == 0
+    lib.call("obe_host_words_wait", hp(out2), 5 + 4 * d, st)
+    assert 1.0 / ref["out"][1] > 0.1 * n
+    assert np.array_equal(out2[:4 + 4 * d], ref["out"]) and out2[4 + 4 * d] == 0.0
+    lib.call("obe_host_words_wait", hp(res2), 3, st)
+    assert np.array_equal(res2[:3].view(np.uint64), ref["res"].view(np.uint64))
+    torch.cuda.synchronize()
+    assert np.array_equal(w.cpu().numpy(), ref["w"]) and np.array_equal(util.cpu().numpy(), ref["util"])
+    assert np.array_equal(mom.cpu().numpy()[:2 + 4 * d], ref["mom"][:2 + 4 * d])
+
+    # ... and behind an update that resamples (threshold 1.1: N_eff / N is always below it): nothing runs
+    reset()
+    lib.call("obe_bayes_update_model_moments_enqueue", *upd, _ptr(mom), _ptr(o._ws), o._ws_bytes, hp(out2), 1, 1.1, st)
+    assert sweep(_lib.OBE_SWEEP_SPECULATIVE, hp(b2), hp(i2), hp(k2)) == 0
+    lib.call("obe_host_words_wait", hp(out2), 5 + 4 * d, st)
+    assert out2[4 + 4 * d] == 1.0 and np.array_equal(out2[:4 + 4 * d], ref["out"])
+    torch.cuda.synchronize()
+    assert np.all(res2[:3].view(np.uint64) == _lib.HOST_SENTINEL)          # still armed: the sweep did nothing
+    assert np.all(util.cpu().numpy() == -1.0) and np.array_equal(w.cpu().numpy(), ref["w"])
+    # auto_resample = 0: the same sums never say "resample"
+    reset()
+    lib.call("obe_bayes_update_model_moments_enqueue", *upd, _ptr(mom), _ptr(o._ws), o._ws_bytes, hp(out2), 0, 1.1, st)
+    lib.call("obe_host_words_wait", hp(out2), 5 + 4 * d, st)
+    assert out2[4 + 4 * d] == 0.0
+
+    # OBE_SWEEP_NOWAIT does not look at the decision (the word still says what the last enqueued update left)
+    lib.call("obe_bayes_update_model_moments_enqueue", *upd, _ptr(mom), _ptr(o._ws), o._ws_bytes, hp(out2), 1, 1.1, st)
+    lib.call("obe_host_words_wait", hp(out2), 5 + 4 * d, st)
+    reset()
+    lib.call("obe_bayes_update_model_moments", *upd, _ptr(mom), _ptr(o._ws), o._ws_bytes, hp(out), st)
+    assert sweep(_lib.OBE_SWEEP_NOWAIT, hp(b2), hp(i2), hp(k2)) == 0
+    lib.call("obe_host_words_wait", hp(res2), 3, st)
+    torch.cuda.synchronize()
+    assert np.array_equal(res2[:3].view(np.uint64), ref["res"].view(np.uint64))
+    assert np.array_equal(util.cpu().numpy(), ref["util"])
+
+    # refusals
+    pageable = np.zeros(1)
+    assert sweep(_lib.OBE_SWEEP_SPECULATIVE, hp(pageable), hp(i2), hp(k2)) != 0
+    assert "page-locked" in lib.last_error()
+    draws = torch.zeros(16, dtype=torch.int64, device=w.device)
+    rc = lib.cdll.obe_sweep_utility(o._model_struct, _P(o._settings_dev.data_ptr()), ns, ns, _ptr(par), par.shape[1], n, _ptr(w),
+                                    _ptr(draws), 16, _ptr(mom), _lib.OBE_SWEEP_SHIFTED | _lib.OBE_SWEEP_NOWAIT, _ptr(noise), 0,
+                                    None, 1.0, _ptr(yvar), _ptr(util), hp(b2), hp(i2), hp(k2), _ptr(o._ws), o._ws_bytes, st)
+    assert rc != 0 and "full sweeps" in lib.last_error()
+    with pytest.raises(_lib.ObeHipError, match="page-locked"):
+        lib.call("obe_bayes_update_model_moments_enqueue", *upd, _ptr(mom), _ptr(o._ws), o._ws_bytes, hp(np.zeros(5 + 4 * d)),
+                 1, 0.5, st)
