@@ -408,6 +408,15 @@ def _sweep_code(trees, settings, parameters, constants):
             fast.render(fast_out), safe.render(safe_out), fast.render_pair(fast_out))
 
 
+def _issue_slots(body):
+    """Rough FP64 issue slots per evaluation of a generated sweep body: one per arithmetic operation, ~20 per
+    elementary function, ~5 per element of a batched division."""
+    import re
+    ops = len(re.findall(r"fma\(| \* | - | \+ | / ", body))
+    funcs = len(re.findall(r"\b(?:exp|log|log1p|expm1|pow|sin|cos|tan|fast_\w+|sqrt|hypot|atan2?|sinh|cosh|tanh)\(", body))
+    return ops + 20 * funcs + 5 * body.count("batch_div")
+
+
 def _check_names(names):
     seen = set()
     for n in names:
@@ -429,6 +438,9 @@ def translate(expressions, settings, parameters, constants):
     prep_body, nxs, pack_body, npk, sweep_body, safe_body, pair_body = _sweep_code(trees, settings, parameters,
                                                                                      constants)
     ns, nc, npar, ncon = len(settings), len(expressions), len(parameters), len(constants)
+    # evaluation time relative to the one-peak Lorentzian (~7 FP64 issue slots per evaluation): the sweep plans
+    # its grid by time (csrc/obe_sweep.hip: plan_sweep)
+    sweep_cost = min(16, max(1, round(_issue_slots(sweep_body) / 7)))
     decl = [f"        const double u_{n} = x_[{i}];" for i, n in enumerate(settings)]
     decl += [f"        const double u_{n} = th_[{i}];" for i, n in enumerate(parameters)]
     decl += [f"        const double u_{n} = c_[{i}];" for i, n in enumerate(constants)]
@@ -441,6 +453,7 @@ def translate(expressions, settings, parameters, constants):
 namespace obe {{
 struct PluginModel {{
     static constexpr int NS = {ns}, NC = {nc}, NREAD = {npar}, NCONST = {ncon}, NXS = {nxs}, NPK = {npk};
+    static constexpr int kSweepCost = {sweep_cost};
     __device__ __forceinline__ static double sq(double v) {{ return v * v; }}
     __device__ __forceinline__ static void formula(const double* x_, const double* th_, const double* c_,
                                                    double* y_) {{
