@@ -565,6 +565,7 @@ struct FirstParam {
 // settings (pulsetime, delta_f); params (B1, f_center); consts (baseline, contrast, T1)
 struct Rabi {
     static constexpr int NS = 2, NC = 1, NREAD = 2, NXS = 3, NPK = 3, NCONST = 3;
+    static constexpr int kSweepCost = 7;   // exp, cos, hypot per evaluation (the generator's estimate for this formula)
     // the fraction removed from the baseline: y = baseline * (1 - frac)
     __device__ __forceinline__ static double frac(double tau, double df, double b1, double fc,
                                                    double contrast, double t1) {
@@ -638,6 +639,7 @@ struct Rabi {
 // setting w; params (L, R, C [, noise]); channels (Re Z, Im Z)
 struct Coil {
     static constexpr int NS = 1, NC = 2, NREAD = 3, NXS = 2, NPK = 7, NCONST = 0;
+    static constexpr int kSweepCost = 3;   // two channels, one shared complex reciprocal
     // (1 + 0j) / (c + dj) the way NumPy's complex divide loop does it (Smith's method,
     // numpy/_core/src/umath/loops.c.src, complex _divide)
     __device__ __forceinline__ static void crecip(double c, double d, double& re, double& im) {

@@ -529,7 +529,9 @@ class OptBayesExpt(ParticlePDF):
             return
         self._spec = None
         if spec.get("ran") and spec["words"] is not None:
-            self._lib.call("obe_host_words_wait", spec["words"], 3, self._stream())
+            self._lib.call("obe_host_words_wait", spec["words"], 3, spec["stream"])
+        elif spec.get("ran") and spec["stream"].value != self._stream().value:
+            torch.cuda.synchronize(self._device)      # a shard's sweep on a stream the caller has left since
             self._spec_streak = 0         # the pattern broke: two plain cycles before the next attempt
 
     def _take_speculative_sweep(self, shifted):
@@ -541,6 +543,7 @@ class OptBayesExpt(ParticlePDF):
         ok = (spec.get("ran") and spec["cloud"] == (self._particles.version, self._weights.version)
               and spec["shifted"] == shifted and spec["noise"] == self._noise_token()
               and spec["settings"] == (self._s_begin, self._s_end) and self._parameters is self._particles
+              and (spec["words"] is not None or spec["stream"].value == self._stream().value)
               and not _overridden(self, "cost_estimate", OptBayesExpt))
         if not ok:
             self._drop_speculative_sweep()
@@ -548,7 +551,7 @@ class OptBayesExpt(ParticlePDF):
         self._spec = None
         if spec["words"] is None:
             return spec["record"]
-        self._lib.call("obe_host_words_wait", spec["words"], 3, self._stream())
+        self._lib.call("obe_host_words_wait", spec["words"], 3, spec["stream"])
         block = spec["block"]
         if np.any(block.view(np.uint64)[:3] == _lib.HOST_SENTINEL):       # drained without delivering: not run
             return None
@@ -711,7 +714,8 @@ class OptBayesExpt(ParticlePDF):
                     record.copy_(self._ws[off:off + 4])
                 self._spec = dict(cloud=(self._particles.version, self._weights.version), shifted=shifted,
                                   noise=self._noise_token(), settings=(self._s_begin, self._s_end),
-                                  words=None if sharded else p_best, block=block, record=record)
+                                  words=None if sharded else p_best, block=block, record=record,
+                                  stream=self._stream())      # (waited for on the stream it was launched on)
                 if speculative == "after_resample":
                     self._spec["ran"] = True
             else:

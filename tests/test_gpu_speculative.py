@@ -299,3 +299,36 @@ def test_enqueue_form_and_sweep_flags_through_the_abi(hip):
     with pytest.raises(_lib.ObeHipError, match="page-locked"):
         lib.call("obe_bayes_update_model_moments_enqueue", *upd, _ptr(mom), _ptr(o._ws), o._ws_bytes, hp(np.zeros(5 + 4 * d)),
                  1, 0.5, st)
+
+
+@pytest.mark.parametrize("sharded", [False, True])
+def test_cycles_on_alternating_streams(hip, sharded):
+    """A caller that moves to another torch stream between pdf_update() and opt_setting() (ordering the streams
+    the torch way): the sweep enqueued on the stream it left is waited for there, or — a shard, whose record
+    lives on the device — not used."""
+    import torch
+    import optbayesexpt_amd as obe
+    from optbayesexpt_amd.dist import SettingsShard
+
+    def run(mode):
+        o = make(obe, mode, n_particles=30000, n_settings=2000, shard=SettingsShard(0, 1) if sharded else None)
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        meas = np.random.default_rng(5)
+        log = []
+        torch.cuda.synchronize()
+        for c in range(16):
+            cur, prev = streams[c % 2], streams[(c + 1) % 2]
+            cur.wait_stream(prev)
+            with torch.cuda.stream(cur):
+                s = o.opt_setting()
+                u = o._utility_dev.clone()
+                y = lorentz(s[0], 3.1, 2.2, 0.4, 0.1) + 0.3 * meas.standard_normal()
+                o.pdf_update((s, y, 0.3))
+                log.append((tuple(s), u.cpu().numpy(), o.particle_weights.copy(), bool(o.just_resampled)))
+        torch.cuda.synchronize()
+        return log
+
+    a, b = run(False), run(True)
+    for x, y in zip(a, b):
+        assert x[0] == y[0] and x[3] == y[3]
+        assert np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2])
