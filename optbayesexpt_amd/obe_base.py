@@ -54,6 +54,9 @@ _OVERRIDDEN = {}
 _SPECULATIVE_DEFAULT = {"0": False, "1": True}.get(os.environ.get("OBE_SPECULATIVE_SWEEP", "auto"), "auto")
 
 
+_SCALARS = (float, int, np.floating, np.integer)
+
+
 def _overridden(obj, name, *owners):
     """True if ``obj``'s class replaces method ``name`` defined by one of ``owners`` (answered once
     per class: the hooks are looked up several times in every cycle)."""
@@ -349,6 +352,10 @@ class OptBayesExpt(ParticlePDF):
         """The setting of a record, zero-padded to OBE_MAX_SETDIMS — in this object's record buffer:
         valid until the next call (every user passes it on or copies it at once)."""
         st = self._rec_x
+        if type(onesettingset) is tuple and len(onesettingset) == 1 and isinstance(onesettingset[0], _SCALARS):
+            st[0] = onesettingset[0]          # (the one-setting tuple opt_setting() returns: no array round trip)
+            st[1:] = 0.0
+            return st
         vals = np.asarray(onesettingset, dtype=np.float64).reshape(-1)
         k = min(vals.size, _lib.OBE_MAX_SETDIMS)
         st[:k] = vals[:k]
@@ -359,6 +366,15 @@ class OptBayesExpt(ParticlePDF):
     def _record_channels(self, y_meas, sigma):
         """zip(y_model, atleast_1d(y_meas), atleast_1d(sigma)) truncation
         (obe_base.py:453-455)."""
+        if isinstance(y_meas, _SCALARS) and (sigma is None or isinstance(sigma, _SCALARS)):
+            yy, s = self._rec_y, None          # one channel given as plain numbers: no array round trip
+            yy[0] = y_meas
+            yy[1:] = 0.0
+            if sigma is not None:
+                s = self._rec_s
+                s[0] = sigma
+                s[1:] = 1.0
+            return 1, yy, s
         y = np.asarray(y_meas, dtype=np.float64).reshape(-1)
         n = min(self.n_channels, y.size)
         s = None
@@ -405,8 +421,9 @@ class OptBayesExpt(ParticlePDF):
                 # ... and the first moments of the posterior in the same pass over the cloud: the next
                 # sweep's shift, mean(), std() and the noise-parameter variance need no launch of their own
                 self._drop_speculative_sweep()
-                if self._speculation_wanted():
-                    self._update_then_speculate(args)
+                if self.utility_method == "variance_full" and not self.__dict__.get("_spec_unavailable") \
+                        and self.tuning_parameters.get("speculative_sweep", _SPECULATIVE_DEFAULT) is not False:
+                    self._update_then_speculate(args)       # (enqueued; what goes behind it is decided while it runs)
                 else:
                     self._mlib.call("obe_bayes_update_model_moments", *args, _ptr(self._moments_dev), _ptr(self._ws),
                                     self._ws_bytes, self._hargs.ptr_keep(self._upd_host), self._stream())
@@ -508,10 +525,11 @@ class OptBayesExpt(ParticlePDF):
         self._weights.mark_device_written()
         key = (self._particles.version, self._weights.version)
         self._mom_dev_key = key + (False,)        # on the device, in stream order: what the sweep reads
-        try:
-            self._sweep_device(False, speculate=True)
-        except _lib.ObeHipError:
-            self._spec_unavailable = True         # (nothing of the sweep was enqueued: refused before any launch)
+        if self._speculation_wanted():
+            try:
+                self._sweep_device(False, speculate=True)
+            except _lib.ObeHipError:
+                self._spec_unavailable = True         # (nothing of the sweep was enqueued: refused before any launch)
         self._lib.call("obe_host_words_wait", p_out, 5 + 4 * d, st)
         spec = self.__dict__.get("_spec")
         if spec is not None:
@@ -528,10 +546,11 @@ class OptBayesExpt(ParticlePDF):
         if spec is None:
             return
         self._spec = None
-        if spec.get("ran") and spec["words"] is not None:
-            self._lib.call("obe_host_words_wait", spec["words"], 3, spec["stream"])
-        elif spec.get("ran") and spec["stream"].value != self._stream().value:
-            torch.cuda.synchronize(self._device)      # a shard's sweep on a stream the caller has left since
+        if spec.get("ran"):
+            if spec["words"] is not None:
+                self._lib.call("obe_host_words_wait", spec["words"], 3, spec["stream"])
+            elif spec["stream"].value != self._stream().value:
+                torch.cuda.synchronize(self._device)      # a shard's sweep on a stream the caller has left since
             self._spec_streak = 0         # the pattern broke: two plain cycles before the next attempt
 
     def _take_speculative_sweep(self, shifted):
@@ -553,9 +572,11 @@ class OptBayesExpt(ParticlePDF):
             return spec["record"]
         self._lib.call("obe_host_words_wait", spec["words"], 3, spec["stream"])
         block = spec["block"]
-        if np.any(block.view(np.uint64)[:3] == _lib.HOST_SENTINEL):       # drained without delivering: not run
+        words = block.view(np.int64)
+        armed = _lib.HOST_SENTINEL                                        # (positive as a signed word too)
+        if words[0] == armed or words[1] == armed or words[2] == armed:   # drained without delivering: not run
             return None
-        return float(block[0]), int(block.view(np.int64)[1]), float(block[2])
+        return float(block[0]), int(words[1]), float(block[2])
 
     def _likelihood_overridden(self):
         return _overridden(self, "likelihood", OptBayesExpt)
