@@ -13,6 +13,7 @@ python tools/measure_update.py 3 > gpurun_out/round/update_moments.txt 2>/dev/nu
 python tools/measure_update.py 10 >> gpurun_out/round/update_moments.txt 2>/dev/null
 python tools/shard_cycle.py c3 8 > gpurun_out/round/shard_cycle_c4.txt 2>/dev/null
 python tools/shard_cycle.py c5 8 > gpurun_out/round/shard_cycle_c5.txt 2>/dev/null
+python tools/spec_cycles.py c2 60 > gpurun_out/round/spec_cycles_c2.txt 2>/dev/null
 python tools/profile_host_split.py c1 2000 > gpurun_out/round/host_split_c1.txt 2>/dev/null
 python tools/profile_host_split.py c2 300 > gpurun_out/round/host_split_c2.txt 2>/dev/null
 bash tools/profile_rocprof.sh c3
