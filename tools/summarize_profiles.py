@@ -22,14 +22,36 @@ def short(name):
 
 
 # 1. kernel-trace --stats summary
+# (from the per-dispatch table, not rocprofv3's own top_kernels view: a sweep enqueued behind an update that
+# then resampled returns at once — pdf_update()'s speculative sweep, DESIGN.md §3 — and such dispatches of a few
+# microseconds must not be averaged with the ones that swept; they get a row of their own)
 c = sqlite3.connect(os.path.join(SRC, "trace", "bench_results.db"))
-rows = list(c.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+per = {}
+for name, start, end in c.execute("select name, start, end from kernels"):
+    per.setdefault(name, []).append((end - start) / 1e3)
+split = {}
+for name, durs in per.items():
+    longest = max(durs)
+    if "sweep_" in name or "argmax_fold" in name:
+        ran = [v for v in durs if v >= 0.05 * longest]
+        idle = [v for v in durs if v < 0.05 * longest]
+        split[name] = ran
+        if idle:
+            split[name + " [returned at once: behind an update that resampled]"] = idle
+    else:
+        split[name] = durs
+grand = sum(sum(v) for v in split.values())
+rows = sorted(((n, len(v), sum(v), sum(v) / len(v), 100.0 * sum(v) / grand) for n, v in split.items()),
+              key=lambda r: -r[2])
 with open(os.path.join(DST, f"{tag}_kernel_stats_{cfg}.txt"), "w") as f:
     f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs ({cfg})\n")
-    f.write("# durations in microseconds; bench.py's own JSON line for this profiled run follows the table\n")
+    f.write("# durations in microseconds, from the trace's per-dispatch table; bench.py's own JSON line for this profiled run follows the table\n")
     f.write(f"{'kernel':70s} {'calls':>6s} {'total_us':>12s} {'avg_us':>12s} {'pct':>7s}\n")
     for name, calls, total, avg, pct in rows:
-        f.write(f"{short(name)[:70]:70s} {calls:6d} {total:12.1f} {avg:12.2f} {pct:7.2f}\n")
+        label = short(name) + (name[name.index(" [returned"):] if " [returned" in name else "")
+        f.write(f"{label[:70]:70s} {calls:6d} {total:12.1f} {avg:12.2f} {pct:7.2f}\n")
+        if len(label) > 70 and " [returned" in label:
+            f.write(f"    ({label[label.index('[returned') + 1:].rstrip(']')})\n")
     log = os.path.join(SRC, "trace_stdout.log")
     if os.path.exists(log):
         for line in open(log):
@@ -41,11 +63,18 @@ print(open(os.path.join(DST, f"{tag}_kernel_stats_{cfg}.txt")).read()[:3000])
 # 2. PMC passes: FETCH_SIZE / WRITE_SIZE are in KiB per dispatch
 def per_kernel(db, counter):
     c = sqlite3.connect(db)
+    vals = {}
+    for name, value in c.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
+        vals.setdefault(short(name), []).append(value)
     out = {}
-    q = ("select kernel_name, count(*), avg(value), min(value), max(value) from counters_collection "
-         "where counter_name = ? group by kernel_name")
-    for name, n, avg, lo, hi in c.execute(q, (counter,)):
-        out[short(name)] = dict(dispatches=n, avg_kib=avg, min_kib=lo, max_kib=hi)
+    for name, v in vals.items():
+        skipped = 0
+        if "sweep_" in name:          # (dispatches that returned at once behind a resampling update moved nothing)
+            ran = [x for x in v if x >= 0.05 * max(v)]
+            skipped, v = len(v) - len(ran), ran
+        out[name] = dict(dispatches=len(v), avg_kib=sum(v) / len(v), min_kib=min(v), max_kib=max(v))
+        if skipped:
+            out[name]["dispatches_that_returned_at_once"] = skipped
     return out
 
 
@@ -99,11 +128,14 @@ sq_db = os.path.join(ROOT, "gpurun_out", "prof_sq", "sq") if cfg == "c3" else ""
 dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(sq_db) for f in fs if f.endswith(".db")] if os.path.isdir(sq_db) else []
 if dbs:
     c = sqlite3.connect(dbs[0])
-    q = ("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
-         "where kernel_name like '%sweep_kernel%' group by kernel_name, counter_name")
+    q = ("select kernel_name, counter_name, value from counters_collection where kernel_name like '%sweep_kernel%'")
+    vals = {}
+    for name, counter, value in c.execute(q):
+        vals.setdefault((short(name), counter), []).append(value)
     out = {}
-    for name, counter, n, avg in c.execute(q):
-        out.setdefault(short(name), {"dispatches": n})[counter] = avg
+    for (name, counter), v in vals.items():
+        ran = [x for x in v if x >= 0.05 * max(v)]       # (not the dispatches that returned at once, see above)
+        out.setdefault(name, {"dispatches": len(ran)})[counter] = sum(ran) / len(ran)
     for k, v in out.items():
         if "GRBM_GUI_ACTIVE" in v and "SQ_ACTIVE_INST_VALU" in v:
             # GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_* counters are in quad-cycles summed over
