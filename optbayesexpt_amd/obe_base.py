@@ -478,7 +478,7 @@ class OptBayesExpt(ParticlePDF):
     # cloud is still the one it swept and every input of the sweep is what a fresh launch would use — the
     # same kernels on the same data, hence the same bits.  tuning_parameters['speculative_sweep']: 'auto'
     # (default), True (from the first update on), False (never).  Measured (MI355X, tools/spec_cycles.py,
-    # tools/shard_cycle.py): the plain cycle of 4096 settings x 262 144 particles 0.333 -> 0.314 ms, of one
+    # tools/shard_cycle.py): the plain cycle of 4096 settings x 262 144 particles 0.314 -> 0.288 ms, of one
     # rank's 8192 x 1 048 576 slice 1.877 -> 1.845 ms.
     def _speculation_wanted(self, after_resample=False):
         mode = self.tuning_parameters.get("speculative_sweep", _SPECULATIVE_DEFAULT)
