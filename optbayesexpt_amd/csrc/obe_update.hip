@@ -96,7 +96,8 @@ __device__ __forceinline__ bool sweep_prologue(const SweepCtl& c, double* red) {
 // pass A, model fused
 // (round 4, measured and not kept: issuing the loads of 6 particles per thread together before their ~170
 // dependent FP64 instructions each — 23.2 vs 23.0 us per update at 1 M particles, 17.4 vs 15.7 at 262 144:
-// three waves per SIMD already hide the latency)
+// three waves per SIMD already hide the latency; t stored with __builtin_nontemporal_store so that the kernel
+// boundary has less to write back: 21.8 vs 21.8-22.6 us at 1 M particles, 47.1 vs 50.2 us with 10 parameters)
 template <class M>
 __global__ __launch_bounds__(kBlock) void update_model_kernel(
     obe_model m, SettingArg st, LikArgs la, const double* __restrict__ particles, int64_t ld,
