@@ -408,6 +408,8 @@ __device__ __forceinline__ void block_argmax(Best b, double* bv, int64_t* bi) {
 // entries past L1, the host words) costs what argmax_fold costs.
 constexpr int kFinGroupsMany = 16, kFinGroupsFew = 4;      // chunk groups = wavefronts of a finalize workgroup
 constexpr int kFinManyChunks = 64;
+constexpr int kFinNarrow = 16;             // settings per workgroup of the narrow form (see sweep_finalize) ...
+constexpr int kFinNarrowBelow = 128;       // ... used while 64 settings per workgroup would make fewer workgroups than this
 
 // worst cancellation factor so far; a NaN (some variance is NaN) is sticky
 __device__ __forceinline__ double kappa_worst(double a, double b) {
@@ -462,8 +464,13 @@ __device__ __forceinline__ void write_result_record(double* out_v, int64_t* out_
     deliver(host, b.v, b.i, k);
 }
 
-template <int FG>
-__global__ __launch_bounds__(FG * kWave) void sweep_finalize(const double* __restrict__ part1,
+// WS = settings per workgroup: 64 (a wavefront per chunk group), or 16 — then a wavefront holds FOUR chunk groups
+// of 16 settings each and the workgroup is a quarter as large, so that a grid of few settings still spreads over
+// the chip: 2048 settings x 1024 chunks (one rank's slice of the 7-peak config, 33.5 MB of partials) was 32
+// workgroups = 32 CUs, 20.4 us; 128 workgroups: see DESIGN.md K1.  Every setting's chunks are summed by the same
+// FG groups in the same order either way: identical bits.
+template <int FG, int WS = kFinSettings>
+__global__ __launch_bounds__(FG * WS) void sweep_finalize(const double* __restrict__ part1,
                                                              const double* __restrict__ part2, int nchunks, int nc,
                                                              int64_t ns, const double* __restrict__ moments,
                                                              int full_mode, UtilArgs ua,
@@ -472,12 +479,14 @@ __global__ __launch_bounds__(FG * kWave) void sweep_finalize(const double* __res
                                                              double* __restrict__ utility, double* __restrict__ bv,
                                                              int64_t* __restrict__ bi, double* __restrict__ bk,
                                                              const unsigned* abort) {
-    __shared__ double acc1[OBE_MAX_CHANNELS][FG][kFinSettings];
-    __shared__ double acc2[OBE_MAX_CHANNELS][FG][kFinSettings];
+    static_assert(WS == 64 || WS == 16, "a wavefront holds one or four chunk groups");
+    __shared__ double acc1[OBE_MAX_CHANNELS][FG][WS];
+    __shared__ double acc2[OBE_MAX_CHANNELS][FG][WS];
     if (sweep_aborted(abort)) return;
     const double W = full_mode ? moments[0] : 1.0;
-    const int lane = threadIdx.x & (kWave - 1), grp = threadIdx.x / kWave;
-    const int64_t s = (int64_t)blockIdx.x * kFinSettings + lane;
+    const int wlane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int lane = wlane % WS, grp = wave * (kWave / WS) + wlane / WS;      // setting within the tile, chunk group
+    const int64_t s = (int64_t)blockIdx.x * WS + lane;
     for (int c = 0; c < nc; ++c) {
         double a1 = 0.0, a2 = 0.0;
         if (s < ns) {
@@ -506,10 +515,10 @@ __global__ __launch_bounds__(FG * kWave) void sweep_finalize(const double* __res
         acc2[c][grp][lane] = a2;
     }
     __syncthreads();
-    if (grp != 0) return;
+    if (wave != 0) return;
     Best best{-INFINITY, INT64_MAX};
     double kappa = 0.0;     // worst (mean of y')^2 / var: the cancellation an UNSHIFTED sweep would suffer
-    if (s < ns) {
+    if (grp == 0 && s < ns) {
         double var[OBE_MAX_CHANNELS];
         for (int c = 0; c < nc; ++c) {
             double a1 = 0.0, a2 = 0.0;
@@ -537,7 +546,7 @@ __global__ __launch_bounds__(FG * kWave) void sweep_finalize(const double* __res
         best = Best{u, s};
     }
     wave_best(best, kappa);
-    if (lane == 0) {
+    if (wlane == 0) {
         bv[blockIdx.x] = best.v;
         bi[blockIdx.x] = best.i;
         bk[blockIdx.x] = kappa;
@@ -975,9 +984,15 @@ int obe_sweep_utility(const obe_model* m, const double* d_settings, int64_t ld_s
         return e;
     });
     if (rc) return rc;
-    const int nb = static_cast<int>((n_settings + kFinSettings - 1) / kFinSettings);
+    int nb = static_cast<int>((n_settings + kFinSettings - 1) / kFinSettings);
     if (nb > kFinMaxBlocks) return bad_arg("obe_sweep_utility: more than 4 194 304 settings per call");
-    if (plan.nchunks >= kFinManyChunks)
+    static const bool no_narrow = getenv("OBE_FINALIZE_NARROW") && atoi(getenv("OBE_FINALIZE_NARROW")) == 0;   // A/B
+    if (plan.nchunks >= kFinManyChunks && nb < kFinNarrowBelow && !no_narrow) {
+        nb = static_cast<int>((n_settings + kFinNarrow - 1) / kFinNarrow);       // (< 512: within the argmax slots)
+        sweep_finalize<kFinGroupsMany, kFinNarrow><<<nb, kFinGroupsMany * kFinNarrow, 0, st>>>(
+            w.part1, w.part2, plan.nchunks, mm.n_channels, n_settings, d_moments, d_draw_idx == nullptr, ua, w.cs,
+            d_yvar, d_utility, w.bv, w.bi, w.bk, a.abort);
+    } else if (plan.nchunks >= kFinManyChunks)
         sweep_finalize<kFinGroupsMany><<<nb, kFinGroupsMany * kWave, 0, st>>>(
             w.part1, w.part2, plan.nchunks, mm.n_channels, n_settings, d_moments, d_draw_idx == nullptr, ua, w.cs,
             d_yvar, d_utility, w.bv, w.bi, w.bk, a.abort);
