@@ -42,6 +42,16 @@ __device__ __forceinline__ double fast_rcp(double q) {
 #endif
 }
 
+// The 1-ulp form, r (1 + e + e^2), where a reciprocal is not shared (N = 1: one setting per lane, i.e. the sweeps
+// of at most a few hundred settings, whose time is launch latency): with a handful of draws nothing averages the
+// one-sided 2e-15 of fast_rcp down, and at kappa = (mean of y)^2 / var ~ 1e9 (a cloud of 2 particles, 10 draws:
+// tools/fuzz_parity.py 300 5, case 185) it showed as 1.7e-10 in one utility value.
+__device__ __forceinline__ double exact_rcp(double q) {
+    const double r = __builtin_amdgcn_rcp(q);
+    const double e = fma(-q, r, 1.0);
+    return fma(r, fma(e, e, e), r);
+}
+
 // Batch inversion: r[j] = 1/q[j] for N values from one reciprocal of their product
 // (3(N-1) multiplies + 1 rcp instead of N rcp + 4N Newton FMAs).  q >= 1 on every
 // direct caller, so the product cannot underflow; it overflows only beyond q ~ 1e77.
@@ -49,7 +59,7 @@ __device__ __forceinline__ double fast_rcp(double q) {
 template <int N>
 __device__ __forceinline__ double batch_rcp(const double (&q)[N], double (&r)[N]) {
     if constexpr (N == 1) {
-        r[0] = fast_rcp(q[0]);
+        r[0] = exact_rcp(q[0]);
         return r[0];
     } else if constexpr (N == 2) {
         const double inv = fast_rcp(q[0] * q[1]);
@@ -250,7 +260,7 @@ __device__ __forceinline__ void batch_rcp_poisoned(const double (&q)[N], double 
 template <int N>
 __device__ __forceinline__ void batch_div_ge1(const double (&q)[N], double s, double (&ip)[(N + 1) / 2]) {
     if constexpr (N == 1) {
-        ip[0] = s * fast_rcp(q[0]);
+        ip[0] = s * exact_rcp(q[0]);
     } else if constexpr (N == 2) {
         const double pp = q[0] * q[1];
         ip[0] = poison_unless(pp < 1e250, fast_rcp(pp)) * s;
@@ -443,7 +453,7 @@ struct Lorentz {
                 q[j] = fma(t, t, 1.0);
             }
             if constexpr (SPT == 1) {
-                v[0][0] = fma(pk[K], fast_rcp(q[0]), v[0][0]);
+                v[0][0] = fma(pk[K], exact_rcp(q[0]), v[0][0]);
             } else {
                 // Batch inversion stopped one level early: invert the SPT/2 pair products, fold
                 // the amplitude into each pair inverse, and let the final multiply by the sibling

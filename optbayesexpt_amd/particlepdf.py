@@ -316,9 +316,14 @@ class ParticlePDF:
     def _device_rng_ok(self, n_uniform, n_normal):
         """Whether self.rng can be continued on the device for this many draws: a Generator over PCG64,
         a request large enough to pay for the launches, tuning_parameters['device_rng'] not False."""
-        if not self.tuning_parameters.get("device_rng", True):
-            return False
-        return n_uniform + n_normal >= _devrng.MIN_DEVICE_DRAWS and _devrng.pcg64_state(self.rng) is not None
+        return self._device_rng_state(n_uniform, n_normal) is not None
+
+    def _device_rng_state(self, n_uniform, n_normal):
+        """(state dict, uint64[4]) of self.rng if it can be continued on the device for this many draws, else
+        None (reading the state costs ~6 us: resample() hands it on to the pipelined path)."""
+        if not self.tuning_parameters.get("device_rng", True) or n_uniform + n_normal < _devrng.MIN_DEVICE_DRAWS:
+            return None
+        return _devrng.pcg64_state(self.rng)
 
     def _device_stream(self, n_uniform, n_normal):
         """A device-side continuation of self.rng for this many draws, or None (then self.rng is
@@ -432,8 +437,9 @@ class ParticlePDF:
         n, d = self.n_particles, self.n_dims
         method = self.tuning_parameters.get("resample_method", "multinomial")
         if method == "multinomial":                       # the reference: N i.i.d. uniforms
-            if self._device_rng_ok(n, n * d) and self.tuning_parameters.get("pipelined_resample", True):
-                return self._resample_pipelined()
+            state = self._device_rng_state(n, n * d)
+            if state is not None and self.tuning_parameters.get("pipelined_resample", True):
+                return self._resample_pipelined(state)
             rstream = self._device_stream(n, n * d)       # exact continuation of self.rng, or None
             idx = self._draw_indices(n, rstream)
         elif method == "systematic":                      # extension: ONE uniform, draws at (i + u0)/N
@@ -510,10 +516,14 @@ class ParticlePDF:
             uni=torch.empty(n, dtype=torch.float64, device=dev),
             normals=torch.empty(n * d, dtype=torch.float64, device=dev),
             zig_ws=torch.empty(zig_bytes // 8 + 1, dtype=torch.float64, device=dev), tables=_devrng._tables(dev),
-            pin_f=pin_f, pin_i=pin_i, p_f=_lib.host_ptr(pin_f), p_i=_lib.host_ptr(pin_i))
+            pin_f=pin_f, pin_i=pin_i, p_f=_lib.host_ptr(pin_f), p_i=_lib.host_ptr(pin_i),
+            # the drawn indices, two buffers used in turn: last_resample_indices_device of one resample stays
+            # what it was through the next one
+            idx=(torch.empty(n, dtype=torch.int64, device=dev), torch.empty(n, dtype=torch.int64, device=dev)),
+            flip=0)
         return b
 
-    def _resample_pipelined(self):
+    def _resample_pipelined(self, state=None):
         """resample() with the caller's generator continued on the device.  ONE library call
         (obe_resample_begin) enqueues CDF, uniforms, search, covariance and the ziggurat normals back to
         back; the host waits — by watching the page-locked words of the covariance block — for
@@ -524,7 +534,7 @@ class ParticlePDF:
         n, d = self.n_particles, self.n_dims
         if self._weights.shape[0] != n:
             raise ValueError("a and p must have same size")
-        st, h_state = _devrng.pcg64_state(self._rng)
+        st, h_state = state if state is not None else _devrng.pcg64_state(self._rng)
         strict = bool(self.tuning_parameters.get("strict_cdf", False))
         key = (self._weights.version, strict)
         p, w = self._pw_tensors()
@@ -533,7 +543,8 @@ class ParticlePDF:
             self._cdf_key = None
         b = self._resample_buffers(n, d)
         mlen = self._lib.moments_len(d)
-        idx = torch.empty(n, dtype=torch.int64, device=self._device)
+        b["flip"] ^= 1
+        idx = b["idx"][b["flip"]]
         mkey = (self._particles.version, self._weights.version)
         have_first = self._mom_host_key is not None and self._mom_host_key[:2] == mkey \
             and self._mom_dev_key is not None and self._mom_dev_key[:2] == mkey

@@ -174,8 +174,17 @@ def run_case(case):
                     (not case["full"] and len(np.unique(b.last_draw_indices)) == 1):
                 return        # all draws identical: the reference's variance is rounding
             ua = a.last_utility if case.get("yspace") else a._gather_settings(a._utility_dev.reshape(1, -1))[0]
-            close(np.asarray(ua).reshape(-1), np.asarray(b.last_utility).reshape(-1), f"{tag} utility",
-                  rtol=1e-9 if case.get("yspace") or case["n_draws"] < 5 or case.get("expression") else 1e-10)
+            rtol = 1e-9 if case.get("yspace") or case["n_draws"] < 5 or case.get("expression") else 1e-10
+            if not case["full"]:
+                # The sweep rounds each draw's packed terms once (x0 / d: eps |x0 / d|) before they meet the
+                # setting, the reference forms (x - x0) / d: against a cloud of spread s that is ~eps |x0| / s
+                # of a variance, averaged down only by sqrt(draws) — 1.7e-10 for 10 draws of a 2-particle cloud
+                # whose peak position is known to 1e-6 (case 185 of seed 5); DESIGN.md section 5.
+                drawn = np.asarray(b.particles)[:, np.asarray(b.last_draw_indices).reshape(-1)]
+                sd, mu = drawn.std(axis=1), np.abs(drawn.mean(axis=1))
+                ratio = float(np.max(mu[sd > 0] / sd[sd > 0])) if np.any(sd > 0) else 0.0
+                rtol = max(rtol, 3 * 4.4e-16 * ratio / np.sqrt(drawn.shape[1]))
+            close(np.asarray(ua).reshape(-1), np.asarray(b.last_utility).reshape(-1), f"{tag} utility", rtol=rtol)
         else:
             xb = b.good_setting(pickiness=7)
             if np.max(b.last_utility) <= 1e-20 * sigma ** -2 or \
