@@ -102,6 +102,12 @@ class OptBayesExpt(ParticlePDF):
         a :class:`~optbayesexpt_amd.dist.SettingsShard`; this process then sweeps only
         its contiguous slice of the settings and ``opt_setting`` combines the per-rank
         maxima with one all-gather.
+    ``tuning_parameters['speculative_sweep']`` (``'auto'``, ``True``, ``False``; ``variance_full`` only)
+        ``pdf_update()`` enqueues the sweep of the next ``opt_setting()`` behind its update (see
+        ``_speculation_wanted``): the same results, one host round trip per cycle less.
+    ``tuning_parameters['sweep_shift']`` (``'auto'``, ``'always'``, ``'never'``), ``['fused_moments']``,
+    ``['replica_check_every']``
+        see ``_sweep_device``, ``pdf_update``, ``check_replicas``.
     """
 
     #: hysteresis of the unshifted sweep (see _sweep_device).  Measured (tools/kappa_error.py, 262 144
