@@ -59,3 +59,20 @@ def test_one_cycle_from_plain_c(hip, tmp_path):
     assert_allclose(mean, oracle.weighted_mean(prior, ref_w), rtol=1e-10)
     assert_allclose(std, oracle.weighted_std(prior, ref_w), rtol=1e-7)
     assert kappa >= 0.0
+
+
+def test_enqueued_cycle_from_plain_c(hip, tmp_path):
+    """examples/c_abi_pipelined.c: the update enqueued without waiting and the sweep behind it
+    (OBE_SWEEP_SPECULATIVE), from C — the program itself compares with the synchronous calls bit for bit and
+    checks that a sweep behind a resampling update does nothing."""
+    rocm = "/opt/rocm"
+    if shutil.which("gcc") is None or not os.path.exists(os.path.join(rocm, "include", "hip", "hip_runtime_api.h")):
+        pytest.skip("gcc or the HIP runtime headers are not installed")
+    libdir = os.path.join(ROOT, "optbayesexpt_amd", "lib")
+    exe = str(tmp_path / "c_abi_pipelined")
+    subprocess.run(["gcc", "-std=c11", "-O2", "-D__HIP_PLATFORM_AMD__", f"-I{rocm}/include", f"-I{ROOT}/include",
+                    os.path.join(ROOT, "examples", "c_abi_pipelined.c"), f"-L{libdir}", "-lobe_hip", f"-L{rocm}/lib",
+                    "-lamdhip64", "-lm", f"-Wl,-rpath,{libdir}", f"-Wl,-rpath,{rocm}/lib", "-o", exe], check=True)
+    r = subprocess.run([exe, "2500", "150000"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "identical to the synchronous one" in r.stdout and "did nothing" in r.stdout
