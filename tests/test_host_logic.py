@@ -358,3 +358,32 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
                        text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr
+
+
+def test_bench_boundary_update_runs_without_the_enqueued_sweep():
+    """bench.update_at_boundary: the last update before a timed region starts or ends must not enqueue the next
+    cycle's sweep (a timed region of K cycles then holds exactly K sweeps), and leaves the object's tuning
+    parameters as it found them — also when the update raises."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    class Stub:
+        def __init__(self, tp, fail=False):
+            self.tuning_parameters, self.seen, self.fail = tp, [], fail
+
+        def pdf_update(self, record):
+            self.seen.append((record, self.tuning_parameters.get("speculative_sweep", "absent")))
+            if self.fail:
+                raise RuntimeError("boom")
+
+    for before in ({}, {"speculative_sweep": "auto"}, {"speculative_sweep": True, "a_param": 0.98}):
+        o = Stub(dict(before))
+        bench.update_at_boundary(o, ("x", 1.0))
+        assert o.seen == [(("x", 1.0), False)] and o.tuning_parameters == before
+    o = Stub({"speculative_sweep": True}, fail=True)
+    with pytest.raises(RuntimeError):
+        bench.update_at_boundary(o, ("x", 1.0))
+    assert o.tuning_parameters == {"speculative_sweep": True}
