@@ -61,6 +61,7 @@ class OptBayesExptSweeper(OptBayesExptNoiseParameter):
         on the host path exactly as in the one-by-one loop, then the rest of the sweep follows."""
         (setting_values,), result_values = measurement_record
         points = list(zip(setting_values, result_values))
+        self.last_sweep_batches = []            # (points submitted, points applied) per device batch; empty: point by point
         if not points:
             return None
         batch = self._sweep_batch_inputs(points)
@@ -74,7 +75,6 @@ class OptBayesExptSweeper(OptBayesExptNoiseParameter):
         if par.shape[1] != w.shape[0]:
             raise ValueError("parameters and particle_weights have different lengths")
         pos, chunk, out = 0, self.SWEEP_BATCH_MIN, self._host_out
-        self.last_sweep_batches = []            # (points submitted, points applied) per device batch
         while pos < len(points):
             k = min(chunk, len(points) - pos)
             par, w = self._parameters.tensor(), self._weights.tensor()

@@ -122,6 +122,11 @@ def test_reference_style_host_subclass_runs_unchanged(hip):
         assert_array_equal(h.particles, d.particles)
         assert sum(a for _, a in d.last_sweep_batches) == len(xs)
         assert len(d.last_sweep_batches) < len(xs) or len(xs) < 3
+    # a sweep of ONE point goes through the per-point path: no device batches, and none left over from the sweep before
+    h.pdf_update(((xs[:1],), ys[:1]))
+    d.pdf_update(((xs[:1],), ys[:1]))
+    assert d.last_sweep_batches == []
+    assert_array_equal(h.particle_weights, d.particle_weights)
 
 
 def test_sweeper_overridden_cost_and_other_selection_methods(hip):
