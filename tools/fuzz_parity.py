@@ -184,6 +184,16 @@ def run_case(case):
                 sd, mu = drawn.std(axis=1), np.abs(drawn.mean(axis=1))
                 ratio = float(np.max(mu[sd > 0] / sd[sd > 0])) if np.any(sd > 0) else 0.0
                 rtol = max(rtol, 3 * 4.4e-16 * ratio / np.sqrt(drawn.shape[1]))
+            # ... and every evaluation of the model carries its own rounding, eps_y relative (a few 1e-16 for the
+            # rational models, ~2e-15 where exp / cos / hypot are involved): against a spread of y that is 1 / sqrt(kappa)
+            # of y — the sweep reports kappa = (mean y)^2 / var, worst over the settings — that is 2 eps_y sqrt(kappa) of a
+            # variance, averaged down by the square root of the effective number of draws.  A cloud of 2 particles a
+            # resample has contracted reaches kappa ~ 5e9 (case 9079 of seed 5151: 1.4e-9 in a variance of 2e-10).
+            kap = float(getattr(a, "last_sweep", {}).get("kappa", 0.0) or 0.0)
+            if np.isfinite(kap) and kap > 0.0 and not case.get("yspace"):
+                eps_y = 2e-15 if case["kind"] in ("rabi", "coil") or case.get("expression") else 4e-16
+                n_eff = 1.0 / float(np.sum(np.asarray(wb0) ** 2)) if case["full"] else float(case["n_draws"])
+                rtol = max(rtol, 4.0 * eps_y * np.sqrt(kap) / np.sqrt(max(n_eff, 1.0)))
             close(np.asarray(ua).reshape(-1), np.asarray(b.last_utility).reshape(-1), f"{tag} utility", rtol=rtol)
         else:
             xb = b.good_setting(pickiness=7)
@@ -223,7 +233,14 @@ def run_case(case):
             if numpy_rejects(wpost):
                 return
             raise
-        b.pdf_update(rec)
+        try:
+            b.pdf_update(rec)
+        except np.linalg.LinAlgError:
+            # the other way round: the oracle's covariance came out non-finite where the device's is merely huge
+            # (case 10394 of seed 9090: 7 particles, one of them carrying the weight)
+            if np.sum(wpost) - np.sum(wpost * wpost) / np.sum(wpost) < 1e-6:
+                return
+            raise AssertionError(f"{tag}: LinAlgError in the oracle only")
         assert bool(a.just_resampled) == bool(b.just_resampled), f"{tag}: resample decision"
         wb = np.asarray(b.particle_weights)
         if b.just_resampled:
