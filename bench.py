@@ -26,7 +26,11 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   cpu_baseline_allcores — the plain C + OpenMP restatement on every host core (full-sweep configs).
   published_workload — the loop behind the only timing the reference publishes for this path (200 settings x
                   30 draws, 50 000 particles: 4.37 ms per cycle, hardware unstated), through this package.
-  other_configs — (default c3 run, N = 1) the cycle loops of c1, c2 and c5 after the timed region.
+  other_configs — (default c3 run, N = 1) the cycle loops of c1, c2 and c5 after the timed region, each with its
+                  own bounded CPU leg.
+  rccl          — (N > 1, or --force-dist) what the communicator itself reports: its world size, an all-gather of
+                  the rank ids, the measured arg-max combine (in the timed cycles and on an idle stream) and
+                  every rank's cycle / K1 / everything-else milliseconds.
 With --gpus N > 1 and no launcher around it (no WORLD_SIZE in the environment) the script starts its N
 ranks itself, as fresh child processes, before anything here touches the GPU.
 """
@@ -127,7 +131,7 @@ def cpu_baseline(cfg, settings, prior, cons, true, sigma, target_s=8.0):
     # evenly spaced sub-grids of 64 settings each, one full cycle per sub-grid (sweep of the sub-grid over the
     # whole cloud + the full update), until the time budget is used: the sample is bounded by the clock, not
     # by an extrapolation from a probe (round 3's probe undershot: 20.8 s for a 10 s target)
-    step = min(64, ns)
+    step = min(64 if target_s >= 6.0 else 8, ns)       # (a short leg takes smaller blocks: the clock is checked per block)
     n_blocks = ns // step
     n_used, t0 = 0, time.perf_counter()
     for b in range(0, n_blocks, max(1, n_blocks // 32)):           # up to 32 blocks, evenly spaced over the grid
@@ -264,6 +268,61 @@ def launch_ranks(n, argv):
         sys.stderr.write(f"bench.py: ranks failed (rank, exit code): {bad}\n")
         return 1
     return 0
+
+
+def collective_report(obe, shard, backend, world, rank, ns, steps, elapsed_local, k1_total_ms, k1_launches):
+    """The "rccl" block of an N > 1 line: proof that the communicator saw N ranks, and where each rank's time
+    went.  (1) an all-gather in which every rank contributes its rank id; (2) the arg-max combine of the timed
+    cycles: device microseconds between this rank's record being ready and everybody's having arrived (events
+    on the launch stream around the all-gather: the collective itself + the skew between the ranks' sweeps);
+    (3) the same call on an idle stream, 200 times back to back: the bare latency of the 32-byte all-gather +
+    copy to the host; (4) per rank: ms per cycle, K1 ms per sweep, everything else — min and max over the ranks."""
+    import torch
+    import torch.distributed as dist
+    from optbayesexpt_amd import _lib
+    dev = "cuda" if backend == "nccl" else "cpu"
+    timing, shard.timing = shard.timing or [], None
+    ids = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(ids, torch.tensor([rank], dtype=torch.int64, device=dev))
+    ids = ids.cpu().tolist()
+    off = _lib.OBE_WS_RESULT_OFFSET
+    rec = obe._ws[off:off + 4].clone()
+    torch.cuda.synchronize()
+    dist.barrier()
+    idle = []
+    for _ in range(200):
+        t0 = time.perf_counter()
+        shard.combine_records(rec, ns)
+        idle.append(1e6 * (time.perf_counter() - t0))
+    in_cycle_dev = [a for a, _ in timing]
+    in_cycle_host = [b for _, b in timing]
+    cycle_ms = 1e3 * elapsed_local / steps
+    k1_ms = k1_total_ms / max(k1_launches, 1)
+    k1_per_cycle = k1_total_ms / steps
+    mine = torch.tensor([cycle_ms, k1_ms, cycle_ms - k1_per_cycle,
+                         float(np.median(in_cycle_dev)) if in_cycle_dev else float("nan"),
+                         float(np.max(in_cycle_dev)) if in_cycle_dev else float("nan"),
+                         float(np.median(idle)), float(len(timing)), float(k1_launches)],
+                        dtype=torch.float64, device=dev)
+    table = torch.empty(world * mine.numel(), dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(table, mine)
+    table = table.cpu().numpy().reshape(world, -1)
+
+    def span(col):
+        return {"min": float(np.nanmin(table[:, col])), "max": float(np.nanmax(table[:, col])),
+                "per_rank": [float(v) for v in table[:, col]]}
+
+    return {"backend": dist.get_backend(), "world_size_reported_by_backend": dist.get_world_size(),
+            "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None),
+            "all_gather_rank_ids": ids, "all_gather_rank_ids_ok": ids == list(range(world)),
+            "combines_in_timed_steps": int(table[0, 6]), "sweep_launches_in_timed_steps": int(table[0, 7]),
+            "cycle_ms": span(0), "k1_ms_per_sweep": span(1), "non_k1_ms_per_cycle": span(2),
+            "combine_us_in_cycle_median": span(3), "combine_us_in_cycle_max": span(4),
+            "combine_us_in_cycle_note": "events on the launch stream around the 32-byte all-gather of the arg-max "
+                                        "records: the collective + the wait for the slowest rank's sweep",
+            "combine_us_idle_median": span(5),
+            "combine_us_idle_note": "200 back-to-back combine_records() calls on an idle stream (host clock): "
+                                    "all-gather + copy of the records to the host + stream synchronisation"}
 
 
 def update_at_boundary(obe, record):
@@ -443,6 +502,8 @@ def main():
     barrier()
     # K1 inside the timed cycles: HIP events around every sweep-kernel launch on its own stream
     obe._mlib.call("obe_sweep_timing", 1, None, None)
+    if shard is not None:
+        shard.timing = []                 # ... and events around every arg-max all-gather (dist.SettingsShard.timing)
     t0 = time.perf_counter()
     resamples = 0
     step_ms, step_resampled = [], []
@@ -456,10 +517,14 @@ def main():
     elapsed = time.perf_counter() - t0
     k1_total_ms, k1_launches = ctypes.c_double(0.0), ctypes.c_int64(0)
     obe._mlib.call("obe_sweep_timing", 0, ctypes.byref(k1_total_ms), ctypes.byref(k1_launches))
+    rccl = None
     if use_dist:
+        elapsed_local = elapsed
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        rccl = collective_report(obe, shard, backend, world, rank, ns, args.steps, elapsed_local,
+                                 k1_total_ms.value, k1_launches.value)
 
     n_draws = obe.N_DRAWS if obe.utility_method == "variance_approx" else n_p
     evals_per_step = ns * n_draws + n_p
@@ -612,6 +677,8 @@ def main():
                       "median_ms_resample_cycle": (float(np.median([m for m, r in zip(step_ms, step_resampled) if r]))
                                                    if resamples else None)},
            "roofline": roofline, "roofline_update": roofline_update}
+    if rccl is not None:
+        out["rccl"] = rccl
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # (before the CPU legs: the 128-thread OpenMP run leaves the host busy for a while, and this loop is
         # ~25 us of host time per cycle)
@@ -633,11 +700,28 @@ def main():
         out["other_configs"] = others
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, settings, prior, cons, true, sigma)
+        # ... and a short leg of the same kind next to every other config's throughput (north_star: the NumPy path
+        # "next to" each reported number): ~2 s each on one core; c1 through the oracle class itself
+        for name, entry in out.get("other_configs", {}).items():
+            if "error" in entry:
+                continue
+            try:
+                entry["cpu_baseline"] = cpu_baseline(name, *make_workload(name), target_s=2.0)
+                entry["vs_cpu_1core"] = entry["value"] / entry["cpu_baseline"]["value"]
+            except Exception as exc:
+                entry["cpu_baseline"] = {"error": str(exc)[:200]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and full_sweep_mode:
         try:
             out["cpu_baseline_allcores"] = cpu_baseline_allcores(cfg, settings, prior, cons, true, sigma)
         except Exception as exc:          # no gcc/OpenMP on the box: the 1-core figure stands alone
             out["cpu_baseline_allcores"] = {"error": str(exc)[:200]}
+        for name, entry in out.get("other_configs", {}).items():
+            if "error" in entry or CONFIGS[name][0] < 1024:          # (c1's reference-semantics cycle has no C restatement)
+                continue
+            try:
+                entry["cpu_baseline_allcores"] = cpu_baseline_allcores(name, *make_workload(name), target_s=1.0)
+            except Exception as exc:
+                entry["cpu_baseline_allcores"] = {"error": str(exc)[:200]}
     if rank == 0:
         print(json.dumps(out))
     if use_dist:

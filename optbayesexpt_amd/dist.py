@@ -57,6 +57,11 @@ class SettingsShard:
             rank, world_size = dist.get_rank(group), dist.get_world_size(group)
         self.rank, self.world_size = int(rank), int(world_size)
         self._record_bufs = {}        # device -> (all-gather receive buffer, page-locked host copy)
+        #: None, or a list that bench.py hangs here while it times cycles: every arg-max combine appends
+        #: (device microseconds between "this rank's record is ready" and "everybody's has arrived" — events
+        #: on the launch stream around the all-gather —, host microseconds of the whole call incl. the wait
+        #: for this rank's own sweep)
+        self.timing = None
         self._starts = {}             # n_settings -> first global index of every rank's slice
 
     def bounds(self, n_settings):
@@ -103,11 +108,25 @@ class SettingsShard:
             bufs[dev] = (torch.empty(4 * w, dtype=torch.float64, device=dev),
                          host.pin_memory() if dev.type == "cuda" else host)
         gathered, host = bufs[dev]
+        timing = self.timing
+        if timing is not None:
+            import time
+            t0 = time.perf_counter()
+            if dev.type == "cuda":
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
         dist.all_gather_into_tensor(gathered, record.contiguous().to(dev), group=self.group)
         if dev.type != "cuda":
+            if timing is not None:
+                us = 1e6 * (time.perf_counter() - t0)
+                timing.append((us, us))
             return gathered.clone().reshape(w, 4)
+        if timing is not None:
+            e1.record()
         host.copy_(gathered, non_blocking=True)       # one asynchronous copy, one wait
         torch.cuda.current_stream(dev).synchronize()
+        if timing is not None:
+            timing.append((1e3 * e0.elapsed_time(e1), 1e6 * (time.perf_counter() - t0)))
         return host.clone().reshape(w, 4)
 
     def broadcast_from_rank0(self, values, device="cpu"):

@@ -15,7 +15,7 @@ OUT = os.path.join(HERE, "_build", "libcsweep.so")
 def build(verbose=False):
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     if not os.path.exists(OUT) or os.path.getmtime(OUT) < os.path.getmtime(SRC):
-        cmd = ["gcc", "-O3", "-mavx2", "-mfma", "-fopenmp", "-shared", "-fPIC", SRC, "-o", OUT, "-lm"]
+        cmd = ["gcc", "-O3", "-mavx2", "-ffp-contract=off", "-fopenmp", "-shared", "-fPIC", SRC, "-o", OUT, "-lm"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"gcc failed:\n{r.stdout}\n{r.stderr}")

@@ -262,3 +262,34 @@ def replay_state_reset(fx, obe, rtol, get_draw_idx, get_utility, get_resample_id
         assert np.all(np.abs(np.asarray(obe.std()) - sd) <= tol), f"std, cycle {cyc}"
         close(obe.covariance(), fx["cov"][cyc], rtol, f"covariance, cycle {cyc}")
     return dict(cycles=meta["n_cycles"], resamples=n_res, worst=worst)
+
+
+
+def assert_rel(got, ref, rtol=1e-10, what="", garbage_floor=0.0):
+    """Pure RELATIVE comparison of variances / utilities, element by element (no floor tied to
+    the largest reference value, so a setting whose variance is 1e-6 of the peak's is held to the same 1e-10
+    as the peak).  The failure message names the worst element.
+
+    ``garbage_floor`` (default: none) is an ABSOLUTE allowance that applies ONLY to elements whose reference
+    value is itself below it — the case of identical draws (one particle, or 30 draws that all hit the same
+    particle), where the reference's two-pass np.var is not 0 but (eps * y)^2-sized rounding debris (~1e-22
+    for y ~ 5e4) and the one-pass device variance is exactly 0 or debris of the same size: there is nothing
+    to compare relatively.  Callers that pass it say why."""
+    import numpy as np
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert np.array_equal(np.isnan(got), np.isnan(ref)), f"{what}: NaN pattern differs"
+    live = ~np.isnan(ref) & (np.abs(ref) > garbage_floor)
+    err = np.zeros(ref.shape)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        err[live] = np.abs(got[live] - ref[live]) / np.abs(ref[live])
+    err[live & (got == ref)] = 0.0                     # (inf == inf, 0 == 0)
+    if live.any():
+        k = np.unravel_index(int(np.argmax(err)), err.shape)
+        assert err[k] <= rtol, (f"{what}: worst relative error {err[k]:.3g} > {rtol:g} at element {k}: got "
+                                f"{got[k]!r}, reference {ref[k]!r} (largest reference value {np.nanmax(np.abs(ref)):.6g})")
+    dead = ~np.isnan(ref) & ~live
+    if dead.any():
+        assert np.all(np.abs(got[dead]) <= garbage_floor), \
+            f"{what}: {int(np.sum(np.abs(got[dead]) > garbage_floor))} value(s) above the debris floor {garbage_floor:g} where the reference is below it"
+    return float(err.max()) if live.any() else 0.0

@@ -1,6 +1,7 @@
 """HIP path at BASELINE.json's full sizes (GPU).  The oracle cannot sweep 65 536 x
-1 048 576 in reasonable time, so parity at these sizes is checked (i) against the
-oracle on a sample of settings with the *whole* particle cloud, and (ii) through
+1 048 576 in reasonable time, so parity at these sizes is checked (i) against the NumPy
+oracle on a sample of settings with the *whole* particle cloud, (i') against the plain-C
+restatement (oracle/csweep.c, OpenMP on the host cores) on EVERY setting, and (ii) through
 size-independent properties of the domain: permutation invariance of the cloud, exact
 power-of-two scaling, duplication invariance, shard-union == full sweep, bit-exact
 resample indices."""
@@ -46,8 +47,57 @@ def _sample_check(o, fn, settings, cons, n_sample, seed=0):
     return yvar
 
 
+def _csweep_or_skip():
+    """oracle/csweep.c (plain C + OpenMP, test infrastructure — validated against the NumPy oracle and the
+    reference in tests/test_oracle_golden.py) on the host cores of this box; skip, saying so, without gcc/OpenMP."""
+    from oracle import csweep
+    try:
+        csweep.build()
+        csweep.lib()
+    except (RuntimeError, OSError) as exc:
+        print(f"oracle/csweep.c cannot be built here (gcc / OpenMP missing?): {exc}")
+        pytest.skip("no gcc/OpenMP on this box: the full-grid independent parity check needs oracle/csweep.c")
+    return csweep
+
+
+def _full_grid_check(o, ref_yvar, ref_util, what):
+    """EVERY setting's variance and utility against the independent host computation at pure rtol, and the
+    setting opt_setting() picks against the arg-max of the INDEPENDENT utility vector (obe_base.py:463-489,
+    745-756: the reference picks from the full vector), for the shifted and the unshifted sweep."""
+    best_ref = int(np.argmax(ref_util))
+    top2 = np.sort(ref_util)[-2:]
+    report = {}
+    for mode in ("always", "never"):
+        o.tuning_parameters["sweep_shift"] = mode
+        yvar = o.yvar_from_parameter_draws()
+        assert o.last_sweep["shifted"] == (mode == "always") and not o.last_sweep["safe"], (what, mode, o.last_sweep)
+        kappa = o.last_sweep["kappa"]
+        if mode == "never" and not kappa <= o.KAPPA_LEAVE:
+            # (the product never keeps an unshifted sweep beyond KAPPA_LEAVE: it repeats it shifted)
+            report[mode] = f"kappa {kappa:.3g} > KAPPA_LEAVE: unshifted form not in use on this cloud"
+            continue
+        err = np.abs(yvar[0] - ref_yvar) / ref_yvar
+        worst = int(np.argmax(err))
+        report[mode] = f"worst rel. error {err[worst]:.3g} at setting {worst}, kappa {kappa:.3g}"
+        assert_allclose(yvar[0], ref_yvar, rtol=RTOL, atol=0.0,
+                        err_msg=f"{what}, sweep_shift={mode}: {report[mode]} (all {ref_yvar.size} settings)")
+        util = o.utility()
+        assert_allclose(util, ref_util, rtol=RTOL, atol=0.0, err_msg=f"{what}, sweep_shift={mode}: utility")
+        o.opt_setting()
+        assert o.last_setting_index == best_ref, \
+            (what, mode, o.last_setting_index, best_ref, f"gap between the two best: {(top2[1] - top2[0]) / top2[1]:.3g}")
+    o.tuning_parameters["sweep_shift"] = "auto"
+    print(f"{what}: full grid of {ref_yvar.size} settings vs oracle/csweep.c — {report}")
+    assert "worst" in report["always"]
+    return report
+
+
 @pytest.mark.parametrize("cfg,n_sample", [("c2", 24), ("c3", 10)])
-def test_full_sweep_at_baseline_size_matches_oracle_on_sampled_settings(obe, cfg, n_sample):
+def test_full_sweep_at_baseline_size_matches_oracle_on_the_whole_grid(obe, cfg, n_sample):
+    """c2 and c3 (the headline config) after three real updates: a sample of settings against the NumPy oracle
+    and ALL settings (4 096 / 65 536) against the C restatement on the host cores, variance and utility at
+    rtol 1e-10, chosen setting exact against the independent vector, shifted and unshifted."""
+    import time
     settings, prior, cons, true, sigma = bench.make_workload(cfg)
     o = bench.build_obe(cfg, None, settings, prior.copy(), cons)
     o.rng = np.random.default_rng(5)
@@ -58,11 +108,18 @@ def test_full_sweep_at_baseline_size_matches_oracle_on_sampled_settings(obe, cfg
     yvar = _sample_check(o, omodels.lorentzian, settings, cons, n_sample)
     util = o.utility()
     assert_allclose(util, yvar[0] / sigma ** 2, rtol=1e-14)
-    o.opt_setting()
-    assert o.last_setting_index == int(np.argmax(util))
+    csweep = _csweep_or_skip()
+    t0 = time.perf_counter()
+    ref = csweep.lorentz_yvar(settings[0], np.array(o.particles), np.array(w), cons[0], 1)
+    print(f"{cfg}: csweep over {settings[0].size} x {w.size} on {csweep.threads()} threads: {time.perf_counter() - t0:.1f} s")
+    _full_grid_check(o, ref, ref / sigma ** 2, cfg)
 
 
-def test_c5_ten_parameter_noise_model_matches_oracle_on_sampled_settings(obe):
+def test_c5_ten_parameter_noise_model_matches_oracle_on_the_whole_grid(obe):
+    """c5 (7 peaks, 10 parameters, noise-parameter class) after three real updates: 8 sampled settings against
+    the NumPy oracle, then all 16 384 variances and utilities (variance / weighted mean of sigma^2,
+    obe_noiseparam.py:122-136) against the C restatement, and the chosen setting against its arg-max."""
+    import time
     settings, prior, cons, true, sigma = bench.make_workload("c5")
     o = bench.build_obe("c5", None, settings, prior.copy(), cons)
     o.rng = np.random.default_rng(5)
@@ -72,6 +129,12 @@ def test_c5_ten_parameter_noise_model_matches_oracle_on_sampled_settings(obe):
     nv = oracle.mean_noise_variance(o.particles, 9, o.particle_weights)
     assert_allclose(o.yvar_noise_model(), nv, rtol=1e-12)
     assert_allclose(o.utility(), yvar[0] / nv[0, 0], rtol=1e-12)
+    csweep = _csweep_or_skip()
+    t0 = time.perf_counter()
+    ref = csweep.lorentz_yvar(settings[0], np.array(o.particles), np.array(o.particle_weights), cons[0], 7)
+    print(f"c5: csweep over {settings[0].size} x {o.n_particles} x 7 peaks on {csweep.threads()} threads: "
+          f"{time.perf_counter() - t0:.1f} s")
+    _full_grid_check(o, ref, ref / nv[0, 0], "c5")
 
 
 def test_sweep_invariances_at_c2_size(obe):
@@ -102,16 +165,8 @@ def test_sweep_invariances_at_c2_size(obe):
     assert_allclose(dup, base, rtol=RTOL)
     # (4) settings sharded 3 ways: the union of the slices is the full sweep, and the
     #     first-max over the rank winners is the global argmax
-    import torch
-    from optbayesexpt_amd.dist import SettingsShard, first_max
-
-    class OneRank(SettingsShard):
-        """A shard without a process group: the gather sees only this rank's record."""
-        def _gather_records(self, record):
-            g = torch.full((self.world_size, 4), float("-inf"), dtype=torch.float64)
-            g[self.rank] = record.cpu()
-            return g
-
+    from optbayesexpt_amd.dist import first_max
+    OneRank = _one_rank_class()
     vals, idxs, parts = [], [], []
     for r in range(3):
         o, _ = sweep(prior.copy(), w, settings_shard=OneRank(rank=r, world_size=3))
@@ -122,6 +177,65 @@ def test_sweep_invariances_at_c2_size(obe):
     assert_allclose(np.concatenate(parts), base, rtol=1e-13)      # only the chunk partial-sum order differs
     k = first_max(np.array(vals), np.array(idxs))
     assert idxs[k] == int(np.argmax(base))
+
+
+def _one_rank_class():
+    import torch
+    from optbayesexpt_amd.dist import SettingsShard
+
+    class OneRank(SettingsShard):
+        """A shard without a process group: the gather sees only this rank's record."""
+        def _gather_records(self, record):
+            g = torch.full((self.world_size, 4), float("-inf"), dtype=torch.float64)
+            g[self.rank] = record.cpu()
+            return g
+    return OneRank
+
+
+def test_c4_the_eight_settings_shards_of_c3(obe):
+    """BASELINE config c4 = c3 with the settings axis sharded over 8 GPUs, one rank at a time on
+    this GPU: each of the 8 ranks sweeps its 8 192-setting slice of the real c3 posterior (three updates).  The
+    union of the slices is the one-GPU sweep (1e-13: only the chunk partial-sum order differs), the first
+    maximum over the 8 rank records is the global arg-max (np.argmax's tie rule), and after one more update
+    through every rank the replicated clouds are bit-identical to the one-GPU run's."""
+    from optbayesexpt_amd.dist import first_max, shard_bounds
+    settings, prior, cons, true, sigma = bench.make_workload("c3")
+    ns = settings[0].size
+    full = bench.build_obe("c3", None, settings, prior.copy(), cons)
+    full.rng = np.random.default_rng(5)
+    full.tuning_parameters["auto_resample"] = False
+    _updated(full, true, cons, sigma)
+    w = np.array(full.particle_weights)
+    base = full.yvar_from_parameter_draws()[0]
+    util = full.utility()
+    x = full.opt_setting()
+    best = full.last_setting_index
+    assert best == int(np.argmax(util))
+    shifted = bool(full.last_sweep["shifted"])
+    record = (x, float(full.model_function(x, true, cons)) + 123.0, sigma)
+    full.pdf_update(record)
+    w_after = np.array(full.particle_weights)
+    OneRank = _one_rank_class()
+    vals, idxs, parts, utils = [], [], [], []
+    for r in range(8):
+        o = bench.build_obe("c3", OneRank(rank=r, world_size=8), settings, prior.copy(), cons)
+        assert (o._s_begin, o._s_end) == shard_bounds(ns, r, 8) == (r * ns // 8, (r + 1) * ns // 8)
+        o.tuning_parameters["auto_resample"] = False
+        o.tuning_parameters["sweep_shift"] = "always" if shifted else "never"
+        o.particle_weights = w
+        v, i = o._sweep_device(True)
+        vals.append(v)
+        idxs.append(i)
+        parts.append(o._yvar_dev.cpu().numpy()[0].copy())
+        utils.append(o._utility_dev.cpu().numpy().copy())
+        assert o._s_begin <= i < o._s_end and v == utils[-1][i - o._s_begin]
+        o.pdf_update(record)                              # the replica's update: the same bits as the one-GPU run
+        assert_array_equal(np.array(o.particle_weights), w_after)
+        del o
+    assert_allclose(np.concatenate(parts), base, rtol=1e-13, atol=0.0)
+    assert_allclose(np.concatenate(utils), util, rtol=1e-13, atol=0.0)
+    k = first_max(np.array(vals), np.array(idxs))
+    assert idxs[k] == best and vals[k] == pytest.approx(util[best], rel=1e-13)
 
 
 def test_update_and_resample_at_one_million_particles(obe):

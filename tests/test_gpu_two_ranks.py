@@ -216,3 +216,11 @@ def test_bench_starts_its_own_ranks(hip):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["config"]["settings_per_rank"] == 2048
     assert out["value"] > 0 and "roofline" in out
+    # the block that makes an N > 1 line self-proving: the communicator's own rank count, the rank-id all-gather,
+    # the measured arg-max combine and where each rank's time went
+    c = out["rccl"]
+    assert c["backend"] == "gloo" and c["world_size_reported_by_backend"] == 2
+    assert c["all_gather_rank_ids"] == [0, 1] and c["all_gather_rank_ids_ok"] is True
+    assert c["combines_in_timed_steps"] >= 4 and c["sweep_launches_in_timed_steps"] >= 4
+    for key in ("cycle_ms", "k1_ms_per_sweep", "non_k1_ms_per_cycle", "combine_us_in_cycle_median", "combine_us_idle_median"):
+        assert len(c[key]["per_rank"]) == 2 and 0.0 < c[key]["min"] <= c[key]["max"], (key, c[key])
