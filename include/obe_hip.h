@@ -154,10 +154,17 @@ int obe_bayes_update_model_moments(const obe_model* m,
  * first-moment block, and [4 + 4 n_params] = 1.0 if auto_resample != 0 and the resample test of
  * particlepdf.py:236-258 on sum w'^2 (N_eff < 0.1 N or N_eff / N < resample_threshold) says "resample",
  * else 0.0 — wait with obe_host_words_wait(h_pinned_out, 5 + 4 n_params, stream).  The same decision stays
- * on the device for an obe_sweep_utility(OBE_SWEEP_SPECULATIVE) call enqueued next on this stream, which
- * hides the host round trip of the update behind the sweep (the reference's cycle is update -> resample
- * test -> next opt_setting: obe_base.py:340-399, 733-756).  Needs the library's per-stream control words
- * (at most 256 streams per device): -1 otherwise, and the caller uses the synchronous form. */
+ * on the device, in the LAST 8-byte word of the caller's workspace (OBE_WS_ABORT_WORD: d_ws + ws_bytes - 8,
+ * ws_bytes a multiple of 8), for an obe_sweep_utility(OBE_SWEEP_SPECULATIVE) call enqueued next on this
+ * stream WITH THE SAME d_ws AND ws_bytes, which hides the host round trip of the update behind the sweep
+ * (the reference's cycle is update -> resample test -> next opt_setting: obe_base.py:340-399, 733-756).
+ * The word belongs to whoever owns the workspace: updates of other objects on the same stream do not touch it.
+ * Refused (-1) BEFORE anything is launched — the weights are untouched and the caller uses the synchronous
+ * form — when h_pinned_out is not page-locked, when the workspace has no 16 spare bytes behind what the
+ * update uses (obe_workspace_bytes() always leaves them), or when the library has no arrival counter for
+ * the stream (device allocation failed; a full table of 256 streams per device hands its least recently
+ * used entry on after a device synchronisation, so it never refuses). */
+#define OBE_WS_ABORT_WORD(d_ws, ws_bytes) ((unsigned*)((char*)(d_ws) + ((ws_bytes) & ~(int64_t)7) - 8))
 int obe_bayes_update_model_moments_enqueue(const obe_model* m, const double* d_particles, int64_t ld_p,
                                            int64_t n_particles, double* d_weights, const double* h_setting,
                                            const double* h_y_meas, const double* h_sigma,
@@ -380,9 +387,10 @@ int obe_power_normalize(const double* d_u, int64_t n, double exponent, double* d
 #define OBE_SWEEP_SHIFTED 1
 #define OBE_SWEEP_SAFE 2
 /* OBE_SWEEP_SPECULATIVE (full sweeps only): the call is enqueued behind
- * obe_bayes_update_model_moments_enqueue() on the same stream and returns at once.  Its kernels read the
- * resample decision that update left on the device and do nothing if it was "resample" (the cloud is about
- * to change: particlepdf.py:236-258).  Page-locked h_best / h_best_idx / h_kappa are armed, not waited
+ * obe_bayes_update_model_moments_enqueue() on the same stream, with the same d_ws and ws_bytes, and returns
+ * at once.  Its kernels read the resample decision that update left in OBE_WS_ABORT_WORD(d_ws, ws_bytes) and
+ * do nothing if it was "resample" (the cloud is about to change: particlepdf.py:236-258).  Refused (-1, before
+ * any launch) if the workspace has no 16 spare bytes behind what the sweep uses.  Page-locked h_best / h_best_idx / h_kappa are armed, not waited
  * for: the caller first learns from the update's host block (word 4 + 4 n_params) whether the sweep ran,
  * and only then waits for the words with obe_host_words_wait().  An aborted call leaves them armed and the
  * device outputs (yvar, utility, the result record) untouched. */

@@ -60,30 +60,48 @@ int wait_host_word(const void* h_word, hipStream_t st) { return wait_host_words(
 // is asked of the caller's workspace.  nullptr (table full, allocation failed): callers fold in a launch
 // of their own.
 namespace {
+constexpr int kControlSlotsMax = 256;      // (kControlSlotWords: obe_common.h, nine 128-byte lines per stream)
 struct ControlTable {
     std::mutex mu;
-    std::unordered_map<uint64_t, unsigned*> slot;      // (device << 56) ^ stream -> its words
+    std::unordered_map<uint64_t, int> slot;            // (device << 56) ^ stream -> slot index on that device
     unsigned* base[64] = {};
     int used[64] = {};
+    uint64_t key_of[64][kControlSlotsMax] = {};
+    uint64_t last_use[64][kControlSlotsMax] = {};
+    uint64_t tick = 0;
 };
 ControlTable& control_table() {
     static ControlTable* t = new ControlTable;          // (leaked on purpose: no destructor order games at exit)
     return *t;
 }
-constexpr int kControlSlots = 256;         // (kControlSlotWords: obe_common.h, nine 128-byte lines per stream)
+// slots per device; OBE_CONTROL_SLOTS (0..256) is a test aid: 0 makes every lookup fail (the refusal paths of
+// the entry points that need a counter), a small number exercises the hand-over of a slot
+int control_slots() {
+    static const int n = [] {
+        const char* e = getenv("OBE_CONTROL_SLOTS");
+        const int v = e ? atoi(e) : kControlSlotsMax;
+        return v < 0 ? 0 : (v > kControlSlotsMax ? kControlSlotsMax : v);
+    }();
+    return n;
+}
 }  // namespace
 
 unsigned* stream_control_words(hipStream_t st) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    const int n_slots = control_slots();
+    if (n_slots == 0) return nullptr;
     ControlTable& t = control_table();
     const uint64_t key = ((uint64_t)dev << 56) ^ (uint64_t)reinterpret_cast<uintptr_t>(st);
     std::lock_guard<std::mutex> lock(t.mu);
     auto it = t.slot.find(key);
-    if (it != t.slot.end()) return it->second;
+    if (it != t.slot.end()) {
+        t.last_use[dev][it->second] = ++t.tick;
+        return t.base[dev] + (size_t)it->second * kControlSlotWords;
+    }
     if (!t.base[dev]) {
         void* p = nullptr;
-        const size_t bytes = (size_t)kControlSlots * kControlSlotWords * sizeof(unsigned);
+        const size_t bytes = (size_t)kControlSlotsMax * kControlSlotWords * sizeof(unsigned);
         if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess ||
             hipDeviceSynchronize() != hipSuccess) {
             (void)hipGetLastError();
@@ -91,10 +109,28 @@ unsigned* stream_control_words(hipStream_t st) {
         }
         t.base[dev] = static_cast<unsigned*>(p);
     }
-    if (t.used[dev] >= kControlSlots) return nullptr;
-    unsigned* w = t.base[dev] + (size_t)t.used[dev]++ * kControlSlotWords;
-    t.slot.emplace(key, w);
-    return w;
+    int s;
+    if (t.used[dev] < n_slots) {
+        s = t.used[dev]++;
+    } else {
+        // Table full (streams come and go: torch creates one per `torch.cuda.Stream()`): the least recently used
+        // slot changes hands.  Its previous owner may be a stream that still exists, with a kernel in flight that
+        // counts arrivals in it: the device is drained first (a counter is zero whenever no kernel is using it),
+        // and if that stream comes back later it simply gets a slot the same way.  Rare by construction — one
+        // device synchronisation per NEW stream beyond the first 256.
+        s = 0;
+        for (int k = 1; k < n_slots; ++k)
+            if (t.last_use[dev][k] < t.last_use[dev][s]) s = k;
+        if (hipDeviceSynchronize() != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        t.slot.erase(t.key_of[dev][s]);
+    }
+    t.key_of[dev][s] = key;
+    t.last_use[dev][s] = ++t.tick;
+    t.slot[key] = s;
+    return t.base[dev] + (size_t)s * kControlSlotWords;
 }
 
 namespace {

@@ -87,7 +87,9 @@ __device__ __forceinline__ void host_results_before_flag() {
 }
 
 // ---- "the last workgroup to arrive folds": arrival counter + write-through partials ----
-// Zeroed device words owned by the library, one slot per (device, stream) (obe_capi.hip); nullptr: none.
+// Zeroed device words owned by the library, one slot per (device, stream) (obe_capi.hip); nullptr: none
+// (allocation failed, or OBE_CONTROL_SLOTS=0).  A full table hands the least recently used slot on — after a
+// device synchronisation, so that no kernel of its previous owner is still counting in it.
 unsigned* stream_control_words(hipStream_t st);
 
 // A second stream (and three events) that belongs to a caller's stream: two independent kernel chains of one
@@ -127,10 +129,15 @@ __device__ __forceinline__ double load_published_f64(const double* p) {
 constexpr int kArriveGroups = 8;
 constexpr int kArriveStride = 32;                       // words between two counters: one 128-byte line each
 constexpr int kControlSlotWords = kArriveStride * (kArriveGroups + 1);
-// a word of the top counter's line that no ticket touches: written by the enqueue form of the fused update
-// (1: this update is followed by a resample), read by the kernels of a sweep enqueued behind it
-// (obe_sweep.hip: OBE_SWEEP_SPECULATIVE), which then do nothing
-constexpr int kAbortWord = kArriveStride * kArriveGroups + 16;
+// The resample decision that the enqueue form of the fused update leaves on the device (1: this update is
+// followed by a resample) for the kernels of a sweep enqueued behind it (obe_sweep.hip: OBE_SWEEP_SPECULATIVE),
+// which then do nothing.  It lives in the CALLER's memory — the last 8-byte word of the workspace both calls
+// are given (include/obe_hip.h: OBE_WS_ABORT_WORD) — so the pair is tied by the object that owns the workspace,
+// not by the stream: another object's (or thread's) update on the same stream cannot change it.  Both forms
+// refuse a workspace without 16 spare bytes behind what their kernels use.
+inline unsigned* ws_abort_word(void* d_ws, int64_t ws_bytes) {
+    return reinterpret_cast<unsigned*>(static_cast<char*>(d_ws) + (ws_bytes & ~(int64_t)7) - 8);
+}
 template <bool ACQUIRE = true>
 __device__ __forceinline__ bool arrive_last(unsigned* counter, int* flag) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores

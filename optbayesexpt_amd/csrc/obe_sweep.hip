@@ -130,7 +130,7 @@ struct SweepArgs {
     double* part1;
     double* part2;
     double* cs_out;            // (C, ns): the shift each setting used (0 when unshifted)
-    const unsigned* abort;     // OBE_SWEEP_SPECULATIVE: the stream's abort word (non-zero: do nothing), else NULL
+    const unsigned* abort;     // OBE_SWEEP_SPECULATIVE: the workspace's abort word (non-zero: do nothing), else NULL
 };
 
 // A speculative sweep (enqueued behind an update whose resample decision was not waited for) does nothing
@@ -752,9 +752,12 @@ struct SweepWs {
     double* packed;
 };
 
+static int64_t sweep_ws_bytes(int64_t part_doubles, int64_t cs_doubles, int64_t slots, int64_t packed_doubles) {
+    return (2 * part_doubles + cs_doubles + 3 * slots + 16 + packed_doubles + 2) * (int64_t)sizeof(double);
+}
 static int carve_sweep_ws(void* d_ws, int64_t ws_bytes, int64_t part_doubles, int64_t cs_doubles, SweepWs& w,
                           int64_t slots = kMaxBlocks, int64_t packed_doubles = 0) {
-    const int64_t need = (2 * part_doubles + cs_doubles + 3 * slots + 16 + packed_doubles + 2) * sizeof(double);
+    const int64_t need = sweep_ws_bytes(part_doubles, cs_doubles, slots, packed_doubles);
     if (!d_ws || ws_bytes < need) return bad_arg("sweep workspace too small");
     double* base = static_cast<double*>(d_ws);
     w.out_v = base;                                     // [0] best value, [1] worst cancellation factor
@@ -844,7 +847,7 @@ static int launch_sweep(const SweepPlan& p, SweepArgs& a, int flags, hipStream_t
 static int prepare_sweep(const obe_model* m, obe_model& mm, const double* d_settings, int64_t ld_s, int64_t ns,
                          const double* d_particles, int64_t ld_p, int64_t np, const double* d_weights,
                          const int64_t* d_draw_idx, int64_t n_draws, const double* d_moments, void* d_ws,
-                         int64_t ws_bytes, SweepPlan& plan, SweepArgs& a, SweepWs& w) {
+                         int64_t ws_bytes, SweepPlan& plan, SweepArgs& a, SweepWs& w, int64_t* ws_need = nullptr) {
     if (!m || !d_settings || !d_particles || !d_moments || ns <= 0 || np <= 0) return bad_arg("sweep: bad pointer/size");
     if (!d_draw_idx && !d_weights) return bad_arg("sweep: full mode needs weights");
     mm = *m;
@@ -862,6 +865,7 @@ static int prepare_sweep(const obe_model* m, obe_model& mm, const double* d_sett
     const int64_t part = (int64_t)plan.nchunks * mm.n_channels * ns;
     if (int rc = carve_sweep_ws(d_ws, ws_bytes, part, (int64_t)mm.n_channels * ns, w, argmax_slots(ns), nd * packed_w))
         return rc;
+    if (ws_need) *ws_need = sweep_ws_bytes(part, (int64_t)mm.n_channels * ns, argmax_slots(ns), nd * packed_w);
     a.cs_out = w.cs;
     a.packed = w.packed;
     a.m = mm;
@@ -922,8 +926,9 @@ int obe_sweep_utility(const obe_model* m, const double* d_settings, int64_t ld_s
     SweepPlan plan;
     SweepArgs a{};
     SweepWs w;
+    int64_t sweep_ws_need = 0;
     if (int rc = prepare_sweep(m, mm, d_settings, ld_s, n_settings, d_particles, ld_p, n_particles, d_weights,
-                               d_draw_idx, n_draws, d_moments, d_ws, ws_bytes, plan, a, w))
+                               d_draw_idx, n_draws, d_moments, d_ws, ws_bytes, plan, a, w, &sweep_ws_need))
         return rc;
     hipStream_t st = as_stream(stream);
     UtilArgs ua{d_noise_var, noise_ld, d_cost, cost_scalar};
@@ -932,9 +937,9 @@ int obe_sweep_utility(const obe_model* m, const double* d_settings, int64_t ld_s
     if (nowait) {
         if (d_draw_idx) return bad_arg("obe_sweep_utility: OBE_SWEEP_SPECULATIVE / OBE_SWEEP_NOWAIT are for full sweeps");
         if (speculative) {
-            unsigned* control = stream_control_words(st);
-            if (!control) return bad_arg("obe_sweep_utility: no control words for this stream");
-            a.abort = control + kAbortWord;
+            if (ws_bytes < sweep_ws_need + 16)
+                return bad_arg("obe_sweep_utility: OBE_SWEEP_SPECULATIVE needs 16 spare bytes at the end of the workspace (OBE_WS_ABORT_WORD)");
+            a.abort = ws_abort_word(d_ws, ws_bytes);
         }
         if ((h_best && !device_view_of_host(h_best)) || (h_best_idx && !device_view_of_host(h_best_idx)) ||
             (h_kappa && !device_view_of_host(h_kappa)))

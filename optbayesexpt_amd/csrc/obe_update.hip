@@ -185,7 +185,7 @@ struct UpdateFold {
     double* mom_out;            // K3 block on the device
     double* host_out;           // device view of the caller's page-locked h_out, or NULL
     // enqueue form (obe_bayes_update_model_moments_enqueue): the resample test of particlepdf.py:236-258 on
-    // sum w'^2, left in the stream's abort word for the sweep that was enqueued behind this update without
+    // sum w'^2, left in the workspace's abort word (obe_common.h: ws_abort_word) for the sweep that was enqueued behind this update without
     // waiting for it (obe_sweep.hip: OBE_SWEEP_SPECULATIVE), and in host_out[4 + 4 d] as 0.0 / 1.0
     unsigned* abort_out;        // NULL: not the enqueue form
     double n_particles, threshold;
@@ -541,9 +541,12 @@ struct UpdateWs {
     double* scalars;
     double* mom;        // block partials of the fused first moments (moments_dims > 0 only)
 };
-static int carve_update_ws(void* d_ws, int64_t ws_bytes, UpdateWs& w, int moments_dims = 0) {
+static int64_t update_ws_bytes(int moments_dims) {
     const int64_t mom = moments_dims > 0 ? (int64_t)kMomGridCap * (3 + 2 * moments_dims) : 0;   // (+1: sum w'^2 rides along)
-    const int64_t need = (2 * (int64_t)kMaxBlocks + 8 + mom) * sizeof(double);
+    return (2 * (int64_t)kMaxBlocks + 8 + mom) * sizeof(double);
+}
+static int carve_update_ws(void* d_ws, int64_t ws_bytes, UpdateWs& w, int moments_dims = 0) {
+    const int64_t need = update_ws_bytes(moments_dims);
     if (!d_ws || ws_bytes < need) return bad_arg("workspace too small");
     w.pa = static_cast<double*>(d_ws);
     w.pb = w.pa + kMaxBlocks;
@@ -620,6 +623,19 @@ static int update_model_moments(const obe_model* m, const double* d_particles, i
     for (int k = 0; k < mm.n_setdims; ++k) sa.x[k] = h_setting ? h_setting[k] : 0.0;
     hipStream_t st = as_stream(stream);
     const int nb = update_blocks(n_particles);
+    // Everything that can refuse the call is checked BEFORE the first launch (pass A multiplies the weights by
+    // the likelihood in place: a refusal after it would leave them half updated, and a caller that then falls
+    // back to the synchronous form would apply the likelihood twice).
+    double* hv = static_cast<double*>(device_view_of_host(h_out));
+    const int64_t n_words = 2 + 2 + 4 * (int64_t)d + (enqueue_only ? 1 : 0);
+    if (enqueue_only && !hv) return bad_arg("obe_bayes_update_model_moments_enqueue: h_out must be page-locked");
+    // the fold rides in the normalisation launch (its last workgroup to arrive) unless there is no counter
+    // for this stream or OBE_UPDATE_FOLD=separate asks for the round-3 shape (A/B measurements)
+    static const bool separate = getenv("OBE_UPDATE_FOLD") && !strcmp(getenv("OBE_UPDATE_FOLD"), "separate");
+    unsigned* counter = separate && !enqueue_only ? nullptr : stream_control_words(st);
+    if (enqueue_only && !counter) return bad_arg("obe_bayes_update_model_moments_enqueue: no control words for this stream");
+    if (enqueue_only && ws_bytes < update_ws_bytes(d) + 16)
+        return bad_arg("obe_bayes_update_model_moments_enqueue: the workspace needs 16 spare bytes at its end (OBE_WS_ABORT_WORD)");
     int rc = dispatch_model(mm, [&](auto M) -> int {
         using Model = decltype(M);
         update_model_kernel<Model><<<nb, kBlock, 0, st>>>(mm, sa, la, d_particles, ld_p, n_particles, d_weights, w.pa,
@@ -629,16 +645,8 @@ static int update_model_moments(const obe_model* m, const double* d_particles, i
     });
     if (rc) return rc;
     const int nm = moment_blocks(n_particles, d);
-    double* hv = static_cast<double*>(device_view_of_host(h_out));
-    const int64_t n_words = 2 + 2 + 4 * (int64_t)d + (enqueue_only ? 1 : 0);
-    if (enqueue_only && !hv) return bad_arg("obe_bayes_update_model_moments_enqueue: h_out must be page-locked");
     if (hv) arm_host_words(h_out, n_words);      // every word of the result block is watched
-    // the fold rides in the normalisation launch (its last workgroup to arrive) unless there is no counter
-    // for this stream or OBE_UPDATE_FOLD=separate asks for the round-3 shape (A/B measurements)
-    static const bool separate = getenv("OBE_UPDATE_FOLD") && !strcmp(getenv("OBE_UPDATE_FOLD"), "separate");
-    unsigned* counter = separate && !enqueue_only ? nullptr : stream_control_words(st);
-    if (enqueue_only && !counter) return bad_arg("obe_bayes_update_model_moments_enqueue: no control words for this stream");
-    const UpdateFold fold{counter, w.scalars, d_moments, hv, enqueue_only ? counter + kAbortWord : nullptr,
+    const UpdateFold fold{counter, w.scalars, d_moments, hv, enqueue_only ? ws_abort_word(d_ws, ws_bytes) : nullptr,
                           (double)n_particles, resample_threshold, auto_resample};
 #define OBE_UPD_MOM_CASE(DD)                                                                                           \
     case DD:                                                                                                           \

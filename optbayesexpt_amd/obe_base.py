@@ -34,6 +34,7 @@ import numpy as np
 import torch
 
 from . import _devrng, _lib
+from ._sweepstate import Form, Pending, SweepState, Ticket
 from . import models as _models
 from ._mirror import Mirror, TrackedArray
 from .models import DeviceModel
@@ -87,6 +88,25 @@ class _LazyState:
     def __iter__(self):
         yield self._owner.particles
         yield self._owner.particle_weights
+
+
+class _SweepIO:
+    """What SweepState (_sweepstate.py) waits through: the library's watched host words and the device."""
+
+    def __init__(self, owner):
+        self._owner = owner
+
+    def wait_words(self, words, n, stream):
+        self._owner._lib.call("obe_host_words_wait", words, n, stream)
+
+    @staticmethod
+    def still_armed(block):
+        words = block.view(np.int64)
+        armed = _lib.HOST_SENTINEL                                        # (positive as a signed word too)
+        return bool(words[0] == armed or words[1] == armed or words[2] == armed)
+
+    def synchronize(self):
+        torch.cuda.synchronize(self._owner._device)
 
 
 class OptBayesExpt(ParticlePDF):
@@ -186,9 +206,8 @@ class OptBayesExpt(ParticlePDF):
         self._rec_y = self._hargs.keep(np.zeros(_lib.OBE_MAX_CHANNELS))
         self._rec_s = self._hargs.keep(np.ones(_lib.OBE_MAX_CHANNELS))
         self._hargs.keep(self._host_out)
-        self._sweep_safe_streak = 0           # consecutive sweeps that had to be repeated with the safe twin
-        self._sweep_safe_run = 0              # sweeps since the fast form was last tried (while pinned to the twin)
-        self._range_hint_key = None           # particles version the model's range_hint last looked at
+        # which form / shift the next sweep uses, and the sweep pdf_update() enqueues ahead (_sweepstate.py)
+        self._sweeps = SweepState(_SweepIO(self), self.KAPPA_ENTER, self.KAPPA_LEAVE, self.SAFE_STREAK, self.SAFE_RETRY)
         if settings_shard is not None:
             self._s_begin, self._s_end = settings_shard.bounds(self._n_settings)
         else:
@@ -201,7 +220,6 @@ class OptBayesExpt(ParticlePDF):
         self._noise_dev = torch.zeros(self.n_channels, dtype=torch.float64, device=self._device)
         self._noise_cache = None
         self._noise_src = None        # bytes of the default_noise_std the cached device value was made from
-        self._sweep_unshifted = False      # see _sweep_device: adaptive variance shift
         self._alloc_scratch()
 
         self.utility_y_space = np.array([])
@@ -427,7 +445,10 @@ class OptBayesExpt(ParticlePDF):
                 # ... and the first moments of the posterior in the same pass over the cloud: the next
                 # sweep's shift, mean(), std() and the noise-parameter variance need no launch of their own
                 self._drop_speculative_sweep()
-                if self.utility_method == "variance_full" and not self.__dict__.get("_spec_unavailable") \
+                # (the calls below arm the page-locked block that an un-awaited constraint mask — two updates in
+                # a row on a noise-parameter object, no sweep in between — may still be delivering into)
+                self._await_host_moments()
+                if self.utility_method == "variance_full" and not self._sweeps.unavailable \
                         and self.tuning_parameters.get("speculative_sweep", _SPECULATIVE_DEFAULT) is not False:
                     self._update_then_speculate(args)       # (enqueued; what goes behind it is decided while it runs)
                 else:
@@ -459,8 +480,8 @@ class OptBayesExpt(ParticlePDF):
         if self.just_resampled:
             self.enforce_parameter_constraints()
         # (the cycle pattern the speculative sweep looks for: a full sweep of exactly this cloud comes next)
-        self._updated_cloud = (self._particles.version, self._weights.version) if fused else None
-        self._resample_rate = 0.8 * self.__dict__.get("_resample_rate", 0.0) + (0.2 if self.just_resampled else 0.0)
+        self._sweeps.update_finished((self._particles.version, self._weights.version) if fused else None,
+                                     self.just_resampled)
         if fused and self.just_resampled and self._speculation_wanted(after_resample=True):
             # the cloud is final (resampled, constrained): its sweep goes out now, behind the gather and the
             # moments, instead of after the caller's way back through opt_setting()
@@ -468,7 +489,7 @@ class OptBayesExpt(ParticlePDF):
             try:
                 self._sweep_device(False, speculate="after_resample")
             except _lib.ObeHipError:
-                self._spec_unavailable = True
+                self._sweeps.library_refused()
         return _LazyState(self)
 
     # ------------------------------------------------------- speculative sweep
@@ -488,21 +509,39 @@ class OptBayesExpt(ParticlePDF):
     # rank's 8192 x 1 048 576 slice 1.877 -> 1.845 ms.
     def _speculation_wanted(self, after_resample=False):
         mode = self.tuning_parameters.get("speculative_sweep", _SPECULATIVE_DEFAULT)
-        if mode is False or mode == "never" or self.__dict__.get("_spec_unavailable"):
-            return False
-        # 'auto': after two update -> sweep cycles in a row, and while fewer than half of the recent updates
-        # resampled (a sweep behind a resampling update is launched for nothing: ~10-35 us of empty workgroups)
-        # (the sweep enqueued after a resample has nothing to guess: the cloud is final)
-        if not (mode is True or (self.__dict__.get("_spec_streak", 0) >= 2
-                                 and (after_resample or self.__dict__.get("_resample_rate", 0.0) < 0.5))):
+        if not self._sweeps.speculation_wanted(mode, after_resample):      # (the policy: _sweepstate.py)
             return False
         if after_resample and self._parameters is not self._particles:
             return False
         return (self.utility_method == "variance_full" and self._utility_fusable()
                 and not _overridden(self, "cost_estimate", OptBayesExpt)
                 and self._noise_token() is not None
-                and self._sweep_safe_streak < self.SAFE_STREAK
+                and self._sweeps.form is Form.FAST
                 and self.N_DRAWS <= self._ws_draws)
+
+    def sweep_state(self):
+        """A snapshot of what steers this object's sweeps (diagnostic): the kernel form in use, the shift
+        hysteresis, the update -> sweep pattern and the sweep enqueued ahead, by name (_sweepstate.py)."""
+        return self._sweeps.describe()
+
+    speculation_state = sweep_state
+
+    # (the names round-4 tests and tools know this state under)
+    _sweep_unshifted = property(lambda self: self._sweeps.unshifted,
+                                lambda self, v: setattr(self._sweeps, "unshifted", bool(v)))
+    _sweep_safe_streak = property(lambda self: self._sweeps.safe_streak,
+                                  lambda self, v: setattr(self._sweeps, "safe_streak", int(v)))
+    _sweep_safe_run = property(lambda self: self._sweeps.safe_run,
+                               lambda self, v: setattr(self._sweeps, "safe_run", int(v)))
+
+    @property
+    def _spec(self):
+        """The sweep enqueued ahead as round-4 code saw it (None, or a dict with 'ran')."""
+        t = self._sweeps.ticket
+        if t is None:
+            return None
+        return dict(t.inputs, words=t.words, block=t.block, record=t.record, stream=t.stream,
+                    ran={Pending.RAN: True, Pending.ABORTED: False}.get(self._sweeps.pending))
 
     def _noise_token(self):
         """What the utility's noise variance depends on besides the cloud (hashable), or None if that cannot
@@ -522,8 +561,9 @@ class OptBayesExpt(ParticlePDF):
                             _ptr(self._ws), self._ws_bytes, p_out, 1 if tp["auto_resample"] else 0,
                             float(tp["resample_threshold"]), st)
         except _lib.ObeHipError:
-            # no control words for this stream (more than 256 streams on the device): the plain form from now on
-            self._spec_unavailable = True
+            # refused before anything was launched (no arrival counter for this stream, a workspace without the
+            # spare tail word): the weights are untouched — the plain form, now and from now on
+            self._sweeps.library_refused()
             self._mlib.call("obe_bayes_update_model_moments", *args, _ptr(self._moments_dev), _ptr(self._ws),
                             self._ws_bytes, p_out, st)
             self._after_weight_update(self._upd_host[1], moments_fresh=True)
@@ -535,54 +575,40 @@ class OptBayesExpt(ParticlePDF):
             try:
                 self._sweep_device(False, speculate=True)
             except _lib.ObeHipError:
-                self._spec_unavailable = True         # (nothing of the sweep was enqueued: refused before any launch)
+                self._sweeps.library_refused()        # (nothing of the sweep was enqueued: refused before any launch)
         self._lib.call("obe_host_words_wait", p_out, 5 + 4 * d, st)
-        spec = self.__dict__.get("_spec")
-        if spec is not None:
-            spec["ran"] = self._upd_host[4 + 4 * d] == 0.0
+        self._sweeps.update_delivered(resampled=self._upd_host[4 + 4 * d] != 0.0)
         self._mom_host_key = key + (False,)
         self._sumsq, self._sumsq_key = float(self._upd_host[1]), self._weights.version
         if tp["auto_resample"]:
             self.resample_test()
 
+    def _sweep_inputs(self, shifted):
+        """Everything the result of a full sweep of this object depends on besides the kernels: compared
+        between the sweep enqueued ahead and the one being asked for (both must read the same)."""
+        return dict(cloud=(self._particles.version, self._weights.version), shifted=bool(shifted),
+                    noise=self._noise_token(), settings=(self._s_begin, self._s_end),
+                    alias=self._parameters is self._particles,
+                    cost_hook=_overridden(self, "cost_estimate", OptBayesExpt))
+
     def _drop_speculative_sweep(self):
-        """Forget a speculative sweep nobody asked for.  Its kernels may still be running and will write the
-        result words: they are waited for before anything arms those words again."""
-        spec = self.__dict__.get("_spec")
-        if spec is None:
-            return
-        self._spec = None
-        if spec.get("ran"):
-            if spec["words"] is not None:
-                self._lib.call("obe_host_words_wait", spec["words"], 3, spec["stream"])
-            elif spec["stream"].value != self._stream().value:
-                torch.cuda.synchronize(self._device)      # a shard's sweep on a stream the caller has left since
-            self._spec_streak = 0         # the pattern broke: two plain cycles before the next attempt
+        """Forget a speculative sweep nobody asked for (what is waited for: SweepState.drop)."""
+        if self._sweeps.ticket is not None:
+            self._sweeps.drop(self._stream().value)
 
     def _take_speculative_sweep(self, shifted):
         """The result of the speculative sweep if it is the sweep being asked for: (best, index, kappa) for an
         unsharded object, the device record for a sharded one; None (and the speculation forgotten) if not."""
-        spec = self.__dict__.get("_spec")
-        if spec is None:
+        if self._sweeps.ticket is None:
             return None
-        ok = (spec.get("ran") and spec["cloud"] == (self._particles.version, self._weights.version)
-              and spec["shifted"] == shifted and spec["noise"] == self._noise_token()
-              and spec["settings"] == (self._s_begin, self._s_end) and self._parameters is self._particles
-              and (spec["words"] is not None or spec["stream"].value == self._stream().value)
-              and not _overridden(self, "cost_estimate", OptBayesExpt))
-        if not ok:
-            self._drop_speculative_sweep()
+        # (a stale `parameters` alias or a cost hook installed since makes the inputs differ: dropped)
+        t = self._sweeps.take(self._sweep_inputs(shifted), self._stream().value)
+        if t is None:
             return None
-        self._spec = None
-        if spec["words"] is None:
-            return spec["record"]
-        self._lib.call("obe_host_words_wait", spec["words"], 3, spec["stream"])
-        block = spec["block"]
-        words = block.view(np.int64)
-        armed = _lib.HOST_SENTINEL                                        # (positive as a signed word too)
-        if words[0] == armed or words[1] == armed or words[2] == armed:   # drained without delivering: not run
-            return None
-        return float(block[0]), int(words[1]), float(block[2])
+        if t.words is None:
+            return t.record
+        block = t.block
+        return float(block[0]), int(block.view(np.int64)[1]), float(block[2])
 
     def _likelihood_overridden(self):
         return _overridden(self, "likelihood", OptBayesExpt)
@@ -670,12 +696,10 @@ class OptBayesExpt(ParticlePDF):
         the sweep it expects to be asked for next (see _speculation_wanted) — enqueued, nothing read."""
         full = self.utility_method == "variance_full"
         sharded = self._shard is not None     # every sweep of a sharded object gathers: ranks stay in lockstep
+        state = self._sweeps
         if full and not speculate:
             # update -> full sweep of exactly that cloud, twice in a row: the next update speculates
-            cloud = (self._particles.version, self._weights.version)
-            seen = self.__dict__.get("_updated_cloud")
-            self._updated_cloud = None
-            self._spec_streak = self.__dict__.get("_spec_streak", 0) + 1 if seen == cloud else 0
+            state.full_sweep_requested((self._particles.version, self._weights.version))
         elif not speculate:
             self._drop_speculative_sweep()
         idx = None
@@ -720,6 +744,7 @@ class OptBayesExpt(ParticlePDF):
             # microsecond before the sweep kernel also costs clock ramp-up inside it)
             mom = self._moments_on_device()
             no_host = sharded or lazy
+            stream = self._stream()
             self._mlib.call("obe_sweep_utility", self._model_struct, s_ptr, self._n_settings, n_local,
                            _ptr(p), p.shape[1], self.n_particles, _ptr(w),
                            None if idx is None else _ptr(idx), n_draws, _ptr(mom),
@@ -731,7 +756,7 @@ class OptBayesExpt(ParticlePDF):
                            None if no_host else p_best,
                            None if no_host else p_best_idx,
                            None if no_host else p_kappa,
-                           _ptr(self._ws), self._ws_bytes, self._stream())
+                           _ptr(self._ws), self._ws_bytes, stream)
             if speculative:
                 record = None
                 if sharded:         # the workspace is reused by whatever is enqueued next: keep the record
@@ -739,12 +764,9 @@ class OptBayesExpt(ParticlePDF):
                     if record is None:
                         record = self._spec_record = torch.empty(4, dtype=torch.float64, device=self._device)
                     record.copy_(self._ws[off:off + 4])
-                self._spec = dict(cloud=(self._particles.version, self._weights.version), shifted=shifted,
-                                  noise=self._noise_token(), settings=(self._s_begin, self._s_end),
-                                  words=None if sharded else p_best, block=block, record=record,
-                                  stream=self._stream())      # (waited for on the stream it was launched on)
-                if speculative == "after_resample":
-                    self._spec["ran"] = True
+                # (waited for on the stream it was launched on; the sweep of a resampled cloud has nothing to guess)
+                state.enqueued(Ticket(self._sweep_inputs(shifted), None if sharded else p_best, block, record,
+                                      stream, stream.value), certain=speculative == "after_resample")
             else:
                 deliver(None if not sharded else self._ws[off:off + 4])
 
@@ -766,45 +788,40 @@ class OptBayesExpt(ParticlePDF):
         # kappa = (mean of y)^2 / var, which every sweep reports: measured ~1e-15 * kappa
         # relative (worst case eps*kappa*sqrt(N)).  It is used only while the previous sweep saw
         # kappa < KAPPA_ENTER, and a sweep that comes back with kappa > KAPPA_LEAVE is repeated
-        # with the shift: the variance is always good to a few 1e-12.
+        # with the shift: the variance is always good to a few 1e-12.  (SweepState.sweep_reported_kappa)
         mode = self.tuning_parameters.get("sweep_shift", "auto")
-        shifted = (not full) or mode == "always" or (mode == "auto" and not self._sweep_unshifted)
+        shifted = state.shifted_for_next_sweep(mode, full)
         safe = False
         if speculate:
             launch(shifted, speculative=speculate)
             return None
         self._apply_range_hint()
-        if self._sweep_safe_streak >= self.SAFE_STREAK:
-            self._sweep_safe_run += 1
-            if self._sweep_safe_run >= self.SAFE_RETRY:     # one fast attempt; a failure pins it again at once
-                self._sweep_safe_streak, self._sweep_safe_run = self.SAFE_STREAK - 1, 0
+        form = state.form_for_next_sweep()
         if lazy:
             launch(True)
             self.last_sweep = dict(shifted=True, kappa=float("nan"), safe=False)     # kappa was not read back
             return None
-        if self._sweep_safe_streak < self.SAFE_STREAK:
+        if form is Form.FAST:
             taken = self._take_speculative_sweep(shifted) if full else None
             if taken is None:
                 launch(shifted)
             else:
                 deliver(taken if sharded else None)
             self._check_pending_total()
-            if full and mode == "auto":
-                if shifted:
-                    self._sweep_unshifted = bool(kappa[0] < self.KAPPA_ENTER)
-                elif not kappa[0] <= self.KAPPA_LEAVE:
-                    self._sweep_unshifted = False
-                    shifted = True
-                    if not (np.isnan(kappa[0]) and self._device_model.safe_sweep):
-                        launch(True)
-            if np.isnan(kappa[0]) and self._device_model.safe_sweep:
+            poisoned = bool(np.isnan(kappa[0])) and bool(self._device_model.safe_sweep)
+            if state.sweep_reported_kappa(mode, full, shifted, float(kappa[0])):
+                shifted = True
+                if not poisoned:          # (a poisoned sweep is repeated below anyway, with the twin)
+                    launch(True)
+                    poisoned = bool(np.isnan(kappa[0])) and bool(self._device_model.safe_sweep)
+            if poisoned:
                 # a model's branch-free batched divisions left their exact range somewhere (or the
                 # model really produces NaN): repeat with its always-in-range twin
                 safe = shifted = True
                 launch(True, safe=True)
-                self._sweep_safe_streak += 1
+                state.fast_form_left_its_range()
             else:
-                self._sweep_safe_streak = 0
+                state.fast_form_held()
         else:
             # the fast form has left its range SAFE_STREAK sweeps in a row: that is a property of the
             # settings grid (its span against the model's width), not of one cloud — stop paying for a
@@ -826,18 +843,15 @@ class OptBayesExpt(ParticlePDF):
         'in range' costs one repeated sweep, a wrong 'out of range' is retried after SAFE_RETRY)."""
         hint = getattr(self._device_model, "range_hint", None)
         pm = self._particles
-        if hint is None or not pm._host_valid or self._range_hint_key == pm.version:
+        state = self._sweeps
+        if hint is None or not pm._host_valid or state.range_hint_key == pm.version:
             return
-        self._range_hint_key = pm.version
+        state.range_hint_key = pm.version
         n_local = self._s_end - self._s_begin
         if n_local <= 0:
             return
         spt = int(self._mlib.cdll.obe_sweep_settings_per_lane(n_local))
-        ok = hint(self.allsettings[:, self._s_begin:self._s_end], pm._host, self.cons, spt)
-        if ok is False:
-            self._sweep_safe_streak, self._sweep_safe_run = self.SAFE_STREAK, 0
-        elif ok is True and self._sweep_safe_streak >= self.SAFE_STREAK:
-            self._sweep_safe_streak = self.SAFE_STREAK - 1      # a new cloud in range: try the fast form again
+        state.range_hint(hint(self.allsettings[:, self._s_begin:self._s_end], pm._host, self.cons, spt))
 
     def yvar_from_parameter_draws(self):
         """Variance of the model output over parameter draws, per setting: (C, N_s)

@@ -52,6 +52,7 @@ class OptBayesExptNoiseParameter(OptBayesExpt):
         renormalise; called by ``pdf_update`` right after a resample.  The same two launches leave the
         first moments of the constrained cloud behind (the next sweep's shift and noise variance need
         them), and nothing is waited for: ``last_constraint_count`` reads the count when asked."""
+        self._await_host_moments()        # (a second call in a row re-arms the words the first one delivers into)
         par = self._parameters.tensor()
         w = self._weights.tensor()
         changed = self.__dict__.get("_changed_pinned")

@@ -121,7 +121,7 @@ def gauss_likelihood(y_model, y_meas, sigma):
     return np.exp(-((y_model - y_meas) / sigma) ** 2 / 2) / sigma
 
 
-def yvar_from_draws(model, allsettings, draws, cons):
+def yvar_from_draws(model, allsettings, draws, cons, return_mean=False):
     """obe_base.py:480-488 — evaluate the model over all settings for each drawn
     parameter set (columns of ``draws``), then the *unweighted, ddof=0* variance
     over the draw axis.  Returns (C, N_s)."""
@@ -130,10 +130,13 @@ def yvar_from_draws(model, allsettings, draws, cons):
     for i in range(n_draws):
         y = np.atleast_2d(np.asarray(model(allsettings, draws[:, i], cons), dtype=np.float64))
         ys.append(np.broadcast_to(y, (y.shape[0], allsettings.shape[1])))
-    return np.var(np.array(ys), axis=0)
+    ys = np.array(ys)
+    if return_mean:
+        return np.var(ys, axis=0), np.mean(ys, axis=0)
+    return np.var(ys, axis=0)
 
 
-def yvar_full_sweep(model, allsettings, particles, weights, cons, chunk=2048):
+def yvar_full_sweep(model, allsettings, particles, weights, cons, chunk=2048, return_mean=False):
     """Full-sweep limit of obe_base.py:480-488: every particle is
     a draw and the variance is *weighted*,  sum_p w_p (y_sp - ybar_s)^2 / sum_p w_p,
     two-pass like np.var.  The particle axis is chunked so the (N_p, C, N_s)
@@ -160,6 +163,8 @@ def yvar_full_sweep(model, allsettings, particles, weights, cons, chunk=2048):
         hi = min(n_p, lo + chunk)
         dev = evaluate(lo, hi) - ybar[:, None, :]
         acc = acc + np.einsum("cps,p->cs", dev * dev, weights[lo:hi])
+    if return_mean:
+        return acc / w_sum, ybar
     return acc / w_sum
 
 
@@ -363,11 +368,16 @@ class OracleOptBayesExpt(OracleParticlePDF):
 
     def yvar_from_parameter_draws(self):
         """obe_base.py:463-489 (or the full-sweep limit)."""
+        # (last_ymean: the predicted mean output per setting rides along, so that a checker can state the
+        # conditioning (mean y)^2 / var of each variance from THIS side — tools/fuzz_parity.py)
         if self.utility_method == "variance_full":
-            return yvar_full_sweep(self.model_function, self.allsettings,
-                                   self.particles, self.particle_weights, self.cons)
+            self.last_yvar, self.last_ymean = yvar_full_sweep(self.model_function, self.allsettings, self.particles,
+                                                              self.particle_weights, self.cons, return_mean=True)
+            return self.last_yvar
         draws = self.randdraw(self.N_DRAWS)
-        return yvar_from_draws(self.model_function, self.allsettings, draws, self.cons)
+        self.last_yvar, self.last_ymean = yvar_from_draws(self.model_function, self.allsettings, draws, self.cons,
+                                                          return_mean=True)
+        return self.last_yvar
 
     def _y_space(self):
         """obe_base.py:480-484 — the model over all settings for N_DRAWS drawn parameter sets."""

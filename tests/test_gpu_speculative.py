@@ -71,8 +71,7 @@ def counted(o):
     take, sweep = o._take_speculative_sweep, o._sweep_device
 
     def counting_take(shifted):
-        spec = o.__dict__.get("_spec")
-        if spec is not None and not spec.get("ran"):
+        if o.sweep_state()["pending"] == "aborted":
             n["aborted"] += 1
         got = take(shifted)
         n["taken"] += got is not None
@@ -332,3 +331,79 @@ def test_cycles_on_alternating_streams(hip, sharded):
     for x, y in zip(a, b):
         assert x[0] == y[0] and x[3] == y[3]
         assert np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2])
+
+
+def _run_tool(args, timeout):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return subprocess.run([sys.executable] + [os.path.join(root, args[0])] + args[1:], capture_output=True, text=True,
+                          timeout=timeout, cwd=root)
+
+
+def test_a_slice_of_the_randomised_parity_runs(hip):
+    """150 seeded recipes of tools/fuzz_parity.py inside the suite (random models, cloud and grid
+    sizes, zero weights, utility and selection methods, noise-parameter and sweeper objects — the product classes
+    against the oracle classes step by step).  The long runs stay in the tool; their totals are in DESIGN.md."""
+    r = _run_tool(["tools/fuzz_parity.py", "150", "20261003"], 900)
+    assert r.returncode == 0 and "fuzz: 150 cases, 0 failures" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    print(r.stdout[-1500:])
+    assert "complete: every cycle compared" in r.stdout          # (how the cases ended is part of the report)
+
+
+def test_a_slice_of_the_speculative_soak(hip):
+    """... and 2 000 cycles of tools/soak_speculative.py: random experiments with and without the sweep enqueued
+    behind the update, random things done between pdf_update() and the next opt_setting(), bit for bit."""
+    r = _run_tool(["tools/soak_speculative.py", "5", "77", "2000"], 900)
+    assert r.returncode == 0 and "all equal" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    print(r.stdout[-300:])
+
+
+def test_a_refused_enqueue_leaves_the_weights_alone(hip):
+    """with no arrival counters in the library (OBE_CONTROL_SLOTS=0, a child process)
+    obe_bayes_update_model_moments_enqueue() must refuse BEFORE its first launch, and the package's fallback to
+    the synchronous form must reproduce the plain path bit for bit (tests/_refusal_check.py)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, OBE_CONTROL_SLOTS="0")
+    r = subprocess.run([sys.executable, os.path.join(here, "_refusal_check.py")], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "REFUSAL OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_control_slots_change_hands_when_the_table_is_full(hip):
+    """with room for TWO streams' arrival counters (OBE_CONTROL_SLOTS=2, a child process) an object
+    driven from five streams in turn keeps the fused fold and the speculation on every one of them — the least
+    recently used slot is handed on — and stays bit-identical to a run on one stream."""
+    import os
+    import subprocess
+    import sys
+    code = """
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch
+import optbayesexpt_amd as obe
+import test_gpu_speculative as t
+ref = t.cycles(t.make(obe, True), 15)
+streams = [torch.cuda.Stream() for _ in range(5)]
+meas = np.random.default_rng(5)
+o = t.make(obe, True)
+log = []
+for k in range(15):
+    with torch.cuda.stream(streams[k %% 5]):
+        s = o.opt_setting()
+        y = t.lorentz(s[0], 3.1, 2.2, 0.4, 0.1) + 0.3 * meas.standard_normal()
+        o.pdf_update((s, y, 0.3))
+        log.append((tuple(float(v) for v in s), o.particle_weights.copy(), bool(o.just_resampled)))
+    torch.cuda.synchronize()
+for c, (e, r) in enumerate(zip(log, ref)):
+    assert e[0] == r['setting'] and e[2] == r['resampled'] and np.array_equal(e[1], r['w']), c
+assert not o.sweep_state()['unavailable']
+print('SLOTS OK')
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OBE_CONTROL_SLOTS="2")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SLOTS OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

@@ -387,3 +387,174 @@ def test_bench_boundary_update_runs_without_the_enqueued_sweep():
     with pytest.raises(RuntimeError):
         bench.update_at_boundary(o, ("x", 1.0))
     assert o.tuning_parameters == {"speculative_sweep": True}
+
+
+# ------------------------------------------------------------------------------------------------
+# The sweep-path state machine (optbayesexpt_amd/_sweepstate.py) driven with a recording I/O object:
+# no device, no library.
+def _load_sweepstate():
+    from optbayesexpt_amd import _sweepstate
+    return _sweepstate
+
+
+class _FakeIO:
+    def __init__(self):
+        self.log, self.armed = [], False
+
+    def wait_words(self, words, n, stream):
+        self.log.append(("wait", words, n, stream))
+
+    def still_armed(self, block):
+        return self.armed
+
+    def synchronize(self):
+        self.log.append(("sync",))
+
+
+def _state(ss, io):
+    return ss.SweepState(io, kappa_enter=1000.0, kappa_leave=3000.0, safe_streak=3, safe_retry=64)
+
+
+def _inputs(cloud=(1, 1), shifted=True, noise="n", settings=(0, 100), alias=True, cost_hook=False):
+    return dict(cloud=cloud, shifted=shifted, noise=noise, settings=settings, alias=alias, cost_hook=cost_hook)
+
+
+def test_sweepstate_pattern_and_auto_policy():
+    ss = _load_sweepstate()
+    st = _state(ss, _FakeIO())
+    assert st.pattern is ss.Pattern.COLD and not st.speculation_wanted("auto")
+    assert st.speculation_wanted(True) and not st.speculation_wanted(False) and not st.speculation_wanted("never")
+    for k, want in ((1, ss.Pattern.WARM), (2, ss.Pattern.STEADY), (3, ss.Pattern.STEADY)):
+        st.update_finished((k, k), resampled=False)
+        st.full_sweep_requested((k, k))
+        assert st.pattern is want
+    assert st.speculation_wanted("auto")
+    # a sweep of some OTHER cloud (the caller wrote new weights in between) breaks the pattern
+    st.update_finished((4, 4), resampled=False)
+    st.full_sweep_requested((4, 5))
+    assert st.pattern is ss.Pattern.COLD and not st.speculation_wanted("auto")
+    # ... as does a sweep nobody's update preceded
+    st.full_sweep_requested((4, 5))
+    assert st.pattern is ss.Pattern.COLD
+    # mostly-resampling updates: 'auto' stops guessing behind the update, but still sends the sweep of a resampled cloud
+    for k in range(6, 12):
+        st.update_finished((k, k), resampled=True)
+        st.full_sweep_requested((k, k))
+    assert st.pattern is ss.Pattern.STEADY and st.resample_rate > 0.5
+    assert not st.speculation_wanted("auto") and st.speculation_wanted("auto", after_resample=True)
+    st.library_refused()
+    assert not st.speculation_wanted(True) and st.describe()["unavailable"]
+
+
+def test_sweepstate_resample_behind_a_speculative_sweep():
+    ss = _load_sweepstate()
+    io = _FakeIO()
+    st = _state(ss, io)
+    st.streak = 5
+    st.enqueued(ss.Ticket(_inputs(), "words", "block", None, "s1", 1))
+    assert st.pending is ss.Pending.ENQUEUED
+    st.update_delivered(resampled=True)
+    assert st.pending is ss.Pending.ABORTED
+    # the sweep did nothing: not taken, nothing to wait for (its words stay armed), the pattern is not blamed
+    assert st.take(_inputs(), 1) is None
+    assert io.log == [] and st.pending is ss.Pending.NONE and st.ticket is None and st.streak == 5
+    # the sweep of the resampled cloud is certain
+    st.enqueued(ss.Ticket(_inputs(cloud=(2, 2)), "words", "block", None, "s1", 1), certain=True)
+    assert st.pending is ss.Pending.RAN
+    st.update_delivered(resampled=True)            # (a late delivery changes nothing: not ENQUEUED)
+    assert st.pending is ss.Pending.RAN
+    t = st.take(_inputs(cloud=(2, 2)), 1)
+    assert t is not None and io.log == [("wait", "words", 3, "s1")] and st.pending is ss.Pending.NONE
+
+
+def test_sweepstate_stream_change_between_the_calls():
+    ss = _load_sweepstate()
+    # unsharded (page-locked result words): collected on the stream it was launched on, whatever is current now
+    io = _FakeIO()
+    st = _state(ss, io)
+    st.enqueued(ss.Ticket(_inputs(), "words", "block", None, "s1", 1))
+    st.update_delivered(resampled=False)
+    assert st.take(_inputs(), 2) is not None and io.log == [("wait", "words", 3, "s1")]
+    # sharded (the record stays on the device): only usable on the same stream; dropped with a device sync otherwise
+    io = _FakeIO()
+    st = _state(ss, io)
+    st.streak = 4
+    st.enqueued(ss.Ticket(_inputs(), None, "block", "record", "s1", 1))
+    st.update_delivered(resampled=False)
+    assert st.take(_inputs(), 2) is None and io.log == [("sync",)] and st.streak == 0
+    st.enqueued(ss.Ticket(_inputs(), None, "block", "record", "s1", 1))
+    st.update_delivered(resampled=False)
+    t = st.take(_inputs(), 1)
+    assert t is not None and t.record == "record" and io.log == [("sync",)]      # (no wait: the collective reads it)
+
+
+def test_sweepstate_hook_replaced_or_set_pdf_between_the_calls():
+    ss = _load_sweepstate()
+    for changed in (dict(cost_hook=True), dict(cloud=(9, 9)), dict(noise="other"), dict(alias=False),
+                    dict(shifted=False), dict(settings=(0, 50))):
+        io = _FakeIO()
+        st = _state(ss, io)
+        st.streak = 3
+        st.enqueued(ss.Ticket(_inputs(), "words", "block", None, "s1", 1))
+        st.update_delivered(resampled=False)
+        # not the sweep being asked for: forgotten — but it RAN and will write its words: waited for before
+        # anything arms them again; two plain cycles before the next attempt
+        assert st.take(_inputs(**changed), 1) is None, changed
+        assert io.log == [("wait", "words", 3, "s1")] and st.streak == 0 and st.ticket is None
+    # an undelivered result (the stream drained, the words still armed): not run
+    io = _FakeIO()
+    io.armed = True
+    st = _state(ss, io)
+    st.enqueued(ss.Ticket(_inputs(), "words", "block", None, "s1", 1))
+    st.update_delivered(resampled=False)
+    assert st.take(_inputs(), 1) is None and st.pending is ss.Pending.NONE
+    # drop() of nothing is nothing
+    st.drop(1)
+    assert io.log == [("wait", "words", 3, "s1")]
+
+
+def test_sweepstate_kappa_crossing_both_thresholds():
+    ss = _load_sweepstate()
+    st = _state(ss, _FakeIO())
+    assert st.shifted_for_next_sweep("auto", full=True)                       # starts shifted
+    assert not st.shifted_for_next_sweep("never", True) and st.shifted_for_next_sweep("always", True)
+    assert st.shifted_for_next_sweep("never", full=False)                     # draws mode: always shifted
+    assert not st.sweep_reported_kappa("auto", True, True, 500.0) and st.unshifted        # below ENTER: go unshifted
+    assert not st.shifted_for_next_sweep("auto", True)
+    assert not st.sweep_reported_kappa("auto", True, False, 2000.0) and st.unshifted      # between: kept (hysteresis)
+    assert st.sweep_reported_kappa("auto", True, False, 5000.0) and not st.unshifted      # above LEAVE: repeat shifted
+    assert not st.sweep_reported_kappa("auto", True, True, 2000.0) and not st.unshifted   # shifted, above ENTER: stays
+    st.unshifted = True
+    assert st.sweep_reported_kappa("auto", True, False, float("nan")) and not st.unshifted  # NaN: never kept
+    assert not st.sweep_reported_kappa("auto", True, True, float("nan")) and not st.unshifted
+    st.unshifted = True                  # the other modes and draws-mode sweeps leave the hysteresis alone
+    assert not st.sweep_reported_kappa("never", True, False, 1e9) and st.unshifted
+    assert not st.sweep_reported_kappa("auto", False, True, 1.0) and st.unshifted
+
+
+def test_sweepstate_form_policy():
+    ss = _load_sweepstate()
+    st = _state(ss, _FakeIO())
+    assert st.form_for_next_sweep() is ss.Form.FAST
+    for k in range(3):
+        assert st.form is ss.Form.FAST
+        st.fast_form_left_its_range()
+    assert st.form is ss.Form.SAFE
+    for k in range(63):                                   # pinned: 63 sweeps with the twin ...
+        assert st.form_for_next_sweep() is ss.Form.SAFE
+    assert st.form_for_next_sweep() is ss.Form.FAST       # ... the 64th probes the fast form
+    st.fast_form_left_its_range()                         # a failure pins it again at once
+    assert st.form is ss.Form.SAFE and st.safe_run == 0
+    for k in range(63):
+        st.form_for_next_sweep()
+    assert st.form_for_next_sweep() is ss.Form.FAST
+    st.fast_form_held()
+    assert st.form is ss.Form.FAST and st.safe_streak == 0
+    st.range_hint(False)
+    assert st.form is ss.Form.SAFE
+    st.range_hint(None)
+    assert st.form is ss.Form.SAFE
+    st.range_hint(True)
+    assert st.form is ss.Form.FAST and st.safe_streak == 2          # one fast attempt; a failure pins it again
+    st.fast_form_left_its_range()
+    assert st.form is ss.Form.SAFE

@@ -7,6 +7,7 @@ noise-parameter options — the product classes against the oracle classes step 
 Every cycle: chosen setting index and resample decision exact, utility / weights / N_eff / moments
 1e-9 (with absolute floors for values that vanish by cancellation), particles after a resample
 given the same normals.  Prints the failing case's recipe so that it can be replayed."""
+import collections
 import os
 import sys
 import traceback
@@ -24,6 +25,12 @@ from oracle import models as om  # noqa: E402
 
 RTOL = 1e-9
 _EXPR = None
+#: how the cases ended (coverage lost through early returns and widened tolerances must be visible)
+STATS = collections.Counter()
+
+
+def ended(why):
+    STATS[why] += 1
 
 
 def close(a, b, what, rtol=RTOL, floor=1e-3):
@@ -162,17 +169,17 @@ def run_case(case):
             # (a prior with sigma <= 0 gives negative likelihoods; all-zero likelihoods give zero weights)
             # the reference's randdraw fails with numpy's ValueError: so must every draw on the device
             if case["full"]:
-                return
+                return ended("early: weights numpy rejects, full sweep")
             try:
                 a.opt_setting() if case["selection"] == "opt" else a.good_setting(pickiness=7)
             except ValueError:
-                return
+                return ended("early: weights numpy rejects, both sides raise")
             raise AssertionError(f"{tag}: probabilities numpy rejects did not raise")
         if case["selection"] == "opt":
             xa, xb = a.opt_setting(), b.opt_setting()
             if np.max(b.last_utility) <= 1e-20 * sigma ** -2 or \
                     (not case["full"] and len(np.unique(b.last_draw_indices)) == 1):
-                return        # all draws identical: the reference's variance is rounding
+                return ended("early: all draws identical")      # the reference's variance is rounding
             ua = a.last_utility if case.get("yspace") else a._gather_settings(a._utility_dev.reshape(1, -1))[0]
             rtol = 1e-9 if case.get("yspace") or case["n_draws"] < 5 or case.get("expression") else 1e-10
             if not case["full"]:
@@ -183,31 +190,42 @@ def run_case(case):
                 drawn = np.asarray(b.particles)[:, np.asarray(b.last_draw_indices).reshape(-1)]
                 sd, mu = drawn.std(axis=1), np.abs(drawn.mean(axis=1))
                 ratio = float(np.max(mu[sd > 0] / sd[sd > 0])) if np.any(sd > 0) else 0.0
+                if 3 * 4.4e-16 * ratio / np.sqrt(drawn.shape[1]) > rtol:
+                    STATS["widened: packed-term rounding of a narrow cloud"] += 1
                 rtol = max(rtol, 3 * 4.4e-16 * ratio / np.sqrt(drawn.shape[1]))
             # ... and every evaluation of the model carries its own rounding, eps_y relative (a few 1e-16 for the
             # rational models, ~2e-15 where exp / cos / hypot are involved): against a spread of y that is 1 / sqrt(kappa)
             # of y — the sweep reports kappa = (mean y)^2 / var, worst over the settings — that is 2 eps_y sqrt(kappa) of a
             # variance, averaged down by the square root of the effective number of draws.  A cloud of 2 particles a
             # resample has contracted reaches kappa ~ 5e9 (case 9079 of seed 5151: 1.4e-9 in a variance of 2e-10).
-            kap = float(getattr(a, "last_sweep", {}).get("kappa", 0.0) or 0.0)
+            # (kappa from the ORACLE's own mean and variance of y at the settings — not the device's report, which
+            # a wrong sweep could get wrong together with the variance — and capped)
+            kap = 0.0
+            if not case.get("yspace"):
+                b_var = np.asarray(b.last_yvar)
+                b_mean = np.asarray(b.last_ymean)
+                with np.errstate(all="ignore"):
+                    k_all = np.where(b_var > 0.0, b_mean ** 2 / b_var, 0.0)
+                kap = float(np.max(k_all[np.isfinite(k_all)])) if np.any(np.isfinite(k_all)) else 0.0
             if np.isfinite(kap) and kap > 0.0 and not case.get("yspace"):
                 eps_y = 2e-15 if case["kind"] in ("rabi", "coil") or case.get("expression") else 4e-16
                 n_eff = 1.0 / float(np.sum(np.asarray(wb0) ** 2)) if case["full"] else float(case["n_draws"])
-                # (kappa is the device's own report: the allowance is capped, so that a variance that is simply
-                # wrong — and a kappa wrong with it — still fails)
-                rtol = max(rtol, min(1e-8, 4.0 * eps_y * np.sqrt(kap) / np.sqrt(max(n_eff, 1.0))))
+                allow = min(1e-8, 4.0 * eps_y * np.sqrt(kap) / np.sqrt(max(n_eff, 1.0)))
+                if allow > rtol:
+                    STATS["widened: conditioning of the variance (oracle-side kappa)"] += 1
+                rtol = max(rtol, allow)
             close(np.asarray(ua).reshape(-1), np.asarray(b.last_utility).reshape(-1), f"{tag} utility", rtol=rtol)
         else:
             xb = b.good_setting(pickiness=7)
             if np.max(b.last_utility) <= 1e-20 * sigma ** -2 or \
                     (not case["full"] and len(np.unique(b.last_draw_indices)) == 1):
-                return
+                return ended("early: all draws identical")
             if not np.all(np.isfinite(np.nan_to_num(b.last_utility ** 7) / np.sum(np.nan_to_num(b.last_utility ** 7)))):
                 # p = 0/0: numpy's Generator.choice raises ValueError in the reference; so must the device path
                 try:
                     a.good_setting(pickiness=7)
                 except ValueError:
-                    return
+                    return ended("early: NaN selection probabilities, both sides raise")
                 raise AssertionError(f"{tag}: NaN selection probabilities did not raise")
             xa = a.good_setting(pickiness=7)
         if not case["full"]:
@@ -226,14 +244,14 @@ def run_case(case):
             try:
                 b.pdf_update(rec)
             except np.linalg.LinAlgError:
-                return
+                return ended("early: degenerate covariance, both sides raise")
             if np.sum(wpost) - np.sum(wpost * wpost) / np.sum(wpost) < 1e-6:
-                return        # 1 / (sum w - sum w^2 / sum w): inf on one side, huge on the other
+                return ended("early: degenerate covariance, device side raises")   # 1 / (sum w - sum w^2 / sum w): inf on one side, huge on the other
             raise AssertionError(f"{tag}: LinAlgError on the device path only")
         except ValueError:
             # the resample inside pdf_update drew from weights numpy rejects (negative likelihoods)?
             if numpy_rejects(wpost):
-                return
+                return ended("early: resample from weights numpy rejects")
             raise
         try:
             b.pdf_update(rec)
@@ -241,7 +259,7 @@ def run_case(case):
             # the other way round: the oracle's covariance came out non-finite where the device's is merely huge
             # (case 10394 of seed 9090: 7 particles, one of them carrying the weight)
             if np.sum(wpost) - np.sum(wpost * wpost) / np.sum(wpost) < 1e-6:
-                return
+                return ended("early: degenerate covariance, oracle side raises")
             raise AssertionError(f"{tag}: LinAlgError in the oracle only")
         assert bool(a.just_resampled) == bool(b.just_resampled), f"{tag}: resample decision"
         wb = np.asarray(b.particle_weights)
@@ -285,6 +303,7 @@ def run_case(case):
             assert np.all(np.abs(sa[ok] ** 2 - sb[ok] ** 2) <= 256 * 2.3e-16 * m2[ok] + 1e-10 * sb[ok] ** 2), \
                 f"{tag} std: {sa} vs {sb}"
     assert a.rng.bit_generator.state == b.rng.bit_generator.state, "generator state"
+    ended("complete: every cycle compared")
 
 
 def make_sweeper_case(g):
@@ -376,6 +395,8 @@ def main():
             if failures >= 10:
                 break
     print(f"fuzz: {n_cases} cases, {failures} failures")
+    for why, count in sorted(STATS.items()):
+        print(f"  {count:6d}  {why}")
     return failures
 
 

@@ -1,6 +1,6 @@
 """Long runs with and without the sweep enqueued behind the update, compared bit for bit (developer aid, GPU):
 
-    python tools/soak_speculative.py [minutes=3] [seed=0]
+    python tools/soak_speculative.py [minutes=3] [seed=0] [max_cycles=0 (no limit)]
 
 Random cloud / grid sizes, both classes, thresholds that resample rarely or often, random things done between
 pdf_update() and the next opt_setting().  Uses the helpers of tests/test_gpu_speculative.py."""
@@ -19,11 +19,12 @@ import test_gpu_speculative as t          # noqa: E402
 
 minutes = float(sys.argv[1]) if len(sys.argv) > 1 else 3.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+max_cycles = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 g = np.random.default_rng(seed)
 warnings.simplefilter("ignore")
 t_end = time.time() + 60 * minutes
 runs = cycles = taken = 0
-while time.time() < t_end:
+while time.time() < t_end and not (max_cycles and cycles >= max_cycles):
     n = int(g.choice([3000, 20000, 70000, 300000]))
     ns = int(g.choice([300, 1500, 2048, 5000]))
     noise = bool(g.integers(2))
