@@ -404,6 +404,10 @@ int obe_power_normalize(const double* d_u, int64_t n, double exponent, double* d
  * caller that predicts whether a settings grid stays inside that form's range needs
  * (optbayesexpt_amd/models.py: range_hint). */
 int obe_sweep_settings_per_lane(int64_t n_settings);
+/* ... and for a reference-semantics sweep of n_draws draws (obe_base.py:463-489 with N_DRAWS draws): 1 when the
+ * one-workgroup kernel serves it.  A model whose fast form shares nothing but the reciprocal of a lane's
+ * settings is IEEE as it is when this returns 1: no range check, no repeat (models.py: safe_sweep_min_spt). */
+int obe_sweep_settings_per_lane_for(int64_t n_settings, int64_t n_draws);
 int obe_sweep_utility(const obe_model* m,
                       const double* d_settings, int64_t ld_s, int64_t n_settings,
                       const double* d_particles, int64_t ld_p, int64_t n_particles,

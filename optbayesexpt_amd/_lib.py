@@ -114,6 +114,7 @@ _SIGNATURES = {
     "obe_timer_stop": (c_int, [_P, _P, ctypes.POINTER(ctypes.c_float)]),
     "obe_timer_destroy": (c_int, [_P]),
     "obe_sweep_settings_per_lane": (c_int, [c_int64]),
+    "obe_sweep_settings_per_lane_for": (c_int, [c_int64, c_int64]),
     "obe_host_device_pointer": (c_int, [_P, ctypes.POINTER(c_void_p)]),
     "obe_host_words_arm": (c_int, [_P, c_int64]),
     "obe_host_words_wait": (c_int, [_P, c_int64, _P]),
@@ -126,7 +127,8 @@ _SIGNATURES = {
 
 
 # entry points whose code depends on the model: a plugin library serves these
-MODEL_ENTRY_POINTS = ("obe_model_validate", "obe_workspace_bytes", "obe_sweep_settings_per_lane", "obe_bayes_update_model",
+MODEL_ENTRY_POINTS = ("obe_model_validate", "obe_workspace_bytes", "obe_sweep_settings_per_lane",
+                      "obe_sweep_settings_per_lane_for", "obe_bayes_update_model",
                       "obe_bayes_update_model_moments", "obe_bayes_update_model_moments_enqueue",
                       "obe_bayes_update_sweep",
                       "obe_eval_over_particles",

@@ -414,12 +414,25 @@ struct Lorentz {
     // to ~170 at K = 7) and a sweep that leaves the range is repeated with sweep_eval_safe() — the
     // peak-by-peak form, good to |x - x0|/d ~ 1e19.
     static constexpr bool kCombinePeaks = K >= 3;
-    static constexpr bool kHasSafeEval = kCombinePeaks;
+    // Every K has a fast form that poisons a batch whose inversion tree leaves the double range and a SAFE twin
+    // that is IEEE for any finite denominator (round 5: K = 1, 2 as well — their fast pair form used to return a
+    // NaN variance beyond |x - x0|/d ~ 4e9 with nothing to repeat the sweep with):
+    //   fast, K < 3 : two particles x SPT settings of one peak share one reciprocal (q^16).  No range check is
+    //                 spent on it: every q >= 1, so the only failure is OVERFLOW of a product, an overflowed root
+    //                 is +inf, fast_rcp(+inf) = NaN (0 * inf in its correction step) and the NaN reaches all 16
+    //                 results, the setting's variance and kappa — the host repeats the sweep SAFE.  A finite root
+    //                 is inverted to >= 50 bits even where 1/root is subnormal.
+    //   fast, K >= 3: the combined fraction, range-checked (batch_div_ge1).
+    //   SAFE, all K : the pair form per peak with a branch: a batch whose root stays below 1e250 shares its
+    //                 reciprocal as before, any other is inverted element by element (guarded_rcp) — the
+    //                 reference's numbers for |x - x0|/d up to sqrt(DBL_MAX) ~ 1e154, where t*t itself overflows
+    //                 and NumPy, too, gets a / inf = 0.
+    static constexpr bool kHasSafeEval = true;
     template <int SPT>
     __device__ __forceinline__ static void sweep_eval(const double (&xs)[SPT][NXS], const double* pk, double sw,
                                                       const obe_model& m, double (&v)[SPT][NC]) {
         if constexpr (!kCombinePeaks) {
-            sweep_eval_safe<SPT>(xs, pk, sw, m, v);
+            sweep_eval_one<SPT, false>(xs, pk, v);
         } else {
             double num[SPT], den[SPT];
 #pragma unroll
@@ -438,10 +451,15 @@ struct Lorentz {
             for (int j = 0; j < SPT; ++j) v[j][0] = fma(ip[j / 2] * sibling_of<SPT>(den, j), num[j], pk[K + 1]);
         }
     }
-    // the peak-by-peak form: one batched inversion per peak
+    // the peak-by-peak form: one batched inversion per peak (SAFE: range-guarded, see above)
     template <int SPT>
     __device__ __forceinline__ static void sweep_eval_safe(const double (&xs)[SPT][NXS], const double* pk, double,
                                                            const obe_model&, double (&v)[SPT][NC]) {
+        sweep_eval_one<SPT, true>(xs, pk, v);
+    }
+    template <int SPT, bool GUARDED>
+    __device__ __forceinline__ static void sweep_eval_one(const double (&xs)[SPT][NXS], const double* pk,
+                                                          double (&v)[SPT][NC]) {
 #pragma unroll
         for (int j = 0; j < SPT; ++j) v[j][0] = pk[K + 1];
 #pragma unroll
@@ -453,20 +471,32 @@ struct Lorentz {
                 q[j] = fma(t, t, 1.0);
             }
             if constexpr (SPT == 1) {
-                v[0][0] = fma(pk[K], exact_rcp(q[0]), v[0][0]);
+                // (nothing shared: the IEEE-edged reciprocal in BOTH forms — a lane that owns one setting cannot
+                // leave the fast form's range, which is what lets small sweeps go unchecked: models.py,
+                // safe_sweep_min_spt)
+                v[0][0] = fma(pk[K], guarded_rcp(q[0]), v[0][0]);
             } else {
                 // Batch inversion stopped one level early: invert the SPT/2 pair products, fold
                 // the amplitude into each pair inverse, and let the final multiply by the sibling
                 // be the FMA that accumulates the peak:  a/q0 = (a / (q0 q1)) * q1.
                 double pp[SPT / 2], ip[SPT / 2];
-#pragma unroll
-                for (int h = 0; h < SPT / 2; ++h) pp[h] = q[2 * h] * q[2 * h + 1];
-                batch_rcp<SPT / 2>(pp, ip);
+                double root = 1.0;
 #pragma unroll
                 for (int h = 0; h < SPT / 2; ++h) {
-                    const double g = pk[K] * ip[h];
-                    v[2 * h][0] = fma(g, q[2 * h + 1], v[2 * h][0]);
-                    v[2 * h + 1][0] = fma(g, q[2 * h], v[2 * h + 1][0]);
+                    pp[h] = q[2 * h] * q[2 * h + 1];
+                    if constexpr (GUARDED) root *= pp[h];
+                }
+                if (!GUARDED || root < 1e250) {
+                    batch_rcp<SPT / 2>(pp, ip);
+#pragma unroll
+                    for (int h = 0; h < SPT / 2; ++h) {
+                        const double g = pk[K] * ip[h];
+                        v[2 * h][0] = fma(g, q[2 * h + 1], v[2 * h][0]);
+                        v[2 * h + 1][0] = fma(g, q[2 * h], v[2 * h + 1][0]);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < SPT; ++j) v[j][0] = fma(pk[K], guarded_rcp(q[j]), v[j][0]);
                 }
             }
         }
@@ -474,11 +504,10 @@ struct Lorentz {
     // Two particles at once: their 2*SPT/2 pair products share ONE reciprocal, and each
     // particle's amplitude enters the inversion tree at its root (2 multiplies per 16 evaluations).
     // The fast form of the peak-by-peak models (a combined fraction already spans q^(8K) per
-    // particle) and, for K >= 3, the form the SAFE repeat streams its particles through: the tree
-    // spans q^16 per peak whatever K is, in range for |x - x0|/d up to ~1e9.
+    // particle) and, range-guarded, the form every SAFE repeat streams its particles through.
     static constexpr bool kHasPairEval = !kCombinePeaks;
-    static constexpr bool kSafePairEval = kCombinePeaks;
-    template <int SPT>
+    static constexpr bool kSafePairEval = true;
+    template <int SPT, bool GUARDED = false>
     __device__ __forceinline__ static void sweep_eval_pair(const double (&xs)[SPT][NXS], const double* pa,
                                                            const double* pb, double (&va)[SPT][NC],
                                                            double (&vb)[SPT][NC]) {
@@ -497,19 +526,29 @@ struct Lorentz {
                 qa[j] = fma(ta, ta, 1.0);
                 qb[j] = fma(tb, tb, 1.0);
             }
+            double root = 1.0;
 #pragma unroll
             for (int h = 0; h < SPT / 2; ++h) {
                 pp[h] = qa[2 * h] * qa[2 * h + 1];
                 pp[SPT / 2 + h] = qb[2 * h] * qb[2 * h + 1];
+                if constexpr (GUARDED) root *= pp[h] * pp[SPT / 2 + h];
             }
-            batch_rcp_scaled2<SPT>(pp, pa[K], pb[K], ip);      // ip = amplitude / pair product
+            if (!GUARDED || root < 1e250) {
+                batch_rcp_scaled2<SPT>(pp, pa[K], pb[K], ip);      // ip = amplitude / pair product
 #pragma unroll
-            for (int h = 0; h < SPT / 2; ++h) {
-                const double ga = ip[h], gb = ip[SPT / 2 + h];
-                va[2 * h][0] = fma(ga, qa[2 * h + 1], va[2 * h][0]);
-                va[2 * h + 1][0] = fma(ga, qa[2 * h], va[2 * h + 1][0]);
-                vb[2 * h][0] = fma(gb, qb[2 * h + 1], vb[2 * h][0]);
-                vb[2 * h + 1][0] = fma(gb, qb[2 * h], vb[2 * h + 1][0]);
+                for (int h = 0; h < SPT / 2; ++h) {
+                    const double ga = ip[h], gb = ip[SPT / 2 + h];
+                    va[2 * h][0] = fma(ga, qa[2 * h + 1], va[2 * h][0]);
+                    va[2 * h + 1][0] = fma(ga, qa[2 * h], va[2 * h + 1][0]);
+                    vb[2 * h][0] = fma(gb, qb[2 * h + 1], vb[2 * h][0]);
+                    vb[2 * h + 1][0] = fma(gb, qb[2 * h], vb[2 * h + 1][0]);
+                }
+            } else {        // (SAFE only) this lane's 16 denominators do not fit one product: one by one
+#pragma unroll
+                for (int j = 0; j < SPT; ++j) {
+                    va[j][0] = fma(pa[K], guarded_rcp(qa[j]), va[j][0]);
+                    vb[j][0] = fma(pb[K], guarded_rcp(qb[j]), vb[j][0]);
+                }
             }
         }
     }

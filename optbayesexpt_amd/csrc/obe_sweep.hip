@@ -267,7 +267,8 @@ __global__ __launch_bounds__(kBlock) OBE_SWEEP_OCCUPANCY void sweep_kernel(Sweep
 #pragma unroll
             for (int e = 0; e < G; e += 2) {              // two particles share one reciprocal
                 double va[SPT][NC], vb[SPT][NC];
-                M::template sweep_eval_pair<SPT>(xs, g[e], g[e + 1], va, vb);
+                if constexpr (SAFE) M::template sweep_eval_pair<SPT, true>(xs, g[e], g[e + 1], va, vb);
+                else M::template sweep_eval_pair<SPT>(xs, g[e], g[e + 1], va, vb);
                 accumulate(va, g[e][NPK]);
                 accumulate(vb, g[e + 1][NPK]);
             }
@@ -894,6 +895,14 @@ extern "C" {
 
 int obe_sweep_settings_per_lane(int64_t n_settings) {
     return plan_sweep(n_settings < 1 ? 1 : n_settings, (int64_t)1 << 40).spt;      // the most any draw count gets
+}
+
+int obe_sweep_settings_per_lane_for(int64_t n_settings, int64_t n_draws) {
+    if (n_settings < 1) n_settings = 1;
+    if (n_draws < 1) return obe_sweep_settings_per_lane(n_settings);
+    static const bool no_small = getenv("OBE_SWEEP_NO_SMALL") != nullptr;
+    if (!no_small && n_draws <= kSmallSweepDraws && n_settings * n_draws <= kSmallSweepEvals) return 1;   // one-workgroup path
+    return plan_sweep(n_settings, n_draws).spt;
 }
 
 int64_t obe_workspace_bytes(int64_t n_particles, int64_t n_settings, int32_t n_channels, int32_t n_dims) {

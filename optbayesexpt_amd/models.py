@@ -37,16 +37,20 @@ class DeviceModel:
     """
 
     def __init__(self, name, model_id, aux, n_read, n_setdims, n_channels, n_consts, numpy_form,
-                 plugin_path=None, safe_sweep=None, range_hint=None):
+                 plugin_path=None, safe_sweep=None, range_hint=None, safe_sweep_min_spt=1):
+        #: the fast sweep form can leave its exact range only when a lane owns at least this many settings
+        #: (obe_sweep_settings_per_lane): 2 for models whose ONLY shared arithmetic is the batched reciprocal
+        #: of a lane's settings — a sweep of few settings (one per lane) is then IEEE as it is and needs no
+        #: kappa check, no repeat, and no host round trip when nobody asks for its result
+        self.safe_sweep_min_spt = int(safe_sweep_min_spt)
         #: optional ``range_hint(settings (S, n), particles (D, N), cons, settings_per_lane)`` ->
         #: True / False: a cheap host-side *prediction* of whether the fast sweep form stays inside
         #: its exact range on this grid and cloud.  False makes the first sweep start with the safe
         #: form instead of discovering it by a poisoned fast attempt; the kernel's own range check
         #: stays the guarantee either way.  (Range of the safe forms themselves: generated models and the
-        #: coil invert element by element — any finite denominator; the multi-peak Lorentzian's safe form
-        #: inverts the 16 denominators of two particles x 8 settings of one peak together and is exact for
-        #: |x - x0| / d up to ~2e9 — a peak 10^9 times narrower than the settings span — beyond which the
-        #: utility of the affected settings is NaN, where the reference returns ~0.)
+        #: coil invert element by element — any finite denominator; the Lorentzians' safe form inverts the 16
+        #: denominators of two particles x 8 settings of one peak together while their product fits a double
+        #: and element by element otherwise: the reference's numbers for any |x - x0| / d.)
         self.range_hint = range_hint
         #: path of the per-model plugin library (expression models), else None
         self.plugin_path = plugin_path
@@ -105,22 +109,28 @@ def lorentzian(n_peaks=1):
         return y
 
     def in_range(settings, particles, cons, settings_per_lane):
-        # the combined form inverts the denominators of a lane's settings together: a tree over
+        # K >= 3: the combined form inverts the denominators of a lane's settings together: a tree over
         # prod_k q_k of each, q_k = 1 + ((x - x0_k)/d)^2, range-checked at 1e250 in the kernel
-        # (csrc/obe_models.h: batch_div_ge1); bound every q by the extremes of grid and cloud
+        # (csrc/obe_models.h: batch_div_ge1).  K < 3: two particles' denominators of ONE peak for a lane's
+        # settings share a reciprocal (q^(2 spt)); an overflowing product poisons the batch.  Either way the
+        # sweep is then repeated with the SAFE form; bounding every q by the extremes of grid and cloud
+        # predicts it, so that such a grid starts with the SAFE form
         x, d = np.asarray(settings[0], dtype=np.float64), abs(float(cons[0]))
         x_lo, x_hi = float(np.min(x)), float(np.max(x))
         with np.errstate(all="ignore"):
-            decades = 0.0
+            per_peak = []
             for k in range(n_peaks):
                 lo, hi = float(np.min(particles[k])), float(np.max(particles[k]))
                 t = max(abs(x_hi - lo), abs(x_lo - lo), abs(x_hi - hi), abs(x_lo - hi)) / d
-                decades += np.log10(1.0 + t * t)
-            return bool(settings_per_lane * decades < 245.0)
-    # 3 and more peaks: the sweep combines the peaks of an evaluation into one fraction, range-checked,
-    # with the peak-by-peak form as its safe twin (csrc/obe_models.h, Lorentz<K>::kCombinePeaks)
+                per_peak.append(np.log10(1.0 + t * t))
+            if n_peaks >= 3:
+                return bool(settings_per_lane * sum(per_peak) < 245.0)
+            return bool(settings_per_lane < 2 or 2 * settings_per_lane * max(per_peak) < 245.0)
+    # the fast sweep forms (3 and more peaks: the peaks of an evaluation combined into one fraction, range-checked;
+    # 1 or 2 peaks: two particles per reciprocal, poisoned by overflow) have an always-IEEE twin for the repeat:
+    # the pair form with a per-batch branch to element-by-element reciprocals (csrc/obe_models.h, Lorentz<K>)
     return DeviceModel(f"lorentzian[{n_peaks}]", MODEL_LORENTZ, n_peaks, n_peaks + 2, 1, 1, 1, form,
-                       safe_sweep=n_peaks >= 3, range_hint=in_range if n_peaks >= 3 else None)
+                       safe_sweep=True, range_hint=in_range, safe_sweep_min_spt=2 if n_peaks < 3 else 1)
 
 
 def line_ab():

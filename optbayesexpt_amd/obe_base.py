@@ -730,8 +730,8 @@ class OptBayesExpt(ParticlePDF):
         # utility_variance), a draws-mode sweep is always shifted (kappa decides nothing) and the model's
         # fast form cannot leave its range.  Then the launch returns no host result and does not
         # synchronise; the deferred check of sum(w) happens at the caller's own synchronisation.
-        lazy = (not want_best and not full and not sharded
-                and not getattr(self._device_model, "safe_sweep", False))
+        checked = self._sweep_needs_range_check(n_draws)
+        lazy = not want_best and not full and not sharded and not checked
         off = _lib.OBE_WS_RESULT_OFFSET
 
         def launch(shifted, safe=False, speculative=False):
@@ -808,12 +808,12 @@ class OptBayesExpt(ParticlePDF):
             else:
                 deliver(taken if sharded else None)
             self._check_pending_total()
-            poisoned = bool(np.isnan(kappa[0])) and bool(self._device_model.safe_sweep)
+            poisoned = checked and bool(np.isnan(kappa[0]))
             if state.sweep_reported_kappa(mode, full, shifted, float(kappa[0])):
                 shifted = True
                 if not poisoned:          # (a poisoned sweep is repeated below anyway, with the twin)
                     launch(True)
-                    poisoned = bool(np.isnan(kappa[0])) and bool(self._device_model.safe_sweep)
+                    poisoned = checked and bool(np.isnan(kappa[0]))
             if poisoned:
                 # a model's branch-free batched divisions left their exact range somewhere (or the
                 # model really produces NaN): repeat with its always-in-range twin
@@ -835,6 +835,23 @@ class OptBayesExpt(ParticlePDF):
             return result["best"]
         return None
 
+    def _settings_per_lane(self, n_draws=0):
+        """Settings one lane of the sweep kernel owns on this object's slice: at most (n_draws = 0, what a full
+        sweep gets), or in a reference-semantics sweep of n_draws draws (1 on the one-workgroup path)."""
+        cache = self.__dict__.setdefault("_spt_local", {})
+        spt = cache.get(n_draws)
+        if spt is None:
+            n_local = max(self._s_end - self._s_begin, 1)
+            spt = cache[n_draws] = int(self._mlib.cdll.obe_sweep_settings_per_lane_for(n_local, n_draws))
+        return spt
+
+    def _sweep_needs_range_check(self, n_draws=0):
+        """Whether this sweep's fast form can leave its exact range at all (then kappa is read back and a NaN
+        repeats the sweep with the model's twin): the model has such a pair of forms and a lane owns enough
+        settings for its batched arithmetic to exist (DeviceModel.safe_sweep_min_spt)."""
+        dm = self._device_model
+        return bool(dm is not None and dm.safe_sweep and self._settings_per_lane(n_draws) >= dm.safe_sweep_min_spt)
+
     def _apply_range_hint(self):
         """Models with a ``range_hint`` (models.py) predict from the settings grid and the extremes
         of a cloud the host holds (the prior, set_pdf, user-written particles) whether their fast
@@ -850,7 +867,7 @@ class OptBayesExpt(ParticlePDF):
         n_local = self._s_end - self._s_begin
         if n_local <= 0:
             return
-        spt = int(self._mlib.cdll.obe_sweep_settings_per_lane(n_local))
+        spt = self._settings_per_lane()
         state.range_hint(hint(self.allsettings[:, self._s_begin:self._s_end], pm._host, self.cons, spt))
 
     def yvar_from_parameter_draws(self):

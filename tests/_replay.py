@@ -285,11 +285,25 @@ def assert_rel(got, ref, rtol=1e-10, what="", garbage_floor=0.0):
         err[live] = np.abs(got[live] - ref[live]) / np.abs(ref[live])
     err[live & (got == ref)] = 0.0                     # (inf == inf, 0 == 0)
     if live.any():
-        k = np.unravel_index(int(np.argmax(err)), err.shape)
-        assert err[k] <= rtol, (f"{what}: worst relative error {err[k]:.3g} > {rtol:g} at element {k}: got "
-                                f"{got[k]!r}, reference {ref[k]!r} (largest reference value {np.nanmax(np.abs(ref)):.6g})")
+        tol = np.broadcast_to(np.asarray(rtol, dtype=np.float64), err.shape)      # (a scalar, or one per element)
+        k = np.unravel_index(int(np.argmax(np.where(live, err / tol, 0.0))), err.shape)
+        assert err[k] <= tol[k], (f"{what}: worst relative error {err[k]:.3g} > {tol[k]:g} at element {k}: got "
+                                  f"{got[k]!r}, reference {ref[k]!r} (largest reference value {np.nanmax(np.abs(ref)):.6g})")
     dead = ~np.isnan(ref) & ~live
     if dead.any():
         assert np.all(np.abs(got[dead]) <= garbage_floor), \
             f"{what}: {int(np.sum(np.abs(got[dead]) > garbage_floor))} value(s) above the debris floor {garbage_floor:g} where the reference is below it"
     return float(err.max()) if live.any() else 0.0
+
+
+def conditioning_rtol(ref_var, ref_mean, n_eff, floor=1e-10, eps_y=2.3e-16):
+    """Per-element relative tolerance for a variance whose samples y are each rounded to eps_y |y|: against a
+    spread of sqrt(var) that is 2 eps_y |mean y| / sqrt(var) of the variance per sample, averaged down by the
+    square root of the effective number of samples — what the REFERENCE's own two-pass np.var is good to when
+    (mean y)^2 / var is large (a converged posterior on a 5e4 background).  Never below ``floor``; x4 margin.
+    Computed from the oracle's mean and variance, not from anything the device reports."""
+    import numpy as np
+    ref_var, ref_mean = np.asarray(ref_var, dtype=np.float64), np.asarray(ref_mean, dtype=np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        cond = np.where(ref_var > 0.0, np.abs(ref_mean) / np.sqrt(ref_var), 0.0)
+    return np.maximum(floor, 4.0 * 2.0 * eps_y * cond / np.sqrt(max(float(n_eff), 1.0)))
