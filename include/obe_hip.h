@@ -149,6 +149,16 @@ int obe_bayes_update_model_moments(const obe_model* m,
                                    int32_t n_lik_channels, double choke, double* d_moments,
                                    void* d_ws, int64_t ws_bytes, double* h_out, void* stream);
 
+/* The form obe_bayes_update_model_moments() and its enqueue variant take on the calling thread: on = 1 — both
+ * passes in ONE launch (a grid barrier between the likelihood pass and the normalisation; every thread keeps its
+ * particles and their unnormalised weights in registers, so the cloud is read once: 8 (D + 1) N bytes read + 8 N
+ * written instead of twice that) wherever it applies (an arrival counter for the stream, at most 6 particles per
+ * thread of the 768-workgroup grid, i.e. N <= 1 179 648, n_params = the model's own parameters or one more, a
+ * co-resident grid, and the first-moment passes on the update's grid: OBE_FIRST_MOM_PER_CU=3), the two launches
+ * otherwise; on = 0 — always two launches.  The results are the same bits either way.  Returns the previous
+ * setting; on = -1 changes nothing and returns what the thread's last fused update did (1: one launch, 2: two). */
+int obe_update_one_pass(int32_t on);
+
 /* The same update, enqueued only: returns without waiting.  h_pinned_out (page-locked, 5 + 4 n_params
  * doubles) is armed here and written by the update's last kernel: [0] sum t, [1] sum w'^2, [2..) the K3
  * first-moment block, and [4 + 4 n_params] = 1.0 if auto_resample != 0 and the resample test of

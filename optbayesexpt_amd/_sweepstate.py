@@ -51,10 +51,11 @@ class Ticket:
 
 
 class SweepState:
-    def __init__(self, io, kappa_enter, kappa_leave, safe_streak, safe_retry):
+    def __init__(self, io, limits):
+        """``limits``: anything with KAPPA_ENTER, KAPPA_LEAVE, SAFE_STREAK, SAFE_RETRY (the owning object: read
+        when used, so that assigning one of them on an object — they are class attributes — takes effect)."""
         self.io = io
-        self.kappa_enter, self.kappa_leave = kappa_enter, kappa_leave
-        self.safe_streak_limit, self.safe_retry = safe_streak, safe_retry
+        self.limits = limits
         # form
         self.safe_streak = 0          # consecutive sweeps that had to be repeated with the twin
         self.safe_run = 0             # sweeps since the fast form was last tried (while pinned)
@@ -72,16 +73,16 @@ class SweepState:
     # ------------------------------------------------------------------ form of the sweep kernel
     @property
     def form(self):
-        return Form.FAST if self.safe_streak < self.safe_streak_limit else Form.SAFE
+        return Form.FAST if self.safe_streak < self.limits.SAFE_STREAK else Form.SAFE
 
     def form_for_next_sweep(self):
         """Called once per (non-speculative) sweep.  While pinned to the twin, every ``safe_retry``-th sweep
         probes the fast form once more (a posterior that has narrowed may be back in range; a failure pins
         it again at once)."""
-        if self.safe_streak >= self.safe_streak_limit:
+        if self.safe_streak >= self.limits.SAFE_STREAK:
             self.safe_run += 1
-            if self.safe_run >= self.safe_retry:
-                self.safe_streak, self.safe_run = self.safe_streak_limit - 1, 0
+            if self.safe_run >= self.limits.SAFE_RETRY:
+                self.safe_streak, self.safe_run = self.limits.SAFE_STREAK - 1, 0
         return self.form
 
     def fast_form_left_its_range(self):
@@ -94,9 +95,9 @@ class SweepState:
         """A model's host-side prediction for a new cloud: False pins the twin without a poisoned attempt,
         True releases a pin for one fast attempt, None says nothing."""
         if in_range is False:
-            self.safe_streak, self.safe_run = self.safe_streak_limit, 0
-        elif in_range is True and self.safe_streak >= self.safe_streak_limit:
-            self.safe_streak = self.safe_streak_limit - 1
+            self.safe_streak, self.safe_run = self.limits.SAFE_STREAK, 0
+        elif in_range is True and self.safe_streak >= self.limits.SAFE_STREAK:
+            self.safe_streak = self.limits.SAFE_STREAK - 1
 
     # ------------------------------------------------------------------ variance shift
     def shifted_for_next_sweep(self, mode, full):
@@ -109,9 +110,9 @@ class SweepState:
         if not (full and mode == "auto"):
             return False
         if shifted:
-            self.unshifted = bool(kappa < self.kappa_enter)
+            self.unshifted = bool(kappa < self.limits.KAPPA_ENTER)
             return False
-        if not kappa <= self.kappa_leave:
+        if not kappa <= self.limits.KAPPA_LEAVE:
             self.unshifted = False
             return True
         return False

@@ -218,10 +218,28 @@ int moments_call(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_
 // (tools/measure_update.py, D = 3, 16.8 M particles: 4.0 TB/s with 256 workgroups, 4.8 with 768; D = 10 is
 // as fast with 256), so narrow clouds get up to three per CU.  kMomGridCap bounds it for the workspace.
 constexpr int kMomGridCap = 3 * kMomBlocks;
+#ifndef OBE_FIRST_MOM_PER_CU_DEFAULT
+#define OBE_FIRST_MOM_PER_CU_DEFAULT 0
+#endif
 static_assert(kMomGridCap <= 1024, "obe_workspace_bytes sizes the moment partials for at most 1024 workgroups");
 inline int moment_blocks(int64_t n, int d) {
     static const int forced = getenv("OBE_MOM_PER_CU") ? atoi(getenv("OBE_MOM_PER_CU")) : 0;     // tuning aid (1..3)
     const int per_cu = forced >= 1 && forced <= 3 ? forced : (n < ((int64_t)1 << 21) ? 1 : (d <= 4 ? 3 : (d <= 7 ? 2 : 1)));
+    return static_cast<int>(std::min<int64_t>((int64_t)per_cu * kMomBlocks, (n + kBlock - 1) / kBlock));
+}
+
+// Grid of the passes that accumulate FIRST moments (moments_pass1, the update's normalisation pass, the
+// constraint mask's second half): all three share one grid so that whichever fills the K3 block leaves the
+// same bits.  Default: that of the covariance pass above.  OBE_FIRST_MOM_PER_CU=3 makes it the grid of the
+// update's likelihood pass (768 workgroups) — what the one-launch update needs (obe_update.hip), since its
+// threads keep their particles in registers from the likelihood to the moments.
+inline int first_moment_blocks(int64_t n, int d) {
+    static const int per_cu = [] {
+        const char* e = getenv("OBE_FIRST_MOM_PER_CU");
+        const int v = e ? atoi(e) : OBE_FIRST_MOM_PER_CU_DEFAULT;
+        return v >= 1 && v <= 3 ? v : 0;
+    }();
+    if (per_cu == 0) return moment_blocks(n, d);
     return static_cast<int>(std::min<int64_t>((int64_t)per_cu * kMomBlocks, (n + kBlock - 1) / kBlock));
 }
 

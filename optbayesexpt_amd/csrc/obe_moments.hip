@@ -112,9 +112,10 @@ static int launch_moments(const double* x, int64_t ld, int64_t n, const double* 
                           const MomentsOut& mo, hipStream_t st) {
     const int nb = moment_blocks(n, D);
     if (want_cov != 2) {            // (2: `out` already holds the first moments of these weights)
-        moments_pass1<D><<<nb, kBlock, 0, st>>>(x, ld, n, w, partials);
+        const int nb1 = first_moment_blocks(n, D);
+        moments_pass1<D><<<nb1, kBlock, 0, st>>>(x, ld, n, w, partials);
         OBE_CHECK_LAUNCH("moments_pass1");
-        fold_derive_pass1<<<1, kFoldThreads, 0, st>>>(partials, nb, D, mo);
+        fold_derive_pass1<<<1, kFoldThreads, 0, st>>>(partials, nb1, D, mo);
         OBE_CHECK_LAUNCH("fold_derive_pass1");
     }
     if (want_cov) {

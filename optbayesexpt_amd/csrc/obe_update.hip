@@ -21,6 +21,10 @@
 #include "obe_models.h"
 #include "obe_moments.h"
 
+#ifndef OBE_UPDATE_ONE_PASS_DEFAULT
+#define OBE_UPDATE_ONE_PASS_DEFAULT 0
+#endif
+
 namespace obe {
 
 struct LikArgs {
@@ -192,6 +196,41 @@ struct UpdateFold {
     int auto_resample;
 };
 
+// The tail of a launch that normalises and accumulates first moments: every workgroup publishes its row of
+// partial sums (v[2 + 2 D] = sum w'^2 rides along), the one that arrives last folds all rows in a fixed order
+// and delivers {sum t, sum w'^2}, the K3 block and (enqueue form) the resample decision.  One definition for
+// the two-launch and the one-launch update: the same bits.
+template <int D>
+__device__ __forceinline__ void publish_and_fold_update(double (&v)[3 + 2 * D], double total, double* partials_mom,
+                                                        const UpdateFold& fold) {
+    constexpr int NV = 3 + 2 * D;
+    store_block_partials<NV, true>(v, partials_mom);
+    __shared__ int last;
+    if (!arrive_last<false>(fold.counter, &last)) return;
+    __shared__ double raw[kMaxMomentValues + 1];
+    fold_values_block<kBlock, true>(partials_mom, gridDim.x, NV, raw);
+    // delivery by ONE wave: K3 block to the device copy and to the host, one system-scope fence, then the
+    // word the host watches (wait_host_word) — [0] sum t, [1] sum w'^2, [2..) K3 block
+    if (threadIdx.x < kWave) {
+        derive_first_moments(raw, D, fold.mom_out, fold.host_out ? fold.host_out + 2 : nullptr);
+        const double b = raw[NV - 1];
+        if (threadIdx.x == 0) {
+            fold.scalars[0] = total;
+            fold.scalars[1] = b;
+            if (fold.host_out) fold.host_out[0] = total;
+            if (fold.abort_out) {
+                const bool due = fold.auto_resample && resample_due(b, fold.n_particles, fold.threshold);
+                *fold.abort_out = due ? 1u : 0u;
+                if (fold.host_out) fold.host_out[4 + 4 * D] = due ? 1.0 : 0.0;
+            }
+        }
+        if (fold.host_out) {
+            host_results_before_flag();
+            if (threadIdx.x == 0) fold.host_out[1] = b;
+        }
+    }
+}
+
 template <int D, bool FOLD>
 __global__ __launch_bounds__(kBlock) void normalize_moments_kernel(const double* __restrict__ partials_in,
                                                                    int n_partials, const double* __restrict__ x,
@@ -221,32 +260,95 @@ __global__ __launch_bounds__(kBlock) void normalize_moments_kernel(const double*
         store_block_partials<NV>(v, partials_mom);
     } else {
         v[NV - 1] = acc;
-        store_block_partials<NV, true>(v, partials_mom);
-        __shared__ int last;
-        if (!arrive_last<false>(fold.counter, &last)) return;
-        __shared__ double raw[kMaxMomentValues + 1];
-        fold_values_block<kBlock, true>(partials_mom, gridDim.x, NV, raw);
-        // delivery by ONE wave: K3 block to the device copy and to the host, one system-scope fence, then the
-        // word the host watches (wait_host_word) — [0] sum t, [1] sum w'^2, [2..) K3 block
-        if (threadIdx.x < kWave) {
-            derive_first_moments(raw, D, fold.mom_out, fold.host_out ? fold.host_out + 2 : nullptr);
-            const double b = raw[NV - 1];
-            if (threadIdx.x == 0) {
-                fold.scalars[0] = total;
-                fold.scalars[1] = b;
-                if (fold.host_out) fold.host_out[0] = total;
-                if (fold.abort_out) {
-                    const bool due = fold.auto_resample && resample_due(b, fold.n_particles, fold.threshold);
-                    *fold.abort_out = due ? 1u : 0u;
-                    if (fold.host_out) fold.host_out[4 + 4 * D] = due ? 1.0 : 0.0;
-                }
-            }
-            if (fold.host_out) {
-                host_results_before_flag();
-                if (threadIdx.x == 0) fold.host_out[1] = b;
-            }
+        publish_and_fold_update<D>(reinterpret_cast<double(&)[3 + 2 * D]>(v), total, partials_mom, fold);
+    }
+}
+
+// ---- both passes in ONE launch (round 5) ------------------------------------------------------------------
+// A grid barrier between the likelihood pass and the normalisation: every workgroup of a launch that is known
+// to be co-resident (the host checks the occupancy before it chooses this form) takes a two-level arrival
+// ticket (arrive_last's counters, which wrap back to zero) and then waits for the last arrival to bump a
+// generation word next to the top counter.  The word is read BEFORE the ticket is taken, so a workgroup
+// can never miss its own barrier's bump.
+constexpr int kGenerationWord = kArriveStride * kArriveGroups + 16;
+__device__ __forceinline__ void grid_barrier(unsigned* counter, int* flag) {
+    unsigned* gen_word = counter + kGenerationWord;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this workgroup's published partials have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned gen = __hip_atomic_load(gen_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned g = blockIdx.x & (kArriveGroups - 1);
+        const unsigned in_group = (gridDim.x - g + kArriveGroups - 1) / kArriveGroups;
+        const unsigned groups = gridDim.x < (unsigned)kArriveGroups ? gridDim.x : (unsigned)kArriveGroups;
+        int last = atomicInc(counter + g * kArriveStride, in_group - 1) == in_group - 1;
+        if (last) last = atomicInc(counter + kArriveGroups * kArriveStride, groups - 1) == groups - 1;
+        if (last) {
+            __hip_atomic_store(gen_word, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            while (__hip_atomic_load(gen_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen)
+                __builtin_amdgcn_s_sleep(2);
+        }
+        *flag = last;
+    }
+    __syncthreads();
+}
+
+// update_model_kernel + normalize_moments_kernel<D, true> in one launch: a thread keeps its <= PPT particles
+// (D rows each) and their t = nan_to_num(w L) in registers across the grid barrier, so the cloud is read once
+// and t never travels: 8 (D + 1) N bytes read + 8 N written instead of twice that.  Same grid for both halves
+// (the update's: first_moment_blocks() must agree — the host checks), same per-thread order of accumulation,
+// same block reductions, same folds: the weights and the K3 block are the two-launch form's, bit for bit.
+template <class M, int D, int PPT>
+__global__ __launch_bounds__(kBlock) void update_moments_onepass_kernel(
+    obe_model m, SettingArg st, LikArgs la, const double* __restrict__ particles, int64_t ld, int64_t n,
+    double* __restrict__ weights, double* partials_t, double* partials_mom, UpdateFold fold) {
+    __shared__ double red[kBlock / kWave];
+    __shared__ int flag;
+    double x[PPT][D], t[PPT];
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const int64_t p0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int64_t p = p0 + j * stride;
+        t[j] = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) x[j][i] = 0.0;
+        if (p < n) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) x[j][i] = particles[(int64_t)i * ld + p];
+            double y[M::NC];
+            M::eval(st.x, ParamRef{&x[j][0], 1}, m, y);
+            const double tt = nan_to_num(weights[p] * likelihood_of(y, la, particles, ld, p));
+            t[j] = tt;
+            acc += tt;
         }
     }
+    const double s = block_sum(acc, red);
+    if (threadIdx.x == 0) store_published(partials_t + blockIdx.x, s);
+    grid_barrier(fold.counter, &flag);
+    // the total, folded by every workgroup in block_sum_array's order (the partials were stored write-through
+    // by other workgroups of this launch: read past this CU's L1)
+    double tv = 0.0;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += kBlock) tv += load_published_f64(partials_t + i);
+    const double total = block_sum_all(tv, red);
+    constexpr int NV = 3 + 2 * D;
+    double v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = 0.0;
+    double acc2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int64_t p = p0 + j * stride;
+        if (p < n) {
+            const double w = nan_to_num(t[j] / total);
+            weights[p] = w;
+            acc2 += nan_to_num(w * w);
+            accumulate_first_moments<D>(reinterpret_cast<double(&)[2 + 2 * D]>(v), w, x[j]);
+        }
+    }
+    v[NV - 1] = acc2;
+    publish_and_fold_update<D>(v, total, partials_mom, fold);
 }
 
 // ... and its fold: {sum t, sum w'^2} + the K3 block (mean, m1, m2, std), to the device copies and,
@@ -564,6 +666,48 @@ static int update_blocks(int64_t n) {
     return nb > cap ? cap : nb;
 }
 
+// which form the calling thread's fused updates take (obe_update_one_pass); default from OBE_UPDATE_ONE_PASS
+static thread_local int g_update_one_pass = -1;
+static thread_local int g_last_update_form = 0;      // 1: one launch, 2: two launches (diagnostic: obe_update_one_pass(-1))
+static bool update_one_pass() {
+    if (g_update_one_pass < 0) {
+        static const int def = getenv("OBE_UPDATE_ONE_PASS") ? atoi(getenv("OBE_UPDATE_ONE_PASS")) != 0 : OBE_UPDATE_ONE_PASS_DEFAULT;
+        g_update_one_pass = def;
+    }
+    return g_update_one_pass != 0;
+}
+
+// 0: launched; 1: does not apply here (the caller takes the two launches); else an error code
+template <class M, int D>
+static int try_onepass(const obe_model& mm, const SettingArg& sa, const LikArgs& la, const double* d_particles,
+                       int64_t ld_p, int64_t n, double* d_weights, const UpdateWs& w, int nb, const UpdateFold& fold,
+                       hipStream_t st) {
+    const int64_t per_thread = (n + (int64_t)nb * kBlock - 1) / ((int64_t)nb * kBlock);
+    auto launch = [&](auto ppt_tag) -> int {
+        constexpr int PPT = decltype(ppt_tag)::value;
+        static int resident = -1;            // workgroups of this kernel the device holds at once
+        if (resident < 0) {
+            int per_cu = 0, dev = 0, n_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, update_moments_onepass_kernel<M, D, PPT>, kBlock, 0) != hipSuccess ||
+                hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+                (void)hipGetLastError();
+                resident = 0;
+            } else {
+                resident = per_cu * n_cu;
+            }
+        }
+        if (resident < nb) return 1;          // the grid barrier needs every workgroup on the chip at once
+        update_moments_onepass_kernel<M, D, PPT><<<nb, kBlock, 0, st>>>(mm, sa, la, d_particles, ld_p, n, d_weights,
+                                                                        w.pa, w.mom, fold);
+        OBE_CHECK_LAUNCH("update_moments_onepass_kernel");
+        return 0;
+    };
+    if (per_thread <= 3) return launch(std::integral_constant<int, 3>{});
+    if (per_thread <= 6) return launch(std::integral_constant<int, 6>{});
+    return 1;
+}
+
 static int finish_update(const UpdateWs& w, int nb, int64_t n, double* d_weights, double* h_out, hipStream_t st) {
     normalize_kernel<<<nb, kBlock, 0, st>>>(w.pa, nb, n, d_weights, w.pb, nullptr);
     OBE_CHECK_LAUNCH("normalize_kernel");
@@ -636,6 +780,33 @@ static int update_model_moments(const obe_model* m, const double* d_particles, i
     if (enqueue_only && !counter) return bad_arg("obe_bayes_update_model_moments_enqueue: no control words for this stream");
     if (enqueue_only && ws_bytes < update_ws_bytes(d) + 16)
         return bad_arg("obe_bayes_update_model_moments_enqueue: the workspace needs 16 spare bytes at its end (OBE_WS_ABORT_WORD)");
+    const int nm = first_moment_blocks(n_particles, d);
+    if (hv) arm_host_words(h_out, n_words);      // every word of the result block is watched
+    const UpdateFold fold{counter, w.scalars, d_moments, hv, enqueue_only ? ws_abort_word(d_ws, ws_bytes) : nullptr,
+                          (double)n_particles, resample_threshold, auto_resample};
+    // One launch for both passes (obe_update_one_pass(1) / OBE_UPDATE_ONE_PASS=1) where it applies: an arrival
+    // counter for the stream, one grid for the likelihood pass and the first moments, a cloud whose threads hold
+    // at most 6 particles each, D = the model's own parameters (+ 1 noise row), and a grid that is co-resident.
+    // Anything else: the two launches below, which give the same bits.
+    bool launched = false;
+    if (update_one_pass() && counter && nm == nb) {
+        const int rc1 = dispatch_model(mm, [&](auto M) -> int {
+            using Model = decltype(M);
+            if (d == Model::NREAD)
+                return try_onepass<Model, Model::NREAD>(mm, sa, la, d_particles, ld_p, n_particles, d_weights, w, nb, fold, st);
+            if constexpr (Model::NREAD + 1 <= OBE_MAX_DIMS) {
+                if (d == Model::NREAD + 1)
+                    return try_onepass<Model, Model::NREAD + 1>(mm, sa, la, d_particles, ld_p, n_particles, d_weights, w,
+                                                                 nb, fold, st);
+            }
+            return 1;
+        });
+        if (rc1 != 0 && rc1 != 1) return rc1;
+        launched = rc1 == 0;
+    }
+    g_last_update_form = launched ? 1 : 2;
+    if (launched) goto delivered;
+    {
     int rc = dispatch_model(mm, [&](auto M) -> int {
         using Model = decltype(M);
         update_model_kernel<Model><<<nb, kBlock, 0, st>>>(mm, sa, la, d_particles, ld_p, n_particles, d_weights, w.pa,
@@ -644,10 +815,7 @@ static int update_model_moments(const obe_model* m, const double* d_particles, i
         return 0;
     });
     if (rc) return rc;
-    const int nm = moment_blocks(n_particles, d);
-    if (hv) arm_host_words(h_out, n_words);      // every word of the result block is watched
-    const UpdateFold fold{counter, w.scalars, d_moments, hv, enqueue_only ? ws_abort_word(d_ws, ws_bytes) : nullptr,
-                          (double)n_particles, resample_threshold, auto_resample};
+    }
 #define OBE_UPD_MOM_CASE(DD)                                                                                           \
     case DD:                                                                                                           \
         if (counter)                                                                                                   \
@@ -669,6 +837,7 @@ static int update_model_moments(const obe_model* m, const double* d_particles, i
         fold_update_moments_kernel<<<1, kFoldThreads, 0, st>>>(w.pa, nb, w.pb, nm, w.mom, d, w.scalars, d_moments, hv);
         OBE_CHECK_LAUNCH("fold_update_moments_kernel");
     }
+delivered:
     if (enqueue_only) return 0;
     if (h_out) {
         if (hv) return wait_host_words(h_out, n_words, st);
@@ -680,6 +849,13 @@ static int update_model_moments(const obe_model* m, const double* d_particles, i
         OBE_HIP_TRY(hipStreamSynchronize(st));
     }
     return 0;
+}
+
+int obe_update_one_pass(int32_t on) {
+    const int prev = update_one_pass() ? 1 : 0;
+    if (on < 0) return g_last_update_form;        // what the calling thread's last fused update actually did
+    g_update_one_pass = on != 0;
+    return prev;
 }
 
 int obe_bayes_update_model_moments(const obe_model* m, const double* d_particles, int64_t ld_p, int64_t n_particles,
@@ -907,7 +1083,7 @@ int obe_mask_nonpositive_moments(const double* d_particles, int64_t ld_p, int32_
     if (hc) arm_host_word(h_changed);
     if (hm) arm_host_words(h_moments, 2 + 4 * (int64_t)n_dims);
     const MaskFold mf{counter, d_moments, hm, hc};
-    const int nm = moment_blocks(n_particles, n_dims);
+    const int nm = first_moment_blocks(n_particles, n_dims);
 #define OBE_MASK_MOM_CASE(DD)                                                                                       \
     case DD:                                                                                                        \
         mask_renorm_moments_kernel<DD><<<nm, kBlock, 0, st>>>(w.pa, w.pb, nb, d_particles, ld_p, n_particles,      \

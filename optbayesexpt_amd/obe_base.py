@@ -207,7 +207,7 @@ class OptBayesExpt(ParticlePDF):
         self._rec_s = self._hargs.keep(np.ones(_lib.OBE_MAX_CHANNELS))
         self._hargs.keep(self._host_out)
         # which form / shift the next sweep uses, and the sweep pdf_update() enqueues ahead (_sweepstate.py)
-        self._sweeps = SweepState(_SweepIO(self), self.KAPPA_ENTER, self.KAPPA_LEAVE, self.SAFE_STREAK, self.SAFE_RETRY)
+        self._sweeps = SweepState(_SweepIO(self), self)
         if settings_shard is not None:
             self._s_begin, self._s_end = settings_shard.bounds(self._n_settings)
         else:

@@ -412,7 +412,8 @@ class _FakeIO:
 
 
 def _state(ss, io):
-    return ss.SweepState(io, kappa_enter=1000.0, kappa_leave=3000.0, safe_streak=3, safe_retry=64)
+    import types
+    return ss.SweepState(io, types.SimpleNamespace(KAPPA_ENTER=1000.0, KAPPA_LEAVE=3000.0, SAFE_STREAK=3, SAFE_RETRY=64))
 
 
 def _inputs(cloud=(1, 1), shifted=True, noise="n", settings=(0, 100), alias=True, cost_hook=False):
