@@ -149,7 +149,9 @@ int obe_bayes_update_model_moments(const obe_model* m,
                                    int32_t n_lik_channels, double choke, double* d_moments,
                                    void* d_ws, int64_t ws_bytes, double* h_out, void* stream);
 
-/* The form obe_bayes_update_model_moments() and its enqueue variant take on the calling thread: on = 1 — both
+/* (Libraries built with -DOBE_ONE_PASS_UPDATE only — a measured alternative that is not in the product build,
+ * where this switch is accepted and changes nothing: csrc/obe_update.hip, profiles/r05_update_moments.txt.)
+ * The form obe_bayes_update_model_moments() and its enqueue variant take on the calling thread: on = 1 — both
  * passes in ONE launch (a grid barrier between the likelihood pass and the normalisation; every thread keeps its
  * particles and their unnormalised weights in registers, so the cloud is read once: 8 (D + 1) N bytes read + 8 N
  * written instead of twice that) wherever it applies (an arrival counter for the stream, at most 6 particles per

@@ -264,7 +264,18 @@ __global__ __launch_bounds__(kBlock) void normalize_moments_kernel(const double*
     }
 }
 
-// ---- both passes in ONE launch (round 5) ------------------------------------------------------------------
+// ---- both passes in ONE launch (round 5: built, measured, NOT in the product build) ----------------------------
+// -DOBE_ONE_PASS_UPDATE compiles it in (tools/build_variant.py onepass -DOBE_ONE_PASS_UPDATE, then
+// OBE_VARIANT=onepass OBE_FIRST_MOM_PER_CU=3 python tools/measure_onepass.py).  Measured on MI355X
+// (profiles/r05_update_moments.txt): bit-identical to the two launches, and no faster — 1 048 576 particles,
+// D = 3: 24.2-24.5 us against 22.1 us (25.1 us with the first moments on the 768-workgroup grid this form
+// needs); 524 288 particles, D = 10: 39.2 us against ~33 us.  Half the bytes move, but the two launches are
+// already bandwidth-bound halves that overlap arithmetic with streaming, while here the latencies line up one
+// behind the other: all loads (2 us), six particles' likelihoods per thread (~170 dependent FP64 instructions
+// each for NumPy-identical divisions and exp: ~5 us), a grid barrier of two device-scope tickets plus the
+// release word across 8 XCDs (~5 us: a launch of 20 workgroups takes 10.2 us against 9.5 us for the two
+// launches), the normalisation, and the same ticket + fold tail as before.  The bar was 18 us.
+#ifdef OBE_ONE_PASS_UPDATE
 // A grid barrier between the likelihood pass and the normalisation: every workgroup of a launch that is known
 // to be co-resident (the host checks the occupancy before it chooses this form) takes a two-level arrival
 // ticket (arrive_last's counters, which wrap back to zero) and then waits for the last arrival to bump a
@@ -308,18 +319,24 @@ __global__ __launch_bounds__(kBlock) void update_moments_onepass_kernel(
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     const int64_t p0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     double acc = 0.0;
+    // every load of the thread's particles is issued before the first likelihood is evaluated (PPT (D + 1)
+    // loads in flight per lane: the ~170 dependent FP64 instructions of one particle no longer sit between
+    // two round trips to HBM); slots past the end of the cloud re-read the last particle and are not used
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
         const int64_t p = p0 + j * stride;
-        t[j] = 0.0;
+        const int64_t q = p < n ? p : n - 1;
 #pragma unroll
-        for (int i = 0; i < D; ++i) x[j][i] = 0.0;
+        for (int i = 0; i < D; ++i) x[j][i] = particles[(int64_t)i * ld + q];
+        t[j] = weights[q];
+    }
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int64_t p = p0 + j * stride;
         if (p < n) {
-#pragma unroll
-            for (int i = 0; i < D; ++i) x[j][i] = particles[(int64_t)i * ld + p];
             double y[M::NC];
             M::eval(st.x, ParamRef{&x[j][0], 1}, m, y);
-            const double tt = nan_to_num(weights[p] * likelihood_of(y, la, particles, ld, p));
+            const double tt = nan_to_num(t[j] * likelihood_of(y, la, particles, ld, p));
             t[j] = tt;
             acc += tt;
         }
@@ -350,6 +367,8 @@ __global__ __launch_bounds__(kBlock) void update_moments_onepass_kernel(
     v[NV - 1] = acc2;
     publish_and_fold_update<D>(v, total, partials_mom, fold);
 }
+
+#endif  // OBE_ONE_PASS_UPDATE
 
 // ... and its fold: {sum t, sum w'^2} + the K3 block (mean, m1, m2, std), to the device copies and,
 // when the caller's h_out is page-locked, straight to the host: [0] sum t, [1] sum w'^2, [2..) K3 block
@@ -677,6 +696,7 @@ static bool update_one_pass() {
     return g_update_one_pass != 0;
 }
 
+#ifdef OBE_ONE_PASS_UPDATE
 // 0: launched; 1: does not apply here (the caller takes the two launches); else an error code
 template <class M, int D>
 static int try_onepass(const obe_model& mm, const SettingArg& sa, const LikArgs& la, const double* d_particles,
@@ -707,6 +727,8 @@ static int try_onepass(const obe_model& mm, const SettingArg& sa, const LikArgs&
     if (per_thread <= 6) return launch(std::integral_constant<int, 6>{});
     return 1;
 }
+
+#endif  // OBE_ONE_PASS_UPDATE
 
 static int finish_update(const UpdateWs& w, int nb, int64_t n, double* d_weights, double* h_out, hipStream_t st) {
     normalize_kernel<<<nb, kBlock, 0, st>>>(w.pa, nb, n, d_weights, w.pb, nullptr);
@@ -789,6 +811,7 @@ static int update_model_moments(const obe_model* m, const double* d_particles, i
     // at most 6 particles each, D = the model's own parameters (+ 1 noise row), and a grid that is co-resident.
     // Anything else: the two launches below, which give the same bits.
     bool launched = false;
+#ifdef OBE_ONE_PASS_UPDATE
     if (update_one_pass() && counter && nm == nb) {
         const int rc1 = dispatch_model(mm, [&](auto M) -> int {
             using Model = decltype(M);
@@ -804,6 +827,7 @@ static int update_model_moments(const obe_model* m, const double* d_particles, i
         if (rc1 != 0 && rc1 != 1) return rc1;
         launched = rc1 == 0;
     }
+#endif
     g_last_update_form = launched ? 1 : 2;
     if (launched) goto delivered;
     {

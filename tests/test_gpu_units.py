@@ -1205,9 +1205,12 @@ def test_lorentzian_peaks_far_narrower_than_the_grid(obe, k, ratio):
             got = o.yvar_from_parameter_draws()
             # K >= 3: the combined fraction of a lane's settings is range-checked at 1e250; K < 3: the product of
             # two particles' denominators overflows at ~1.8e308 (the hint pins the SAFE form from 1e245 on)
+            # (the hint pins the SAFE form from 1e245 on)
             decades = (k if k >= 3 else 2) * spt * np.log10(1 + ratio ** 2)
-            assert not 245 <= decades <= 309, "choose a ratio outside the grey zone"
-            leaves = (k >= 3 or spt >= 2) and decades > 250
+            batched = k >= 3 or spt >= 2
+            limit = 250 if k >= 3 else 308.5
+            leaves = batched and decades > (245 if hinted else limit)
+            assert not (batched and 245 <= decades <= limit and not hinted), "choose a ratio outside the grey zone"
             assert o.last_sweep["safe"] == bool(leaves), (k, ratio, ns, hinted, o.last_sweep, o.sweep_state())
             if leaves:      # found out by a poisoned attempt (streak 1), or predicted (pinned at once)
                 assert o._sweep_safe_streak == (o.SAFE_STREAK if hinted else 1)

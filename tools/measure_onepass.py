@@ -1,6 +1,7 @@
 """The fused update (K2 + first moments) in one launch against the two-launch form (developer aid, GPU):
 
-    OBE_FIRST_MOM_PER_CU=3 python tools/measure_onepass.py [D=3|10|4|11]
+    python tools/build_variant.py onepass -DOBE_ONE_PASS_UPDATE
+    OBE_VARIANT=onepass OBE_FIRST_MOM_PER_CU=3 python tools/measure_onepass.py [D=3|10|4|11]
 
 For several cloud sizes: (1) weights, the K3 block and the host block of both forms compared BIT FOR BIT
 (obe_update_one_pass(0 / 1) on the same inputs; obe_update_one_pass(-1) tells which form actually ran),
@@ -17,6 +18,9 @@ import torch                                          # noqa: E402
 from optbayesexpt_amd import _lib, models             # noqa: E402
 from optbayesexpt_amd.particlepdf import _ptr         # noqa: E402
 
+if os.environ.get("OBE_VARIANT"):
+    _lib._LIB = _lib.HipLib(os.path.join(ROOT, "tools", "_variants", f"libobe_hip_{os.environ['OBE_VARIANT']}.so"),
+                            allow_variant=True)
 lib = _lib.load()
 torch.cuda.set_device(0)
 d = int(sys.argv[1]) if len(sys.argv) > 1 else 3
