@@ -325,6 +325,38 @@ def collective_report(obe, shard, backend, world, rank, ns, steps, elapsed_local
                                     "all-gather + copy of the records to the host + stream synchronisation"}
 
 
+def warm_clocks(obe, at_least_ms=150.0):
+    """Untimed, before the warm-up steps: the sweep kernel of this object back to back for ~150 ms.  An MI355X that
+    has been idle (building the object takes the host a second) needs ~35 ms of sustained load before its clocks
+    reach their sustained level: K1 of one rank's c5 slice takes 1.24 ms in the first cycle and 1.04 ms from the
+    22nd on (profiles/r05_k1_per_cycle_c5_cold.txt).  Three warm-up steps of 1.4 ms do not get there, and a short
+    sharded run would be timed entirely inside the ramp while the 14 ms cycles of the one-GPU run are not — the
+    scaling ratio would compare a cold chip with a warm one.  A real experiment runs thousands of cycles."""
+    import torch
+    from optbayesexpt_amd import _lib
+    from optbayesexpt_amd.particlepdf import _ptr
+    if obe.utility_method != "variance_full" or obe._s_end <= obe._s_begin:
+        return 0.0
+    mom = obe._moments_on_device()
+    p, w = obe._pw_tensors()
+    s_ptr = ctypes.c_void_p(obe._settings_dev.data_ptr() + 8 * obe._s_begin)
+    ms = ctypes.c_float(0.0)
+
+    def run(iters):
+        obe._mlib.call("obe_sweep_kernel_time", obe._model_struct, s_ptr, obe._n_settings, obe._s_end - obe._s_begin,
+                       _ptr(p), p.shape[1], obe.n_particles, _ptr(w), _ptr(mom), _lib.OBE_SWEEP_SHIFTED, _ptr(obe._ws),
+                       obe._ws_bytes, iters, ctypes.byref(ms), obe._stream())
+        return ms.value
+    one = max(run(1), 1e-3)
+    total = 2.0 * one
+    left = at_least_ms - total
+    if left > 0:
+        iters = int(min(2000, max(1, round(left / one))))
+        total += iters * run(iters)
+    torch.cuda.synchronize()
+    return total
+
+
 def update_at_boundary(obe, record):
     """pdf_update() for the last cycle before a timed region starts or ends.  From the third cycle on,
     pdf_update() enqueues the NEXT cycle's sweep behind its update (obe_base.py: speculative sweep); a sweep
@@ -356,6 +388,7 @@ def other_config(cfg, steps, warmup):
     sim = np.random.default_rng(4321)
     fn = obe.model_function
     noise_rec = model == "lorentzian"
+    warm_clocks(obe, 50.0)             # (the chip is warm from the main run; building this object left it idle)
     step_ms, res = [], []
     full = obe.utility_method == "variance_full"
     # the cycles are timed WITHOUT the event pair around the sweep kernel (at these sizes the two event packets
@@ -496,6 +529,7 @@ def main():
         if use_dist:
             dist.barrier()
 
+    warmed_ms = warm_clocks(obe)          # (untimed; see warm_clocks: the chip's clocks, not the code's caches)
     # state for the benchmark: a few real updates (non-uniform weights), SURVEY §8(d)
     for k in range(max(args.warmup, 0)):
         one_step(boundary=k == args.warmup - 1)
@@ -672,6 +706,7 @@ def main():
                                   f"variance_approx (N_DRAWS = {obe.N_DRAWS} weighted draws, reference semantics)"),
                       "settings_per_rank": n_local, "sharding": f"settings axis / {world}",
                       "resamples_in_timed_steps": resamples,
+                      "clock_warm_up_ms_before_the_warmup_steps": warmed_ms,
                       "median_ms_plain_cycle": (float(np.median([m for m, r in zip(step_ms, step_resampled) if not r]))
                                                 if resamples < args.steps else None),
                       "median_ms_resample_cycle": (float(np.median([m for m, r in zip(step_ms, step_resampled) if r]))

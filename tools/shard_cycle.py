@@ -45,6 +45,8 @@ def run(cfg, shard, log, steps, warmup):
     sim = np.random.default_rng(4321)
     fn = obe.model_function
     noise_rec = bench.CONFIGS[cfg][2] == "lorentzian"
+    if not os.environ.get("OBE_NO_CLOCK_WARM_UP"):
+        bench.warm_clocks(obe)         # (as bench.py does: the chip's clocks ramp for ~35 ms after an idle second)
     times, res = [], []
     record = log is None
     if record:
