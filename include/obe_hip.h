@@ -304,6 +304,13 @@ int obe_resample_particles(const double* d_old, int64_t ld_old, int32_t n_dims, 
                            double a_param, int32_t scale,
                            double* d_new, int64_t ld_new, double* d_weights,
                            void* d_ws, int64_t ws_bytes, void* stream);
+/* The same with the (N, D) copy of the old cloud already made (obe_resample_begin's d_aos): no copy pass in
+ * front of the gather. */
+int obe_resample_particles_aos(const double* d_old_aos, int32_t n_dims, int64_t n_particles,
+                               const int64_t* d_idx, const double* d_normals,
+                               const double* h_factor, const double* h_mean,
+                               double a_param, int32_t scale,
+                               double* d_new, int64_t ld_new, double* d_weights, void* stream);
 
 /* resample(), the device side up to the host's factorisation of the covariance, enqueued by ONE call
  * (particlepdf.py:260-301; RNG order as there: N uniforms for rng.choice, then N x D normals): the caller's
@@ -317,13 +324,16 @@ int obe_resample_particles(const double* d_old, int64_t ld_old, int32_t n_dims, 
  *   h_f64[1..]   the K3 block: the covariance and, unless have_first_moments, the first moments — wait for
  *                the words h_f64 + 1 + lo .. h_f64 + 1 + obe_moments_len(D), lo = have_first ? 2 + 4 D : 0;
  *   h_i64[0..1]  {raw values the normals consumed, normals found}: wait for both, then obe_ziggurat_check().
- * Same kernels, same numbers as the calls one by one. */
+ * d_aos (nullable, 8 n_dims N bytes): receives the (N, D) copy of the PRE-resample cloud for
+ * obe_resample_particles_aos() — made here, while the host factorises, instead of in front of the gather; on
+ * large clouds the covariance and this copy then run as a third chain beside the CDF / search and the random
+ * numbers.  Same kernels, same numbers as the calls one by one. */
 int obe_resample_begin(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t n_particles,
                        const double* d_weights, const uint64_t* h_pcg_state4, int32_t strict_cdf,
                        int32_t cdf_is_fresh, int32_t have_first_moments, int64_t n_raw,
                        double* d_cdf, double* d_uniforms, int64_t* d_idx, const void* d_zig_tables,
                        double* d_normals, void* d_zig_ws, int64_t zig_ws_bytes, double* d_moments,
-                       double* h_f64, int64_t* h_i64, void* d_ws, int64_t ws_bytes, void* stream);
+                       double* h_f64, int64_t* h_i64, double* d_aos, void* d_ws, int64_t ws_bytes, void* stream);
 
 /* ---- K6: OptBayesExptNoiseParameter extras ----
  * enforce_parameter_constraints (obe_noiseparam.py:57-79): zero the weight of every
@@ -371,7 +381,11 @@ int obe_power_normalize(const double* d_u, int64_t n, double exponent, double* d
  * amplifies rounding — so the caller can choose the mode for the next sweep, or repeat
  * this one with shifted = 1 if an unshifted result came back with a large factor.
  * Then utility[s] = sum_c yvar[c,s] / noise_var[c(,s)] / cost[(s)]   (obe_base.py:650-655)
- * with d_noise_var (C) if noise_ld == 0 else (C, n_settings) rows noise_ld apart, and
+ * with d_noise_var (C) if noise_ld == 0, (C, n_settings) rows noise_ld apart if noise_ld > 0, and, if
+ * noise_ld = OBE_NOISE_FROM_MOMENTS(r0, r1, r2, r3) < 0, taken from the K3 block d_noise_var then points to
+ * (obe_moments layout for m->n_params parameters; normally d_moments itself): channel c's noise variance is
+ * that block's m2[r_c] / sum w — the weighted mean of sigma_c^2 of obe_noiseparam.py:122-136, the division
+ * obe_noise_var_from_moments() does, without a launch of its own — and
  * cost = cost_scalar if d_cost == NULL else d_cost[s]; and the first-maximum argmax
  * (np.argmax, obe_base.py:748): h_best[0] = value, h_best_idx[0] = index relative to
  * s_begin (sync) when h_best != NULL.  d_yvar (C, n_settings) and d_utility
@@ -381,6 +395,8 @@ int obe_power_normalize(const double* d_u, int64_t n, double exponent, double* d
  * {best value (f64), best local index (i64 bits), kappa (f64), 0} — what a sharded caller
  * all-gathers across ranks (RCCL) without copying it to the host first. */
 #define OBE_WS_RESULT_OFFSET 2
+#define OBE_NOISE_FROM_MOMENTS(r0, r1, r2, r3) \
+    (-(int64_t)1 - ((int64_t)(r0) | ((int64_t)(r1) << 5) | ((int64_t)(r2) << 10) | ((int64_t)(r3) << 15)))
 /* bits of the `shifted` argument of obe_sweep_utility / obe_sweep_kernel_time.  A plugin
  * model's fast sweep form batches its divisions without a branch and poisons (NaN) a batch
  * whose denominators leave the range in which that is exact; a NaN variance comes back as

@@ -157,9 +157,11 @@ bool side_stream_of(hipStream_t st, SideStream* out) {
     }
     SideStream s{};
     bool ok = t.of.size() < 256 && hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&s.stream2, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&s.entry, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&s.mid, hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&s.done, hipEventDisableTiming) == hipSuccess;
+         hipEventCreateWithFlags(&s.done, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&s.done2, hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         (void)hipGetLastError();
         s = SideStream{};                 // remembered: not tried again for this stream

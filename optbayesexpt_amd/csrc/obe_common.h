@@ -99,6 +99,8 @@ unsigned* stream_control_words(hipStream_t st);
 struct SideStream {
     hipStream_t stream;
     hipEvent_t entry, mid, done;
+    hipStream_t stream2;         // a third chain (round 5: the covariance + the (N, D) copy of a resample)
+    hipEvent_t done2;
 };
 bool side_stream_of(hipStream_t st, SideStream* out);      // obe_capi.hip
 

@@ -423,11 +423,22 @@ __global__ __launch_bounds__(kBlock) void resample_kernel(NudgeArgs na, const do
 }
 
 template <int D>
+static int launch_soa_to_aos(const double* d_old, int64_t ld_old, int64_t n, double* aos, hipStream_t st) {
+    soa_to_aos_kernel<D><<<stream_blocks(n, kBlock), kBlock, 0, st>>>(d_old, ld_old, n, aos);
+    OBE_CHECK_LAUNCH("soa_to_aos_kernel");
+    return 0;
+}
+
+// d_old == nullptr: d_ws already IS the (N, D) copy of the old cloud (obe_resample_particles_aos)
+template <int D>
 static int launch_resample(const NudgeArgs& na, const double* d_old, int64_t ld_old, int64_t n, const int64_t* d_idx,
                            const double* d_normals, double* d_new, int64_t ld_new, double* d_weights, void* d_ws,
                            int64_t ws_bytes, hipStream_t st) {
     const int blocks = stream_blocks(n, kBlock);
-    if (D >= 2 && n >= 65536 && d_ws && ws_bytes >= (int64_t)sizeof(double) * D * n) {
+    if (!d_old) {
+        resample_kernel<D, true><<<blocks, kBlock, 0, st>>>(na, static_cast<const double*>(d_ws), 0, n, d_idx, d_normals,
+                                                            d_new, ld_new, d_weights);
+    } else if (D >= 2 && n >= 65536 && d_ws && ws_bytes >= (int64_t)sizeof(double) * D * n) {
         double* aos = static_cast<double*>(d_ws);
         soa_to_aos_kernel<D><<<blocks, kBlock, 0, st>>>(d_old, ld_old, n, aos);
         OBE_CHECK_LAUNCH("soa_to_aos_kernel");
@@ -601,14 +612,36 @@ int obe_gather_columns(const double* d_particles, int64_t ld_p, int32_t n_dims, 
     return 0;
 }
 
+static int resample_particles(const double* d_old, int64_t ld_old, int32_t n_dims, int64_t n_particles,
+                              const int64_t* d_idx, const double* d_normals, const double* h_factor,
+                              const double* h_mean, double a_param, int32_t scale, double* d_new, int64_t ld_new,
+                              double* d_weights, void* d_ws, int64_t ws_bytes, void* stream);
+
 int obe_resample_particles(const double* d_old, int64_t ld_old, int32_t n_dims, int64_t n_particles,
                            const int64_t* d_idx, const double* d_normals, const double* h_factor,
                            const double* h_mean, double a_param, int32_t scale, double* d_new, int64_t ld_new,
                            double* d_weights, void* d_ws, int64_t ws_bytes, void* stream) {
-    if (!d_old || !d_idx || !d_normals || !h_factor || !h_mean || !d_new || !d_weights || n_particles <= 0)
+    if (!d_old) return bad_arg("obe_resample_particles: bad pointer/size");
+    if (d_old == d_new) return bad_arg("obe_resample_particles: in-place gather is not supported");
+    return resample_particles(d_old, ld_old, n_dims, n_particles, d_idx, d_normals, h_factor, h_mean, a_param, scale,
+                              d_new, ld_new, d_weights, d_ws, ws_bytes, stream);
+}
+
+int obe_resample_particles_aos(const double* d_old_aos, int32_t n_dims, int64_t n_particles, const int64_t* d_idx,
+                               const double* d_normals, const double* h_factor, const double* h_mean, double a_param,
+                               int32_t scale, double* d_new, int64_t ld_new, double* d_weights, void* stream) {
+    if (!d_old_aos || d_old_aos == d_new) return bad_arg("obe_resample_particles_aos: bad pointer");
+    return resample_particles(nullptr, 0, n_dims, n_particles, d_idx, d_normals, h_factor, h_mean, a_param, scale, d_new,
+                              ld_new, d_weights, const_cast<double*>(d_old_aos), 0, stream);
+}
+
+static int resample_particles(const double* d_old, int64_t ld_old, int32_t n_dims, int64_t n_particles,
+                              const int64_t* d_idx, const double* d_normals, const double* h_factor,
+                              const double* h_mean, double a_param, int32_t scale, double* d_new, int64_t ld_new,
+                              double* d_weights, void* d_ws, int64_t ws_bytes, void* stream) {
+    if (!d_idx || !d_normals || !h_factor || !h_mean || !d_new || !d_weights || n_particles <= 0)
         return bad_arg("obe_resample_particles: bad pointer/size");
     if (n_dims < 1 || n_dims > OBE_MAX_DIMS) return bad_arg("obe_resample_particles: n_dims must be 1..16");
-    if (d_old == d_new) return bad_arg("obe_resample_particles: in-place gather is not supported");
     NudgeArgs na{};
     na.d = n_dims;
     na.scale = scale;
@@ -649,7 +682,7 @@ int obe_resample_begin(const double* d_particles, int64_t ld_p, int32_t n_dims, 
                        int32_t cdf_is_fresh, int32_t have_first_moments, int64_t n_raw, double* d_cdf,
                        double* d_uniforms, int64_t* d_idx, const void* d_zig_tables, double* d_normals,
                        void* d_zig_ws, int64_t zig_ws_bytes, double* d_moments, double* h_f64, int64_t* h_i64,
-                       void* d_ws, int64_t ws_bytes, void* stream) {
+                       double* d_aos, void* d_ws, int64_t ws_bytes, void* stream) {
     if (!d_particles || !d_weights || !h_pcg_state4 || !d_cdf || !d_uniforms || !d_idx || !d_zig_tables ||
         !d_normals || !d_zig_ws || !d_moments || !h_f64 || !h_i64 || n_particles <= 0)
         return bad_arg("obe_resample_begin: bad pointer/size");
@@ -679,10 +712,42 @@ int obe_resample_begin(const double* d_particles, int64_t ld_p, int32_t n_dims, 
     void* rs = split ? static_cast<void*>(side.stream) : stream;
     const int64_t lo = have_first_moments ? 2 + 4 * (int64_t)n_dims : 0;
     auto ev = [](hipError_t e) { return e == hipSuccess ? 0 : fail(e, "obe_resample_begin: stream / event call"); };
+    // d_aos (nullable; 8 n_dims N bytes): the (N, D) copy of the PRE-resample cloud that the gather of
+    // obe_resample_particles_aos() reads, made here — it needs nothing but the old cloud, so it runs while the host
+    // factorises the covariance instead of in front of the gather (16.5 us at 524 288 x 10).  With it, split mode
+    // runs a THIRD chain on a second stream of the library's: the covariance (its partial sums in d_aos, which is
+    // written only afterwards — the caller's workspace belongs to the scan and the search, which now run beside
+    // it) and the copy.  The host then has the covariance ~20 us earlier, and the caller's stream is scan ->
+    // guide -> search only: the random chain (~85 us at that size) is what the gather waits for.
+    const int64_t nv_max = std::max<int64_t>(2 + 2 * n_dims, (int64_t)n_dims * (n_dims + 1) / 2);
+    const bool third = split && d_aos && n_dims >= 2 && side.stream2 &&
+                       (int64_t)n_dims * n >= (int64_t)kMomGridCap * nv_max + nv_max;
+    const bool copy_here = d_aos && n_dims >= 2;
+    auto make_aos = [&](hipStream_t on) -> int {
+#define OBE_AOS_CASE(DD) \
+    case DD: return launch_soa_to_aos<DD>(d_particles, ld_p, n, d_aos, on);
+        switch (n_dims) {
+            OBE_AOS_CASE(2) OBE_AOS_CASE(3) OBE_AOS_CASE(4) OBE_AOS_CASE(5) OBE_AOS_CASE(6) OBE_AOS_CASE(7) OBE_AOS_CASE(8)
+            OBE_AOS_CASE(9) OBE_AOS_CASE(10) OBE_AOS_CASE(11) OBE_AOS_CASE(12) OBE_AOS_CASE(13) OBE_AOS_CASE(14)
+            OBE_AOS_CASE(15) OBE_AOS_CASE(16)
+        }
+#undef OBE_AOS_CASE
+        return 0;
+    };
     do {
         // (split: the cloud's chain is enqueued first — the host waits for the covariance, and every launch costs
         // it a few microseconds; the kernels of the random chain arrive while the scan is already running)
         if (split && (rc = ev(hipEventRecord(side.entry, st)))) break;
+        if (third) {
+            if ((rc = ev(hipStreamWaitEvent(side.stream2, side.entry, 0)))) break;
+            arm_host_words(h_f64 + 1 + lo, obe_moments_len(n_dims) - lo);
+            bool host_written = false;
+            if ((rc = moments_call(d_particles, ld_p, n_dims, n, d_weights, have_first_moments ? 2 : 1, d_moments,
+                                   h_f64 + 1, d_aos, (int64_t)sizeof(double) * n_dims * n, side.stream2, &host_written)))
+                break;
+            if ((rc = make_aos(side.stream2))) break;
+            if ((rc = ev(hipEventRecord(side.done2, side.stream2)))) break;
+        }
         auto cdf_and_covariance = [&]() -> int {
             if (!cdf_is_fresh) {
                 arm_host_word(h_f64);
@@ -690,7 +755,7 @@ int obe_resample_begin(const double* d_particles, int64_t ld_p, int32_t n_dims, 
             } else {
                 h_f64[0] = 1.0;
             }
-            if (!split) return 0;       // (one stream: the round-3 order, covariance after the search)
+            if (!split || third) return 0;       // (one stream: the round-3 order, covariance after the search)
             arm_host_words(h_f64 + 1 + lo, obe_moments_len(n_dims) - lo);
             bool host_written = false;
             return moments_call(d_particles, ld_p, n_dims, n, d_weights, have_first_moments ? 2 : 1, d_moments, h_f64 + 1,
@@ -712,8 +777,10 @@ int obe_resample_begin(const double* d_particles, int64_t ld_p, int32_t n_dims, 
             break;
         }
         if ((rc = obe_cdf_search(d_cdf, n, d_uniforms, n, d_idx, d_ws, ws_bytes, stream))) break;
+        if (copy_here && !third && (rc = make_aos(st))) break;
         if (split) {
             if ((rc = ev(hipStreamWaitEvent(st, side.done, 0)))) break;
+            if (third && (rc = ev(hipStreamWaitEvent(st, side.done2, 0)))) break;
         } else {
             arm_host_words(h_f64 + 1 + lo, obe_moments_len(n_dims) - lo);
             bool host_written = false;

@@ -355,16 +355,38 @@ __global__ __launch_bounds__(kBlock) OBE_SWEEP_OCCUPANCY void sweep_kernel(Sweep
 
 struct UtilArgs {
     const double* noise_var;
-    int64_t noise_ld;     // 0: one value per channel
+    int64_t noise_ld;     // 0: one value per channel; > 0: (C, n_settings) rows this far apart; < 0: see make_util_args
     const double* cost;   // NULL: scalar
     double cost_scalar;
+    int mom_dims;         // noise_ld < 0: noise_var is a K3 block of this many parameters ...
+    int mom_rows[OBE_MAX_CHANNELS];   // ... and channel c's noise variance is its m2[row] / sum w
 };
+
+// noise_ld < 0 (OBE_NOISE_FROM_MOMENTS): the noise variance of channel c is np.average(sigma_c^2, weights=w)
+// (obe_noiseparam.py:122-136) = m2[row_c] / sum w of the K3 block d_noise_var points to — the division that
+// obe_noise_var_from_moments()'s kernel does, done by the kernel that needs the value: one launch (4-5 us between
+// the update and every sweep of a noise-parameter object) less, the same bits.
+static int make_util_args(UtilArgs& ua, const double* d_noise_var, int64_t noise_ld, const double* d_cost, double cost_scalar,
+                          int n_channels, int n_params) {
+    ua = UtilArgs{d_noise_var, noise_ld, d_cost, cost_scalar, 0, {0, 0, 0, 0}};
+    if (noise_ld >= 0) return 0;
+    const int64_t code = -noise_ld - 1;
+    ua.mom_dims = n_params;
+    for (int c = 0; c < OBE_MAX_CHANNELS; ++c) {
+        ua.mom_rows[c] = (int)((code >> (5 * c)) & 31);
+        if (c < n_channels && ua.mom_rows[c] >= n_params) return bad_arg("noise rows encoded in noise_ld: out of range");
+    }
+    if (n_params < 1 || n_params > OBE_MAX_DIMS) return bad_arg("noise_ld < 0 needs the number of parameters");
+    return 0;
+}
 
 __device__ __forceinline__ double utility_of(const double* var, int nc, int64_t s, const UtilArgs& u) {
     // np.sum(var_p / var_n, axis=0) / cost   (obe_base.py:654-655)
     double acc = 0.0;
     for (int c = 0; c < nc; ++c) {
-        const double nv = u.noise_ld ? u.noise_var[(int64_t)c * u.noise_ld + s] : u.noise_var[c];
+        const double nv = u.noise_ld > 0 ? u.noise_var[(int64_t)c * u.noise_ld + s]
+                          : (u.noise_ld == 0 ? u.noise_var[c]
+                                             : u.noise_var[2 + 2 * u.mom_dims + u.mom_rows[c]] / u.noise_var[0]);
         acc = acc + var[c] / nv;
     }
     return acc / (u.cost ? u.cost[s] : u.cost_scalar);
@@ -940,7 +962,8 @@ int obe_sweep_utility(const obe_model* m, const double* d_settings, int64_t ld_s
                                d_draw_idx, n_draws, d_moments, d_ws, ws_bytes, plan, a, w, &sweep_ws_need))
         return rc;
     hipStream_t st = as_stream(stream);
-    UtilArgs ua{d_noise_var, noise_ld, d_cost, cost_scalar};
+    UtilArgs ua;
+    if (int rc = make_util_args(ua, d_noise_var, noise_ld, d_cost, cost_scalar, mm.n_channels, mm.n_params)) return rc;
     const bool speculative = shifted & OBE_SWEEP_SPECULATIVE;
     const bool nowait = speculative || (shifted & OBE_SWEEP_NOWAIT);
     if (nowait) {
@@ -1129,7 +1152,9 @@ int obe_utility_argmax(const double* d_yvar, int32_t n_channels, int64_t n_setti
     SweepWs w;
     if (int rc = carve_sweep_ws(d_ws, ws_bytes, 0, 0, w)) return rc;
     hipStream_t st = as_stream(stream);
-    UtilArgs ua{d_noise_var, noise_ld, d_cost, cost_scalar};
+    if (noise_ld < 0) return bad_arg("obe_utility_argmax: noise_ld < 0 (noise variance from a K3 block) is for obe_sweep_utility");
+    UtilArgs ua;
+    if (int rc = make_util_args(ua, d_noise_var, noise_ld, d_cost, cost_scalar, n_channels, 0)) return rc;
     const int nb = stream_blocks(n_settings, kBlock);
     utility_kernel<<<nb, kBlock, 0, st>>>(d_yvar, n_channels, n_settings, ua, d_utility, w.bv, w.bi);
     OBE_CHECK_LAUNCH("utility_kernel");

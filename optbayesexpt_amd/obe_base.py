@@ -649,10 +649,11 @@ class OptBayesExpt(ParticlePDF):
         """Cost of a measurement per setting (obe_base.py:566-577)."""
         return 1.0
 
-    def _noise_var_device(self):
+    def _noise_var_device(self, values=False):
         """(tensor, ld): noise variance on the device — one value per channel (ld = 0)
         or, for an overriding yvar_noise_model() that returns per-setting values, a
-        (C, n_local) array (ld = n_local)."""
+        (C, n_local) array (ld = n_local).  (``values``: see the noise-parameter class, whose sweeps take the
+        variance straight from the moment block.)"""
         if not _overridden(self, "yvar_noise_model", OptBayesExpt) and self._noise_cache is not None:
             dns = self.default_noise_std
             if isinstance(dns, np.ndarray) and dns.tobytes() == self._noise_src:
@@ -909,7 +910,7 @@ class OptBayesExpt(ParticlePDF):
             n = self._n_settings
             yv = torch.from_numpy(np.array(np.broadcast_to(np.asarray(var_p, dtype=np.float64),
                                                            (self.n_channels, n)))).to(self._device)
-        noise, noise_ld = self._noise_var_device()
+        noise, noise_ld = self._noise_var_device(values=True)
         cost_t, cost_s = self._cost_device()
         util = torch.empty(max(n, 1), dtype=torch.float64, device=self._device)
         if n > 0:

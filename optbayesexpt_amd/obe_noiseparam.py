@@ -94,7 +94,7 @@ class OptBayesExptNoiseParameter(OptBayesExpt):
     # -- noise model: weighted mean of sigma^2 (obe_noiseparam.py:122-136) ------------
     def yvar_noise_model(self):
         """(C, 1) weighted mean of sigma^2, reduced on the device (K3 block)."""
-        t, _ = OptBayesExptNoiseParameter._noise_var_device(self)
+        t, _ = OptBayesExptNoiseParameter._noise_var_device(self, values=True)
         return t.cpu().numpy().reshape((self.n_channels, 1))
 
     def _noise_token(self):
@@ -104,11 +104,20 @@ class OptBayesExptNoiseParameter(OptBayesExpt):
             return None
         return "cloud"
 
-    def _noise_var_device(self):
+    def _noise_var_device(self, values=False):
+        """What a sweep takes as its noise variance: the K3 block itself with the noise rows encoded in the
+        leading dimension (include/obe_hip.h: OBE_NOISE_FROM_MOMENTS) — the kernel that forms the utility divides
+        m2[row] by sum w itself; ``values``: the C variances as a device vector (yvar_noise_model())."""
         if _overridden(self, "yvar_noise_model", OptBayesExptNoiseParameter):
             return OptBayesExpt._noise_var_device(self)
         if self._parameters is self._particles:
             mom = self._moments_on_device()
+            if not values and self._device_model is not None:
+                code = self.__dict__.get("_noise_ld_code")
+                if code is None:
+                    rows = [int(r) for r in self._noise_rows[:self.n_channels]] + [0] * 4
+                    code = self._noise_ld_code = -1 - (rows[0] | rows[1] << 5 | rows[2] << 10 | rows[3] << 15)
+                return mom, code
         else:
             # stale alias after set_pdf(): the reference averages the rows of
             # ``parameters`` (old samples) with the current weights

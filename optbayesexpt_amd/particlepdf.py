@@ -486,15 +486,21 @@ class ParticlePDF:
         check()
         return factor, mean
 
-    def _resample_apply(self, idx, z_dev, factor, mean):
+    def _resample_apply(self, idx, z_dev, factor, mean, aos=None):
+        """Gather + nudge.  ``aos``: the (N, D) copy of the old cloud that obe_resample_begin already made."""
         n, d = self.n_particles, self.n_dims
         old = self._particles.tensor()
         new = torch.empty((d, n), dtype=torch.float64, device=self._device)
         w = self._weights.tensor()
-        self._lib.call("obe_resample_particles", _ptr(old), old.shape[1], d, n, _ptr(idx), _ptr(z_dev),
-                       _lib.host_ptr(factor), _lib.host_ptr(mean), float(self.tuning_parameters["a_param"]),
-                       1 if self.tuning_parameters["scale"] else 0, _ptr(new), n, _ptr(w), _ptr(self._ws),
-                       self._ws_bytes, self._stream())
+        if aos is not None:
+            self._lib.call("obe_resample_particles_aos", _ptr(aos), d, n, _ptr(idx), _ptr(z_dev),
+                           _lib.host_ptr(factor), _lib.host_ptr(mean), float(self.tuning_parameters["a_param"]),
+                           1 if self.tuning_parameters["scale"] else 0, _ptr(new), n, _ptr(w), self._stream())
+        else:
+            self._lib.call("obe_resample_particles", _ptr(old), old.shape[1], d, n, _ptr(idx), _ptr(z_dev),
+                           _lib.host_ptr(factor), _lib.host_ptr(mean), float(self.tuning_parameters["a_param"]),
+                           1 if self.tuning_parameters["scale"] else 0, _ptr(new), n, _ptr(w), _ptr(self._ws),
+                           self._ws_bytes, self._stream())
         self._particles = Mirror(self._device, tensor=new)
         self._weights.mark_device_written()
         self.last_resample_indices_device = idx
@@ -517,6 +523,9 @@ class ParticlePDF:
             normals=torch.empty(n * d, dtype=torch.float64, device=dev),
             zig_ws=torch.empty(zig_bytes // 8 + 1, dtype=torch.float64, device=dev), tables=_devrng._tables(dev),
             pin_f=pin_f, pin_i=pin_i, p_f=_lib.host_ptr(pin_f), p_i=_lib.host_ptr(pin_i),
+            # the (N, D) copy of the pre-resample cloud the gather reads (made inside obe_resample_begin, while
+            # the host factorises the covariance); small or one-parameter clouds gather from the (D, N) array
+            aos=torch.empty(n * d, dtype=torch.float64, device=dev) if d >= 2 and n >= 65536 else None,
             # the drawn indices, two buffers used in turn: last_resample_indices_device of one resample stays
             # what it was through the next one
             idx=(torch.empty(n, dtype=torch.int64, device=dev), torch.empty(n, dtype=torch.int64, device=dev)),
@@ -554,7 +563,8 @@ class ParticlePDF:
                        1 if strict else 0, 1 if self._cdf_key == key else 0, 1 if have_first else 0,
                        b["n_raw"], _ptr(self._cdf_dev), _ptr(b["uni"]), _ptr(idx), _ptr(b["tables"]),
                        _ptr(b["normals"]), _ptr(b["zig_ws"]), b["zig_ws"].numel() * 8, _ptr(self._moments_dev),
-                       b["p_f"], b["p_i"], _ptr(self._ws), self._ws_bytes, stream)
+                       b["p_f"], b["p_i"], None if b["aos"] is None else _ptr(b["aos"]), _ptr(self._ws),
+                       self._ws_bytes, stream)
         pin_f = b["pin_f"]
         first = 2 + 4 * d                              # (a covariance-only pass delivers only the covariance)
         lo = first if have_first else 0
@@ -568,7 +578,7 @@ class ParticlePDF:
         factor, mean, check_covariance = self._nudge_factor(self._moments_host, defer_check=True)
         self.last_draw_indices_device = idx
         before = self._particles
-        self._resample_apply(idx, b["normals"], factor, mean)
+        self._resample_apply(idx, b["normals"], factor, mean, aos=b["aos"])
         check_covariance()
         self._lib.call("obe_host_words_wait", b["p_i"], 2, stream)     # {raw consumed, normals found}
         consumed, found = int(b["pin_i"][0]), int(b["pin_i"][1])
@@ -581,7 +591,7 @@ class ParticlePDF:
             rstream._generate()
             z_dev = rstream.normals()                  # (advances the generator past uniforms + normals)
             self._particles = before
-            self._resample_apply(idx, z_dev, factor, mean)
+            self._resample_apply(idx, z_dev, factor, mean, aos=b["aos"])
         else:
             _devrng.advance(self._rng, st, n + consumed)
 
