@@ -395,6 +395,12 @@ int obe_power_normalize(const double* d_u, int64_t n, double exponent, double* d
  * {best value (f64), best local index (i64 bits), kappa (f64), 0} — what a sharded caller
  * all-gathers across ranks (RCCL) without copying it to the host first. */
 #define OBE_WS_RESULT_OFFSET 2
+/* ... and once more in the last 48 bytes of the workspace, 4 doubles at d_ws + ws_bytes - 48 (ws_bytes a multiple
+ * of 8; written when the workspace has that much room behind what the call uses — obe_workspace_bytes() always
+ * leaves it): the update calls reuse the HEAD of the workspace, so a record that has to outlive them — the sweep
+ * enqueued behind an update, whose record a sharded caller all-gathers one host round trip later — is read
+ * there.  The word behind it is OBE_WS_ABORT_WORD. */
+#define OBE_WS_RESULT_TAIL(d_ws, ws_bytes) ((double*)((char*)(d_ws) + ((ws_bytes) & ~(int64_t)7) - 48))
 #define OBE_NOISE_FROM_MOMENTS(r0, r1, r2, r3) \
     (-(int64_t)1 - ((int64_t)(r0) | ((int64_t)(r1) << 5) | ((int64_t)(r2) << 10) | ((int64_t)(r3) << 15)))
 /* bits of the `shifted` argument of obe_sweep_utility / obe_sweep_kernel_time.  A plugin

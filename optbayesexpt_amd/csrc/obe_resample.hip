@@ -735,10 +735,20 @@ int obe_resample_begin(const double* d_particles, int64_t ld_p, int32_t n_dims, 
         return 0;
     };
     do {
-        // (split: the cloud's chain is enqueued first — the host waits for the covariance, and every launch costs
-        // it a few microseconds; the kernels of the random chain arrive while the scan is already running)
-        if (split && (rc = ev(hipEventRecord(side.entry, st)))) break;
         if (third) {
+            // Three chains.  The host enqueues the LONGEST first — the random numbers (uniforms + classification,
+            // then four ziggurat kernels: ~90 us at 524 288 x 10, what the gather ends up waiting for) —, then the
+            // covariance + (N, D) copy (the host's factorisation waits for the covariance), then CDF -> guide ->
+            // search on the caller's stream: every launch costs the host 2-4 us, and with the cloud's chains first
+            // the random chain used to start 20-45 us after the others.
+            if ((rc = ev(hipEventRecord(side.entry, st)))) break;
+            if ((rc = ev(hipStreamWaitEvent(side.stream, side.entry, 0)))) break;
+            if ((rc = obe_pcg64_uniforms_classify(h_pcg_state4, n, n_raw - n, d_uniforms, d_zig_tables, d_zig_ws,
+                                                  zig_ws_bytes, rs)))
+                break;
+            if ((rc = ev(hipEventRecord(side.mid, side.stream)))) break;
+            if ((rc = obe_ziggurat_finish(n_raw - n, n_normal, d_normals, h_i64, d_zig_ws, zig_ws_bytes, rs))) break;
+            if ((rc = ev(hipEventRecord(side.done, side.stream)))) break;
             if ((rc = ev(hipStreamWaitEvent(side.stream2, side.entry, 0)))) break;
             arm_host_words(h_f64 + 1 + lo, obe_moments_len(n_dims) - lo);
             bool host_written = false;
@@ -747,7 +757,21 @@ int obe_resample_begin(const double* d_particles, int64_t ld_p, int32_t n_dims, 
                 break;
             if ((rc = make_aos(side.stream2))) break;
             if ((rc = ev(hipEventRecord(side.done2, side.stream2)))) break;
+            if (!cdf_is_fresh) {
+                arm_host_word(h_f64);
+                if ((rc = obe_weight_cdf(d_weights, n, strict_cdf, d_cdf, h_f64, d_ws, ws_bytes, stream))) break;
+            } else {
+                h_f64[0] = 1.0;
+            }
+            if ((rc = ev(hipStreamWaitEvent(st, side.mid, 0)))) break;
+            if ((rc = obe_cdf_search(d_cdf, n, d_uniforms, n, d_idx, d_ws, ws_bytes, stream))) break;
+            if ((rc = ev(hipStreamWaitEvent(st, side.done, 0)))) break;
+            if ((rc = ev(hipStreamWaitEvent(st, side.done2, 0)))) break;
+            break;
         }
+        // (split: the cloud's chain is enqueued first — the host waits for the covariance, and every launch costs
+        // it a few microseconds; the kernels of the random chain arrive while the scan is already running)
+        if (split && (rc = ev(hipEventRecord(side.entry, st)))) break;
         auto cdf_and_covariance = [&]() -> int {
             if (!cdf_is_fresh) {
                 arm_host_word(h_f64);
@@ -755,7 +779,7 @@ int obe_resample_begin(const double* d_particles, int64_t ld_p, int32_t n_dims, 
             } else {
                 h_f64[0] = 1.0;
             }
-            if (!split || third) return 0;       // (one stream: the round-3 order, covariance after the search)
+            if (!split) return 0;       // (one stream: the round-3 order, covariance after the search)
             arm_host_words(h_f64 + 1 + lo, obe_moments_len(n_dims) - lo);
             bool host_written = false;
             return moments_call(d_particles, ld_p, n_dims, n, d_weights, have_first_moments ? 2 : 1, d_moments, h_f64 + 1,
@@ -777,10 +801,9 @@ int obe_resample_begin(const double* d_particles, int64_t ld_p, int32_t n_dims, 
             break;
         }
         if ((rc = obe_cdf_search(d_cdf, n, d_uniforms, n, d_idx, d_ws, ws_bytes, stream))) break;
-        if (copy_here && !third && (rc = make_aos(st))) break;
+        if (copy_here && (rc = make_aos(st))) break;
         if (split) {
             if ((rc = ev(hipStreamWaitEvent(st, side.done, 0)))) break;
-            if (third && (rc = ev(hipStreamWaitEvent(st, side.done2, 0)))) break;
         } else {
             arm_host_words(h_f64 + 1 + lo, obe_moments_len(n_dims) - lo);
             bool host_written = false;

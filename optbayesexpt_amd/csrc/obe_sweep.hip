@@ -445,9 +445,16 @@ struct HostResult {
     double* best;
     int64_t* idx;
     double* kappa;
+    double* tail = nullptr;     // the result record once more, at the END of the workspace (OBE_WS_RESULT_TAIL), or NULL
 };
 // (every word is armed by the host and waited for on its own: the order of the stores does not matter)
 __device__ __forceinline__ void deliver(const HostResult& h, double v, int64_t i, double k) {
+    if (h.tail) {       // where the update calls that reuse the head of the workspace do not reach
+        h.tail[0] = v;
+        reinterpret_cast<int64_t*>(h.tail)[1] = i;
+        h.tail[2] = k;
+        h.tail[3] = 0.0;
+    }
     if (h.idx) {
         if (h.best) *h.best = v;
         if (h.kappa) *h.kappa = k;
@@ -796,6 +803,13 @@ static int carve_sweep_ws(void* d_ws, int64_t ws_bytes, int64_t part_doubles, in
     return 0;
 }
 
+// the copy of the result record at the end of the workspace (include/obe_hip.h: OBE_WS_RESULT_TAIL), if the
+// workspace has the 48 spare bytes behind what the call itself uses
+static double* result_tail(void* d_ws, int64_t ws_bytes, int64_t need_bytes) {
+    if (!d_ws || ws_bytes < need_bytes + 48) return nullptr;
+    return reinterpret_cast<double*>(static_cast<char*>(d_ws) + (ws_bytes & ~(int64_t)7) - 48);
+}
+
 // the device views of the caller's host outputs if every one that is asked for is page-locked; each such
 // word is armed (before any launch) and read_best() waits for each of them
 static HostResult host_result(double* h_best, int64_t* h_best_idx, double* h_kappa) {
@@ -977,7 +991,8 @@ int obe_sweep_utility(const obe_model* m, const double* d_settings, int64_t ld_s
             (h_kappa && !device_view_of_host(h_kappa)))
             return bad_arg("obe_sweep_utility: OBE_SWEEP_SPECULATIVE / OBE_SWEEP_NOWAIT need page-locked host outputs");
     }
-    const HostResult hr = host_result(h_best, h_best_idx, h_kappa);
+    HostResult hr = host_result(h_best, h_best_idx, h_kappa);
+    hr.tail = result_tail(d_ws, ws_bytes, sweep_ws_need);
     static const bool no_small = getenv("OBE_SWEEP_NO_SMALL") != nullptr;      // test / tuning aid
     if (d_draw_idx && !no_small && n_draws <= kSmallSweepDraws && n_settings * n_draws <= kSmallSweepEvals) {
         int rc = dispatch_model(mm, [&](auto M) -> int {
@@ -1158,7 +1173,8 @@ int obe_utility_argmax(const double* d_yvar, int32_t n_channels, int64_t n_setti
     const int nb = stream_blocks(n_settings, kBlock);
     utility_kernel<<<nb, kBlock, 0, st>>>(d_yvar, n_channels, n_settings, ua, d_utility, w.bv, w.bi);
     OBE_CHECK_LAUNCH("utility_kernel");
-    const HostResult hr = host_result(h_best, h_best_idx, nullptr);
+    HostResult hr = host_result(h_best, h_best_idx, nullptr);
+    hr.tail = result_tail(d_ws, ws_bytes, sweep_ws_bytes(0, 0, kMaxBlocks, 0));
     argmax_fold<<<1, kBlock, 0, st>>>(w.bv, w.bi, nb, nullptr, w.out_v, w.out_i, hr);
     OBE_CHECK_LAUNCH("argmax_fold");
     return read_best(w, h_best, h_best_idx, st, nullptr, hr);
@@ -1173,7 +1189,8 @@ int obe_argmax(const double* d_v, int64_t n, double* h_best, int64_t* h_best_idx
     const int nb = stream_blocks(n, kBlock);
     argmax_kernel<<<nb, kBlock, 0, st>>>(d_v, n, w.bv, w.bi);
     OBE_CHECK_LAUNCH("argmax_kernel");
-    const HostResult hr = host_result(h_best, h_best_idx, nullptr);
+    HostResult hr = host_result(h_best, h_best_idx, nullptr);
+    hr.tail = result_tail(d_ws, ws_bytes, sweep_ws_bytes(0, 0, kMaxBlocks, 0));
     argmax_fold<<<1, kBlock, 0, st>>>(w.bv, w.bi, nb, nullptr, w.out_v, w.out_i, hr);
     OBE_CHECK_LAUNCH("argmax_fold");
     return read_best(w, h_best, h_best_idx, st, nullptr, hr);

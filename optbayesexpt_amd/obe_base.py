@@ -733,7 +733,9 @@ class OptBayesExpt(ParticlePDF):
         # synchronise; the deferred check of sum(w) happens at the caller's own synchronisation.
         checked = self._sweep_needs_range_check(n_draws)
         lazy = not want_best and not full and not sharded and not checked
-        off = _lib.OBE_WS_RESULT_OFFSET
+        # (sharded: the 32-byte result record at the END of the workspace — include/obe_hip.h: OBE_WS_RESULT_TAIL —,
+        # which the update calls between a sweep enqueued ahead and its collection do not touch)
+        tail = self._ws[-6:-2]
 
         def launch(shifted, safe=False, speculative=False):
             # sharded: no host read here — the 32-byte result record is all-gathered from
@@ -759,17 +761,12 @@ class OptBayesExpt(ParticlePDF):
                            None if no_host else p_kappa,
                            _ptr(self._ws), self._ws_bytes, stream)
             if speculative:
-                record = None
-                if sharded:         # the workspace is reused by whatever is enqueued next: keep the record
-                    record = self.__dict__.get("_spec_record")
-                    if record is None:
-                        record = self._spec_record = torch.empty(4, dtype=torch.float64, device=self._device)
-                    record.copy_(self._ws[off:off + 4])
                 # (waited for on the stream it was launched on; the sweep of a resampled cloud has nothing to guess)
-                state.enqueued(Ticket(self._sweep_inputs(shifted), None if sharded else p_best, block, record,
-                                      stream, stream.value), certain=speculative == "after_resample")
+                state.enqueued(Ticket(self._sweep_inputs(shifted), None if sharded else p_best, block,
+                                      tail if sharded else None, stream, stream.value),
+                               certain=speculative == "after_resample")
             else:
-                deliver(None if not sharded else self._ws[off:off + 4])
+                deliver(None if not sharded else tail)
 
         def deliver(record):
             if lazy:

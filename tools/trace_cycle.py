@@ -7,6 +7,8 @@ c = sqlite3.connect(sys.argv[1])
 rows = list(c.execute("select name, start, end from kernels order by start"))
 idx = [i for i, r in enumerate(rows) if "sweep_kernel" in r[0]]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else len(idx) // 2
+if k < 0:
+    k += len(idx) - 1          # counted from the last pair of sweeps
 a, b = idx[k], idx[k + 1]
 t0 = rows[a][1]
 prev_end = None
