@@ -121,7 +121,16 @@ class OptBayesExpt(ParticlePDF):
     ``settings_shard``
         a :class:`~optbayesexpt_amd.dist.SettingsShard`; this process then sweeps only
         its contiguous slice of the settings and ``opt_setting`` combines the per-rank
-        maxima with one all-gather.
+        maxima with one all-gather.  A sharded object is ONE experiment in G processes, and several of its
+        operations are COLLECTIVE — every rank must perform them, in the same order: construction, every
+        sweep (``opt_setting`` / ``good_setting`` / ``utility`` ...), ``random_setting``, ``check_replicas()``
+        and **assigning** ``rng`` (rank 0's generator state is broadcast inside the setter and adopted by
+        every rank, whatever type or seed the other ranks passed).  A script that reseeds on one rank only, or
+        in a different order on different ranks — legal against the reference's API, where ``rng`` is a plain
+        attribute (particlepdf.py:142-145) — blocks inside the setter until the communicator's timeout expires
+        (``torch.distributed.init_process_group(timeout=...)``) instead of raising at once; a generator that
+        was replaced behind the setter's back (``obj._rng = ...``) is reported by the next
+        ``check_replicas()`` on every rank.
     ``tuning_parameters['speculative_sweep']`` (``'auto'``, ``True``, ``False``; ``variance_full`` only)
         ``pdf_update()`` enqueues the sweep of the next ``opt_setting()`` behind its update (see
         ``_speculation_wanted``): the same results, one host round trip per cycle less.
