@@ -83,31 +83,33 @@ class SettingsShard:
         worst kappa over ALL ranks) — the same triple on every rank, so that decisions taken
         from it (repeat the sweep with the variance shift?) keep the ranks' collectives in step."""
         w = self.world_size
-        g = self._gather_records(record)
-        vals = g[:, 0].numpy()
-        local = g[:, 1].contiguous().view(torch.int64).numpy()
+        g = np.asarray(self._gather_records(record), dtype=np.float64).reshape(w, 4)    # (torch tensor or ndarray)
+        vals = g[:, 0]
+        local = np.ascontiguousarray(g[:, 1]).view(np.int64)
         starts = self._starts.get(n_settings)
         if starts is None:
             starts = self._starts[n_settings] = np.array([shard_bounds(n_settings, r, w)[0] for r in range(w)],
                                                          dtype=np.int64)
         gidx = local + starts
         k = first_max(vals, gidx)
-        kappas = g[:, 2].numpy()
+        kappas = g[:, 2]
         worst = float("nan") if np.any(np.isnan(kappas)) else float(np.max(kappas))
         return float(vals[k]), int(gidx[k]), worst
 
     def _gather_records(self, record):
-        """(world, 4) host tensor of every rank's record."""
+        """(world, 4) host array of every rank's record (valid until the next call: the page-locked landing zone
+        itself — combine_records() consumes it at once)."""
         w = self.world_size
         if w == 1:
-            return record.cpu().reshape(1, 4)
+            return record.cpu().numpy().reshape(1, 4)
         dev = self._comm_device(record.device)        # nccl: stay on the GPU; gloo: host tensors
         bufs = self._record_bufs
-        if dev not in bufs:                           # receive buffer + page-locked landing zone, made once
+        if dev not in bufs:                           # receive buffer + page-locked landing zone + its numpy view, made once
             host = torch.empty(4 * w, dtype=torch.float64)
-            bufs[dev] = (torch.empty(4 * w, dtype=torch.float64, device=dev),
-                         host.pin_memory() if dev.type == "cuda" else host)
-        gathered, host = bufs[dev]
+            if dev.type == "cuda":
+                host = host.pin_memory()
+            bufs[dev] = (torch.empty(4 * w, dtype=torch.float64, device=dev), host, host.numpy().reshape(w, 4))
+        gathered, host, host_np = bufs[dev]
         timing = self.timing
         if timing is not None:
             import time
@@ -115,19 +117,21 @@ class SettingsShard:
             if dev.type == "cuda":
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-        dist.all_gather_into_tensor(gathered, record.contiguous().to(dev), group=self.group)
+        # (the record is a contiguous float64 view of the sweep's workspace on this rank's device already)
+        src = record if record.device == dev and record.is_contiguous() else record.contiguous().to(dev)
+        dist.all_gather_into_tensor(gathered, src, group=self.group)
         if dev.type != "cuda":
             if timing is not None:
                 us = 1e6 * (time.perf_counter() - t0)
                 timing.append((us, us))
-            return gathered.clone().reshape(w, 4)
+            return gathered.numpy().reshape(w, 4)
         if timing is not None:
             e1.record()
         host.copy_(gathered, non_blocking=True)       # one asynchronous copy, one wait
         torch.cuda.current_stream(dev).synchronize()
         if timing is not None:
             timing.append((1e3 * e0.elapsed_time(e1), 1e6 * (time.perf_counter() - t0)))
-        return host.clone().reshape(w, 4)
+        return host_np
 
     def broadcast_from_rank0(self, values, device="cpu"):
         """Rank 0's host array on every rank (same shape and dtype everywhere): used for random

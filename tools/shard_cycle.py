@@ -32,9 +32,11 @@ class _Solo(SettingsShard):
     device memory as combine_records() does after the all-gather."""
 
     def _gather_records(self, record):
-        g = torch.full((self.world_size, 4), float("-inf"), dtype=torch.float64)
-        g[:, 2] = 0.0
-        g[self.rank] = record.cpu()
+        g = self.__dict__.get("_g")
+        if g is None:                     # (made once, like the real path's landing zone)
+            g = self._g = np.full((self.world_size, 4), float("-inf"))
+            g[:, 2] = 0.0
+        g[self.rank] = record.cpu().numpy()
         return g
 
 
