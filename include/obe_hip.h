@@ -312,6 +312,19 @@ int obe_resample_particles_aos(const double* d_old_aos, int32_t n_dims, int64_t 
                                double a_param, int32_t scale,
                                double* d_new, int64_t ld_new, double* d_weights, void* stream);
 
+/* ... and with the first half of OptBayesExptNoiseParameter.enforce_parameter_constraints
+ * (obe_noiseparam.py:57-79), which pdf_update() runs right after a resample, done by the gather: a new particle
+ * whose parameter h_rows[k] <= 0 for any k gets weight 0 instead of 1/N, and d_mask_partials (2 x 2048 doubles,
+ * the caller's) receives the partial sums {sum w, count} that obe_mask_nonpositive()'s first kernel would leave —
+ * same grid, same order, same bits — for obe_mask_renorm_moments().  ONLY for a resample that the constraint
+ * follows: the reference's resample() on its own leaves uniform weights. */
+int obe_resample_particles_aos_masked(const double* d_old_aos, int32_t n_dims, int64_t n_particles,
+                                      const int64_t* d_idx, const double* d_normals,
+                                      const double* h_factor, const double* h_mean,
+                                      double a_param, int32_t scale,
+                                      double* d_new, int64_t ld_new, double* d_weights,
+                                      const int32_t* h_rows, int32_t n_rows, double* d_mask_partials, void* stream);
+
 /* resample(), the device side up to the host's factorisation of the covariance, enqueued by ONE call
  * (particlepdf.py:260-301; RNG order as there: N uniforms for rng.choice, then N x D normals): the caller's
  * PCG64 stream continued on the device (h_pcg_state4 = {state hi, lo, increment hi, lo}; n_raw >= N + N D +
@@ -356,6 +369,14 @@ int obe_mask_nonpositive_moments(const double* d_particles, int64_t ld_p, int32_
 
 /* yvar_noise_model (obe_noiseparam.py:122-136): d_out[c] = weighted mean of
  * (particle row h_rows[c])^2, read from the K3 block: m2[row] / sum w.  No sync. */
+/* The second half of obe_mask_nonpositive_moments() on its own — renormalise if anything was zeroed, first moments
+ * of the constrained cloud, nothing waited for — from the partial sums a masked gather left in d_mask_partials
+ * (obe_resample_particles_aos_masked).  Refused (-1) before any launch without an arrival counter for the stream or
+ * with pageable host outputs: the caller then calls obe_mask_nonpositive_moments(), which on weights the gather has
+ * already masked zeroes the same particles and leaves the same bits. */
+int obe_mask_renorm_moments(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t n_particles,
+                            const double* d_mask_partials, double* d_weights, double* d_moments,
+                            double* h_moments, int64_t* h_changed, void* d_ws, int64_t ws_bytes, void* stream);
 int obe_noise_var_from_moments(const double* d_moments, int32_t n_dims, const int32_t* h_rows,
                                int32_t n_rows, double* d_out, void* stream);
 

@@ -88,6 +88,9 @@ _SIGNATURES = {
     "obe_resample_begin": (c_int, [_P, c_int64, c_int32, c_int64, _P, _P, c_int32, c_int32, c_int32, c_int64,
                                    _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, c_int64, _P]),
     "obe_resample_particles_aos": (c_int, [_P, c_int32, c_int64, _P, _P, _P, _P, c_double, c_int32, _P, c_int64, _P, _P]),
+    "obe_resample_particles_aos_masked": (c_int, [_P, c_int32, c_int64, _P, _P, _P, _P, c_double, c_int32, _P, c_int64, _P,
+                                                  _P, c_int32, _P, _P]),
+    "obe_mask_renorm_moments": (c_int, [_P, c_int64, c_int32, c_int64, _P, _P, _P, _P, _P, _P, c_int64, _P]),
     "obe_pcg64_uniforms_classify": (c_int, [_P, c_int64, c_int64, _P, _P, _P, c_int64, _P]),
     "obe_ziggurat_finish": (c_int, [c_int64, c_int64, _P, _P, _P, c_int64, _P]),
     "obe_noise_var_from_moments": (c_int, [_P, c_int32, _P, c_int32, _P, _P]),

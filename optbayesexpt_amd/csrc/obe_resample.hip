@@ -380,14 +380,24 @@ __global__ __launch_bounds__(kBlock) void soa_to_aos_kernel(const double* __rest
 }
 
 // AOS: `old` is the (N, D) copy made by soa_to_aos_kernel (ld_old unused)
-template <int D, bool AOS>
+// MASK (round 5): the first half of OptBayesExptNoiseParameter.enforce_parameter_constraints
+// (obe_noiseparam.py:57-79), which pdf_update() calls right after this resample, done here: a new particle
+// whose parameter `row` <= 0 for any row of mask_bits gets weight 0 instead of 1/N, and the workgroup leaves
+// the partial sums of the weights and of the zeroed count that mask_kernel (obe_update.hip) would leave —
+// the same grid, the same per-thread order, the same block reductions: the same bits — for
+// obe_mask_renorm_moments().  One launch and one pass over the noise rows and the weights less.
+template <int D, bool AOS, bool MASK = false>
 __global__ __launch_bounds__(kBlock) void resample_kernel(NudgeArgs na, const double* __restrict__ old, int64_t ld_old,
                                                           int64_t n, const int64_t* __restrict__ idx,
                                                           const double* __restrict__ z, double* __restrict__ out,
-                                                          int64_t ld_new, double* __restrict__ weights) {
+                                                          int64_t ld_new, double* __restrict__ weights,
+                                                          unsigned mask_bits = 0u, double* __restrict__ psum = nullptr,
+                                                          double* __restrict__ pcount = nullptr) {
     // the (N, D) row-major normals of a workgroup's 256 particles are one contiguous run: read it
     // lane-contiguously into LDS (a thread reading its own row makes every load touch 64 lines)
     __shared__ double zs[kBlock * D];
+    __shared__ double red[kBlock / kWave];
+    double acc = 0.0, cnt = 0.0;
     for (int64_t p0 = (int64_t)blockIdx.x * kBlock; p0 < n; p0 += (int64_t)gridDim.x * kBlock) {
         const int64_t p = p0 + threadIdx.x;
         const int64_t run = (n - p0 < kBlock ? n - p0 : kBlock) * D;
@@ -403,22 +413,40 @@ __global__ __launch_bounds__(kBlock) void resample_kernel(NudgeArgs na, const do
 #pragma unroll
         for (int i = 0; i < D; ++i)                                              // D independent gathers in flight
             x0[i] = AOS ? old[src * D + i] : old[(int64_t)i * ld_old + src];
+        bool bad = false;
 #pragma unroll
         for (int i = 0; i < D; ++i) {
             // (z @ F.T)[p, i]: FMA chain from zero in j order — bit-identical to the
             // dgemm NumPy's multivariate_normal uses (checked against numpy 2.2.6/OpenBLAS)
-            double acc = 0.0;
+            double nudge = 0.0;
 #pragma unroll
-            for (int j = 0; j < D; ++j) acc = fma(zr[j], na.factor[i * D + j], acc);
-            double v = x0[i] + acc;
+            for (int j = 0; j < D; ++j) nudge = fma(zr[j], na.factor[i * D + j], nudge);
+            double v = x0[i] + nudge;
             if (na.scale) {
                 const double va = v * na.a;
                 const double mc = na.mean[i] * na.one_minus_a;
                 v = va + mc;
             }
             out[(int64_t)i * ld_new + p] = v;
+            if constexpr (MASK) bad = bad || (((mask_bits >> i) & 1u) && v <= 0.0);
         }
-        weights[p] = na.uniform_w;
+        if constexpr (MASK) {
+            const double w = bad ? 0.0 : na.uniform_w;
+            weights[p] = w;
+            acc += w;
+            if (bad) cnt += 1.0;
+        } else {
+            weights[p] = na.uniform_w;
+        }
+    }
+    if constexpr (MASK) {
+        const double s = block_sum(acc, red);
+        __syncthreads();
+        const double c = block_sum(cnt, red);
+        if (threadIdx.x == 0) {
+            psum[blockIdx.x] = s;
+            pcount[blockIdx.x] = c;
+        }
     }
 }
 
@@ -433,9 +461,13 @@ static int launch_soa_to_aos(const double* d_old, int64_t ld_old, int64_t n, dou
 template <int D>
 static int launch_resample(const NudgeArgs& na, const double* d_old, int64_t ld_old, int64_t n, const int64_t* d_idx,
                            const double* d_normals, double* d_new, int64_t ld_new, double* d_weights, void* d_ws,
-                           int64_t ws_bytes, hipStream_t st) {
+                           int64_t ws_bytes, hipStream_t st, unsigned mask_bits = 0u, double* d_mask_partials = nullptr) {
     const int blocks = stream_blocks(n, kBlock);
-    if (!d_old) {
+    if (!d_old && mask_bits) {
+        resample_kernel<D, true, true><<<blocks, kBlock, 0, st>>>(na, static_cast<const double*>(d_ws), 0, n, d_idx,
+                                                                  d_normals, d_new, ld_new, d_weights, mask_bits,
+                                                                  d_mask_partials, d_mask_partials + kMaxBlocks);
+    } else if (!d_old) {
         resample_kernel<D, true><<<blocks, kBlock, 0, st>>>(na, static_cast<const double*>(d_ws), 0, n, d_idx, d_normals,
                                                             d_new, ld_new, d_weights);
     } else if (D >= 2 && n >= 65536 && d_ws && ws_bytes >= (int64_t)sizeof(double) * D * n) {
@@ -615,7 +647,8 @@ int obe_gather_columns(const double* d_particles, int64_t ld_p, int32_t n_dims, 
 static int resample_particles(const double* d_old, int64_t ld_old, int32_t n_dims, int64_t n_particles,
                               const int64_t* d_idx, const double* d_normals, const double* h_factor,
                               const double* h_mean, double a_param, int32_t scale, double* d_new, int64_t ld_new,
-                              double* d_weights, void* d_ws, int64_t ws_bytes, void* stream);
+                              double* d_weights, void* d_ws, int64_t ws_bytes, void* stream, unsigned mask_bits = 0u,
+                              double* d_mask_partials = nullptr);
 
 int obe_resample_particles(const double* d_old, int64_t ld_old, int32_t n_dims, int64_t n_particles,
                            const int64_t* d_idx, const double* d_normals, const double* h_factor,
@@ -635,10 +668,27 @@ int obe_resample_particles_aos(const double* d_old_aos, int32_t n_dims, int64_t 
                               ld_new, d_weights, const_cast<double*>(d_old_aos), 0, stream);
 }
 
+int obe_resample_particles_aos_masked(const double* d_old_aos, int32_t n_dims, int64_t n_particles,
+                                      const int64_t* d_idx, const double* d_normals, const double* h_factor,
+                                      const double* h_mean, double a_param, int32_t scale, double* d_new,
+                                      int64_t ld_new, double* d_weights, const int32_t* h_rows, int32_t n_rows,
+                                      double* d_mask_partials, void* stream) {
+    if (!d_old_aos || d_old_aos == d_new || !h_rows || !d_mask_partials || n_rows < 1 || n_rows > OBE_MAX_DIMS)
+        return bad_arg("obe_resample_particles_aos_masked: bad pointer/size");
+    unsigned bits = 0u;
+    for (int k = 0; k < n_rows; ++k) {
+        if (h_rows[k] < 0 || h_rows[k] >= n_dims) return bad_arg("obe_resample_particles_aos_masked: row index out of range");
+        bits |= 1u << h_rows[k];
+    }
+    return resample_particles(nullptr, 0, n_dims, n_particles, d_idx, d_normals, h_factor, h_mean, a_param, scale, d_new,
+                              ld_new, d_weights, const_cast<double*>(d_old_aos), 0, stream, bits, d_mask_partials);
+}
+
 static int resample_particles(const double* d_old, int64_t ld_old, int32_t n_dims, int64_t n_particles,
                               const int64_t* d_idx, const double* d_normals, const double* h_factor,
                               const double* h_mean, double a_param, int32_t scale, double* d_new, int64_t ld_new,
-                              double* d_weights, void* d_ws, int64_t ws_bytes, void* stream) {
+                              double* d_weights, void* d_ws, int64_t ws_bytes, void* stream, unsigned mask_bits,
+                              double* d_mask_partials) {
     if (!d_idx || !d_normals || !h_factor || !h_mean || !d_new || !d_weights || n_particles <= 0)
         return bad_arg("obe_resample_particles: bad pointer/size");
     if (n_dims < 1 || n_dims > OBE_MAX_DIMS) return bad_arg("obe_resample_particles: n_dims must be 1..16");
@@ -653,7 +703,7 @@ static int resample_particles(const double* d_old, int64_t ld_old, int32_t n_dim
     hipStream_t st = as_stream(stream);
 #define OBE_RS_CASE(DD) \
     case DD: return launch_resample<DD>(na, d_old, ld_old, n_particles, d_idx, d_normals, d_new, ld_new, d_weights, \
-                                        d_ws, ws_bytes, st);
+                                        d_ws, ws_bytes, st, mask_bits, d_mask_partials);
     switch (n_dims) {
         OBE_RS_CASE(1) OBE_RS_CASE(2) OBE_RS_CASE(3) OBE_RS_CASE(4) OBE_RS_CASE(5) OBE_RS_CASE(6) OBE_RS_CASE(7)
         OBE_RS_CASE(8) OBE_RS_CASE(9) OBE_RS_CASE(10) OBE_RS_CASE(11) OBE_RS_CASE(12) OBE_RS_CASE(13)

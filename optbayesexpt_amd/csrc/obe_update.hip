@@ -1075,6 +1075,32 @@ int obe_mask_nonpositive(const double* d_particles, int64_t ld_p, int64_t n_part
     return 0;
 }
 
+static int mask_renorm_moments(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t n_particles,
+                               const double* psum, const double* pcount, int nb, double* d_weights, double* d_moments,
+                               double* h_moments, double* hm, int64_t* h_changed, int64_t* hc, unsigned* counter,
+                               double* partials_mom, hipStream_t st);
+
+int obe_mask_renorm_moments(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t n_particles,
+                            const double* d_mask_partials, double* d_weights, double* d_moments, double* h_moments,
+                            int64_t* h_changed, void* d_ws, int64_t ws_bytes, void* stream) {
+    if (!d_particles || !d_weights || !d_mask_partials || !d_moments || n_particles <= 0)
+        return bad_arg("obe_mask_renorm_moments: bad pointer/size");
+    if (n_dims < 1 || n_dims > OBE_MAX_DIMS) return bad_arg("obe_mask_renorm_moments: n_dims must be 1..16");
+    hipStream_t st = as_stream(stream);
+    unsigned* counter = stream_control_words(st);
+    int64_t* hc = static_cast<int64_t*>(device_view_of_host(h_changed));
+    double* hm = static_cast<double*>(device_view_of_host(h_moments));
+    // (refused before any launch: the caller then runs obe_mask_nonpositive_moments(), which on weights the gather
+    // has already masked finds the same particles and leaves the same bits)
+    if (!counter || (h_changed && !hc) || (h_moments && !hm))
+        return bad_arg("obe_mask_renorm_moments: needs an arrival counter for the stream and page-locked host outputs");
+    UpdateWs w;
+    if (int rc = carve_update_ws(d_ws, ws_bytes, w, n_dims)) return rc;
+    return mask_renorm_moments(d_particles, ld_p, n_dims, n_particles, d_mask_partials, d_mask_partials + kMaxBlocks,
+                               stream_blocks(n_particles, kBlock), d_weights, d_moments, h_moments, hm, h_changed, hc,
+                               counter, w.mom, st);
+}
+
 int obe_mask_nonpositive_moments(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t n_particles,
                                  const int32_t* h_rows, int32_t n_rows, double* d_weights, double* d_moments,
                                  double* h_moments, int64_t* h_changed, void* d_ws, int64_t ws_bytes, void* stream) {
@@ -1104,14 +1130,24 @@ int obe_mask_nonpositive_moments(const double* d_particles, int64_t ld_p, int32_
     const int nb = stream_blocks(n_particles, kBlock);
     mask_kernel<<<nb, kBlock, 0, st>>>(ra, d_particles, ld_p, n_particles, d_weights, w.pa, w.pb);
     OBE_CHECK_LAUNCH("mask_kernel");
+    return mask_renorm_moments(d_particles, ld_p, n_dims, n_particles, w.pa, w.pb, nb, d_weights, d_moments, h_moments,
+                               hm, h_changed, hc, counter, w.mom, st);
+}
+
+// the second half: renormalise if anything was zeroed + the first moments of the constrained cloud, from the partial
+// sums {sum w, count} that mask_kernel — or the masked gather of a resample (obe_resample_particles_aos_masked) — left
+static int mask_renorm_moments(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t n_particles,
+                               const double* psum, const double* pcount, int nb, double* d_weights, double* d_moments,
+                               double* h_moments, double* hm, int64_t* h_changed, int64_t* hc, unsigned* counter,
+                               double* partials_mom, hipStream_t st) {
     if (hc) arm_host_word(h_changed);
     if (hm) arm_host_words(h_moments, 2 + 4 * (int64_t)n_dims);
     const MaskFold mf{counter, d_moments, hm, hc};
     const int nm = first_moment_blocks(n_particles, n_dims);
 #define OBE_MASK_MOM_CASE(DD)                                                                                       \
     case DD:                                                                                                        \
-        mask_renorm_moments_kernel<DD><<<nm, kBlock, 0, st>>>(w.pa, w.pb, nb, d_particles, ld_p, n_particles,      \
-                                                              d_weights, w.mom, mf);                                \
+        mask_renorm_moments_kernel<DD><<<nm, kBlock, 0, st>>>(psum, pcount, nb, d_particles, ld_p, n_particles,    \
+                                                              d_weights, partials_mom, mf);                         \
         break;
     switch (n_dims) {
         OBE_MASK_MOM_CASE(1) OBE_MASK_MOM_CASE(2) OBE_MASK_MOM_CASE(3) OBE_MASK_MOM_CASE(4) OBE_MASK_MOM_CASE(5)

@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from .obe_base import OptBayesExpt, _overridden
-from .particlepdf import _ptr
+from .particlepdf import ParticlePDF, _ptr
 
 
 class OptBayesExptNoiseParameter(OptBayesExpt):
@@ -59,11 +59,26 @@ class OptBayesExptNoiseParameter(OptBayesExpt):
         if changed is None:
             changed = self._changed_pinned = _lib.pinned_array(1, np.int64)
         fused = self._parameters is self._particles
+        masked = self.__dict__.get("_masked_by_gather")
+        self._masked_by_gather = None
         if fused:
-            self._lib.call("obe_mask_nonpositive_moments", _ptr(par), par.shape[1], self.n_dims, self.n_particles,
-                           _lib.host_ptr(self._noise_rows), self.n_channels, _ptr(w), _ptr(self._moments_dev),
-                           self._hargs.ptr_keep(self._moments_host), _lib.host_ptr(changed), _ptr(self._ws),
-                           self._ws_bytes, self._stream())
+            done = False
+            if masked is not None and masked == (self._particles.version, self._weights.version):
+                # the gather of the resample that pdf_update() has just run zeroed these weights already and left
+                # the partial sums: only the renormalisation + first moments remain (one launch instead of two)
+                try:
+                    self._lib.call("obe_mask_renorm_moments", _ptr(par), par.shape[1], self.n_dims, self.n_particles,
+                                   _ptr(self._mask_partials), _ptr(w), _ptr(self._moments_dev),
+                                   self._hargs.ptr_keep(self._moments_host), _lib.host_ptr(changed), _ptr(self._ws),
+                                   self._ws_bytes, self._stream())
+                    done = True
+                except _lib.ObeHipError:
+                    pass          # (refused before any launch: the full form below finds the same particles)
+            if not done:
+                self._lib.call("obe_mask_nonpositive_moments", _ptr(par), par.shape[1], self.n_dims, self.n_particles,
+                               _lib.host_ptr(self._noise_rows), self.n_channels, _ptr(w), _ptr(self._moments_dev),
+                               self._hargs.ptr_keep(self._moments_host), _lib.host_ptr(changed), _ptr(self._ws),
+                               self._ws_bytes, self._stream())
             self._constraint_pending = True
             # (weights may have changed: a new version either way; the moments describe exactly them)
             self._weights.mark_device_written()
@@ -78,6 +93,25 @@ class OptBayesExptNoiseParameter(OptBayesExpt):
             self._constraint_pending = False
             if changed[0]:
                 self._weights.mark_device_written()
+
+    def _resample_mask_rows(self):
+        """The gather of a resample may apply this class's constraint itself when that constraint is certain to
+        follow: the resample runs inside pdf_update() (which calls enforce_parameter_constraints() right after it —
+        a resample() called on its own must leave uniform weights, like the reference's), the hook is this class's
+        own, and tuning_parameters['mask_in_gather'] (default True) does not say otherwise."""
+        if not self.__dict__.get("_constraint_follows") or not self.tuning_parameters.get("mask_in_gather", True) \
+                or _overridden(self, "enforce_parameter_constraints", OptBayesExpt, OptBayesExptNoiseParameter) \
+                or _overridden(self, "resample_test", ParticlePDF) or _overridden(self, "resample", ParticlePDF):
+            return None           # (a replaced resample test might resample without reporting it: no constraint would follow)
+        return self._noise_rows, self.n_channels
+
+    def pdf_update(self, measurement_record, y_model_data=None):
+        """obe_base.py:340-399 (the noise-parameter class inherits it); see _resample_mask_rows."""
+        self._constraint_follows = True
+        try:
+            return OptBayesExpt.pdf_update(self, measurement_record, y_model_data)
+        finally:
+            self._constraint_follows = False
 
     @property
     def last_constraint_count(self):

@@ -486,13 +486,28 @@ class ParticlePDF:
         check()
         return factor, mean
 
+    def _resample_mask_rows(self):
+        """Hook: (int32 rows array, n) if a positivity constraint on those parameter rows is KNOWN to follow this
+        resample (OptBayesExptNoiseParameter inside pdf_update()): the gather then zeroes those weights itself."""
+        return None
+
     def _resample_apply(self, idx, z_dev, factor, mean, aos=None):
         """Gather + nudge.  ``aos``: the (N, D) copy of the old cloud that obe_resample_begin already made."""
         n, d = self.n_particles, self.n_dims
         old = self._particles.tensor()
         new = torch.empty((d, n), dtype=torch.float64, device=self._device)
         w = self._weights.tensor()
-        if aos is not None:
+        mask = self._resample_mask_rows() if aos is not None else None
+        self._masked_by_gather = None
+        if mask is not None:
+            partials = self.__dict__.get("_mask_partials")
+            if partials is None:          # {sum w, count} per workgroup of the gather: the object's own, not the workspace
+                partials = self._mask_partials = torch.empty(2 * 2048, dtype=torch.float64, device=self._device)
+            self._lib.call("obe_resample_particles_aos_masked", _ptr(aos), d, n, _ptr(idx), _ptr(z_dev),
+                           _lib.host_ptr(factor), _lib.host_ptr(mean), float(self.tuning_parameters["a_param"]),
+                           1 if self.tuning_parameters["scale"] else 0, _ptr(new), n, _ptr(w), _lib.host_ptr(mask[0]),
+                           mask[1], _ptr(partials), self._stream())
+        elif aos is not None:
             self._lib.call("obe_resample_particles_aos", _ptr(aos), d, n, _ptr(idx), _ptr(z_dev),
                            _lib.host_ptr(factor), _lib.host_ptr(mean), float(self.tuning_parameters["a_param"]),
                            1 if self.tuning_parameters["scale"] else 0, _ptr(new), n, _ptr(w), self._stream())
@@ -504,6 +519,8 @@ class ParticlePDF:
         self._particles = Mirror(self._device, tensor=new)
         self._weights.mark_device_written()
         self.last_resample_indices_device = idx
+        if mask is not None:      # (valid while nobody touches the cloud or the weights: enforce_parameter_constraints checks)
+            self._masked_by_gather = (self._particles.version, self._weights.version)
 
     def _resample_buffers(self, n, d):
         """Scratch of the pipelined resample, made once per cloud shape: raw PCG64 values, uniforms,

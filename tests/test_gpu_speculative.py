@@ -333,6 +333,42 @@ def test_cycles_on_alternating_streams(hip, sharded):
         assert np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2])
 
 
+def test_the_constraint_mask_inside_the_gather_is_the_mask_after_it(hip):
+    """Round 5: inside pdf_update() the gather of a resample zeroes the weights of new particles with sigma <= 0 itself and
+    leaves mask_kernel's partial sums, so that enforce_parameter_constraints() (obe_noiseparam.py:57-79) is one launch
+    instead of two.  Same particles masked, same weights, moments, counts, settings, generator — bit for bit — as with
+    tuning_parameters['mask_in_gather'] = False; a resample() called on its own still leaves uniform weights."""
+    import optbayesexpt_amd as obe
+    logs, counts = {}, {}
+    for flag in (True, False):
+        o = make(obe, "auto", n_particles=70000, n_settings=1500, noise_param=True, threshold=0.9)
+        o.tuning_parameters["mask_in_gather"] = flag
+        used = []
+        call = o._lib.call
+
+        class Spy:                        # which of the two routes the constraint took
+            def __getattr__(self, name):
+                return getattr(o_lib, name)
+
+            def call(self, name, *a):
+                if name in ("obe_mask_renorm_moments", "obe_mask_nonpositive_moments", "obe_resample_particles_aos_masked"):
+                    used.append(name)
+                return call(name, *a)
+        o_lib = o._lib
+        o._lib = Spy()
+        log = cycles(o, 25, between=lambda obj, c: np.array([obj.last_constraint_count], dtype=np.float64))
+        logs[flag], counts[flag] = log, used
+        assert sum(e["resampled"] for e in log) >= 5 and max(e["between"][0] for e in log) > 0
+    same(logs[True], logs[False])
+    assert "obe_mask_renorm_moments" in counts[True] and "obe_resample_particles_aos_masked" in counts[True]
+    assert "obe_mask_renorm_moments" not in counts[False] and "obe_resample_particles_aos_masked" not in counts[False]
+    # outside pdf_update() nothing follows the resample: uniform weights, as the reference's resample() leaves them
+    o = make(obe, False, n_particles=70000, n_settings=300, noise_param=True)
+    o.resample()
+    w = o.particle_weights
+    assert np.all(w == 1.0 / w.size)
+
+
 def _run_tool(args, timeout):
     import os
     import subprocess

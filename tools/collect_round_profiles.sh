@@ -22,7 +22,7 @@ bash tools/profile_rocprof.sh c2
 bash tools/profile_sq.sh
 for cfg in c3 c5 c2; do
   src=gpurun_out/prof; [ $cfg != c3 ] && src=gpurun_out/prof_$cfg
-  ( for k in 2 3 4; do timeout 60 python tools/trace_cycle.py $src/trace/bench_results.db $k; echo; done ) > gpurun_out/round/cycle_timeline_$cfg.txt 2>&1
+  ( for k in -9 -8 -7; do timeout 60 python tools/trace_cycle.py $src/trace/bench_results.db $k; echo; done ) > gpurun_out/round/cycle_timeline_$cfg.txt 2>&1
 done
 # the rocpd databases are too large to travel back (64 MiB limit): summarise them here
 cp profiles/pmc_traffic.json gpurun_out/round/ 2>/dev/null
