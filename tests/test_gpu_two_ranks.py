@@ -224,3 +224,27 @@ def test_bench_starts_its_own_ranks(hip):
     assert c["combines_in_timed_steps"] >= 4 and c["sweep_launches_in_timed_steps"] >= 4
     for key in ("cycle_ms", "k1_ms_per_sweep", "non_k1_ms_per_cycle", "combine_us_in_cycle_median", "combine_us_idle_median"):
         assert len(c[key]["per_rank"]) == 2 and 0.0 < c[key]["min"] <= c[key]["max"], (key, c[key])
+
+
+def test_bench_line_of_a_one_rank_rccl_world_carries_the_rccl_block(hip):
+    """`python bench.py --force-dist`: the sharded code path over a real RCCL communicator (of one rank — all a
+    one-GPU box can host): the line carries what an N > 1 line carries, reported by the backend itself."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT",
+                                                             "OBE_BENCH_BACKEND", "OBE_BENCH_ONE_DEVICE")}
+    env["MASTER_PORT"] = str(_free_port())
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--config", "c2", "--steps", "4",
+                        "--warmup", "2", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    c = out["rccl"]
+    assert c["backend"] == "nccl" and c["world_size_reported_by_backend"] == 1 and c["all_gather_rank_ids"] == [0]
+    assert c["rccl_version"] and c["sweep_launches_in_timed_steps"] >= 4
+    assert 0.0 < c["k1_ms_per_sweep"]["max"] < c["cycle_ms"]["max"]
+    assert 0.0 < c["combine_us_idle_median"]["max"] < 5000.0
+    assert out["config"]["clock_warm_up_ms_before_the_warmup_steps"] >= 100.0
