@@ -426,11 +426,6 @@ __device__ __forceinline__ uint32_t flag_tile_scan(uint32_t (&v)[kFlagItems], ui
     return total;
 }
 
-__global__ __launch_bounds__(kBlock) void flag_scan_offsets(uint32_t* __restrict__ sums, int64_t nb) {
-    __shared__ uint32_t lds[kBlock + 1];
-    block_exclusive_scan_inplace<uint32_t>(sums, nb, lds);
-}
-
 // out[rank] = val[i] for the first n starts; result[0] = raw consumed by them (relative to `first`),
 // result[1] = number of starts found.
 // The tile of candidate values is staged through LDS: a thread needs the flags of 8 CONSECUTIVE
@@ -462,7 +457,21 @@ __global__ __launch_bounds__(kBlock) void zig_compact_kernel(const uint8_t* __re
 #pragma unroll
     for (int k = 0; k < kFlagItems; ++k) f[k] = v[k] = (uint32_t)((packed >> (8 * k)) & 1u);
     const uint32_t total = flag_tile_scan(v, lds);       // (contains the barriers that publish sval)
-    const uint32_t off = block_off[blockIdx.x];
+    // This tile's first rank = the number of starts in all tiles before it.  Round 5: every workgroup adds up the
+    // tile counts in front of it itself (zig_starts_kernel left them in block_off[]; <= ~2600 values = 10 KB that
+    // live in L2, ten independent loads per thread at most, exact integer arithmetic) instead of a one-workgroup
+    // exclusive scan in a launch of its own between the two kernels: 8 us + a launch boundary off the longest
+    // chain of a resample.
+    uint32_t before = 0;
+    for (unsigned j = threadIdx.x; j < blockIdx.x; j += kBlock) before += block_off[j];
+    for (int o = kWave / 2; o > 0; o >>= 1) before += __shfl_down(before, o, kWave);
+    __shared__ uint32_t woff[kBlock / kWave];
+    __syncthreads();                                     // (lds[] of the tile scan has been consumed)
+    if ((threadIdx.x & (kWave - 1)) == 0) woff[threadIdx.x / kWave] = before;
+    __syncthreads();
+    uint32_t off = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / kWave; ++w) off += woff[w];
 #pragma unroll
     for (int k = 0; k < kFlagItems; ++k) {
         if (f[k]) {
@@ -582,8 +591,7 @@ static int zig_finish(const ZigWs& w, int64_t n_raw, int64_t offset, int64_t n, 
     static_assert(kStartTile == kFlagTile && kStartItems == kFlagItems, "the start flags and their scan share one tiling");
     zig_starts_kernel<<<(unsigned)w.nb, kBlock, 0, st>>>(w.len, n_raw, offset, w.flag, w.sums);
     OBE_CHECK_LAUNCH("zig_starts_kernel");
-    flag_scan_offsets<<<1, kBlock, 0, st>>>(w.sums, w.nb);
-    OBE_CHECK_LAUNCH("flag_scan_offsets");
+    // (no scan launch: zig_compact_kernel's workgroups add up the tile counts in front of them themselves)
     // deferred + page-locked h_consumed: the kernel delivers {consumed, found} itself and the caller watches
     // both words (armed here: no count has that bit pattern)
     int64_t* hv = defer_host_sync() ? static_cast<int64_t*>(device_view_of_host(h_consumed)) : nullptr;
