@@ -491,11 +491,13 @@ class ParticlePDF:
         resample (OptBayesExptNoiseParameter inside pdf_update()): the gather then zeroes those weights itself."""
         return None
 
-    def _resample_apply(self, idx, z_dev, factor, mean, aos=None):
-        """Gather + nudge.  ``aos``: the (N, D) copy of the old cloud that obe_resample_begin already made."""
+    def _resample_apply(self, idx, z_dev, factor, mean, aos=None, new=None):
+        """Gather + nudge.  ``aos``: the (N, D) copy of the old cloud that obe_resample_begin already made;
+        ``new``: the (D, N) tensor for the new cloud if the caller has allocated it already."""
         n, d = self.n_particles, self.n_dims
         old = self._particles.tensor()
-        new = torch.empty((d, n), dtype=torch.float64, device=self._device)
+        if new is None:
+            new = torch.empty((d, n), dtype=torch.float64, device=self._device)
         w = self._weights.tensor()
         mask = self._resample_mask_rows() if aos is not None else None
         self._masked_by_gather = None
@@ -585,6 +587,8 @@ class ParticlePDF:
         pin_f = b["pin_f"]
         first = 2 + 4 * d                              # (a covariance-only pass delivers only the covariance)
         lo = first if have_first else 0
+        # (the new cloud's storage, while the covariance is still on its way: off the host's critical path)
+        new_cloud = torch.empty((d, n), dtype=torch.float64, device=self._device)
         # every word of the block is watched (the call armed them): the covariance is there, the normals still run
         self._lib.call("obe_host_words_wait", _P(pin_f.ctypes.data + 8 * (1 + lo)), mlen - lo, stream)
         self._lib.call("obe_host_words_wait", b["p_f"], 1, stream)     # sum(w), from an earlier kernel
@@ -595,7 +599,7 @@ class ParticlePDF:
         factor, mean, check_covariance = self._nudge_factor(self._moments_host, defer_check=True)
         self.last_draw_indices_device = idx
         before = self._particles
-        self._resample_apply(idx, b["normals"], factor, mean, aos=b["aos"])
+        self._resample_apply(idx, b["normals"], factor, mean, aos=b["aos"], new=new_cloud)
         check_covariance()
         self._lib.call("obe_host_words_wait", b["p_i"], 2, stream)     # {raw consumed, normals found}
         consumed, found = int(b["pin_i"][0]), int(b["pin_i"][1])
