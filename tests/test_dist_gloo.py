@@ -97,6 +97,13 @@ def _worker(rank, world, port, ret):
             shard, np.random.Generator(np.random.MT19937(5)) if rank == 0 else np.random.default_rng())
         table = shard.all_gather_int64(np.array([7, rank, -rank]))
         assert table.shape == (world, 3) and table[:, 1].tolist() == list(range(world))
+        # bench.py's instrumentation of the arg-max combine (the "rccl" block of an N > 1 line): one entry per combine
+        shard.timing = []
+        for k in range(3):
+            shard.combine_records(SettingsShard.make_record(float(rank + k), 5, kappa=1.0), 1000)
+        assert len(shard.timing) == 3 and all(a > 0.0 and b > 0.0 for a, b in shard.timing)
+        shard.timing = None
+        shard.combine_records(SettingsShard.make_record(1.0, 0), 1000)
     finally:
         dist.destroy_process_group()
 
