@@ -144,27 +144,47 @@ __device__ __forceinline__ bool sweep_aborted(const unsigned* abort) {
 template <class M>
 __global__ __launch_bounds__(kBlock) void sweep_pack_kernel(SweepArgs a) {
     constexpr int NPK = M::NPK, NPKW = packed_width<M>();
+    // records wider than 32 bytes leave through LDS (round 5): a thread storing its own 80-byte record makes every
+    // store instruction of a wave touch 40 cache lines, 16 bytes each; staged, a workgroup's 256 records are one
+    // contiguous run written lane by lane
+    constexpr bool STAGED = NPKW > 4 && NPKW <= 24;          // (<= 48 KB of LDS)
+    __shared__ double2 tile[STAGED ? kBlock * NPKW / 2 : 1];
     if (sweep_aborted(a.abort)) return;
     const double* __restrict__ thbar = a.moments + 2;   // weighted-mean parameters (K3 output)
-    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < a.nd; p += (int64_t)gridDim.x * kBlock) {
-        int64_t src = p;
-        double w;
-        if (a.draw_idx) {
-            src = a.draw_idx[p];
-            src = src < 0 ? 0 : (src >= a.n_particles ? a.n_particles - 1 : src);
-            w = a.uniform_w;
-        } else {
-            w = a.weights[p];
-        }
-        const double sw = sqrt(w);
+    for (int64_t p0 = (int64_t)blockIdx.x * kBlock; p0 < a.nd; p0 += (int64_t)gridDim.x * kBlock) {
+        const int64_t p = p0 + threadIdx.x;
         double pk[NPKW];
-        M::pack(ParamRef{a.particles + src, a.ld_p}, thbar, a.m, sw, pk);
-        pk[NPK] = sw;
+        if (p < a.nd) {
+            int64_t src = p;
+            double w;
+            if (a.draw_idx) {
+                src = a.draw_idx[p];
+                src = src < 0 ? 0 : (src >= a.n_particles ? a.n_particles - 1 : src);
+                w = a.uniform_w;
+            } else {
+                w = a.weights[p];
+            }
+            const double sw = sqrt(w);
+            M::pack(ParamRef{a.particles + src, a.ld_p}, thbar, a.m, sw, pk);
+            pk[NPK] = sw;
 #pragma unroll
-        for (int k = NPK + 1; k < NPKW; ++k) pk[k] = 0.0;
-        double2* __restrict__ out = reinterpret_cast<double2*>(a.packed + p * NPKW);
+            for (int k = NPK + 1; k < NPKW; ++k) pk[k] = 0.0;
+        }
+        if constexpr (STAGED) {
+            __syncthreads();           // the previous trip's tile has left
+            if (p < a.nd) {
 #pragma unroll
-        for (int k = 0; k < NPKW / 2; ++k) out[k] = double2{pk[2 * k], pk[2 * k + 1]};
+                for (int k = 0; k < NPKW / 2; ++k) tile[threadIdx.x * (NPKW / 2) + k] = double2{pk[2 * k], pk[2 * k + 1]};
+            }
+            __syncthreads();
+            const int64_t run = (a.nd - p0 < kBlock ? a.nd - p0 : kBlock) * (NPKW / 2);
+            double2* __restrict__ out = reinterpret_cast<double2*>(a.packed + p0 * NPKW);
+            for (int64_t e = threadIdx.x; e < run; e += kBlock) out[e] = tile[e];
+        } else if (p < a.nd) {
+            double2* __restrict__ out = reinterpret_cast<double2*>(a.packed + p * NPKW);
+#pragma unroll
+            for (int k = 0; k < NPKW / 2; ++k) out[k] = double2{pk[2 * k], pk[2 * k + 1]};
+        }
     }
 }
 
