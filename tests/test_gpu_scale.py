@@ -116,7 +116,23 @@ def _full_grid_check(o, ref_yvar, ref_util, what, pick=None):
     o.tuning_parameters["sweep_shift"] = "auto"
     print(f"{what}: full grid of {ref_yvar.size} settings vs oracle/csweep.c — {report}")
     assert "worst" in report["always"]
+    if full:
+        # good_setting() on the whole grid (obe_base.py:758-789): p = nan_to_num(u ** pickiness) / sum, one uniform
+        # of the caller's generator, numpy's choice = searchsorted on the CDF — the index from the INDEPENDENT utility
+        for seed in (11, 12, 13):
+            o.rng = np.random.default_rng(seed)
+            o.good_setting(pickiness=7)
+            p = np.nan_to_num(ref_util ** 7)
+            want = int(np.random.default_rng(seed).choice(ref_util.size, p=p / np.sum(p)))
+            assert o.last_setting_index == want, (what, "good_setting", seed, o.last_setting_index, want)
+            assert o.rng.bit_generator.state == _advanced(seed)
     return report
+
+
+def _advanced(seed):
+    g = np.random.default_rng(seed)
+    g.random()
+    return g.bit_generator.state
 
 
 @pytest.mark.parametrize("cfg,n_sample", [("c2", 24), ("c3", 10)])
