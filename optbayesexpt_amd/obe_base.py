@@ -744,7 +744,7 @@ class OptBayesExpt(ParticlePDF):
         lazy = not want_best and not full and not sharded and not checked
         # (sharded: the 32-byte result record at the END of the workspace — include/obe_hip.h: OBE_WS_RESULT_TAIL —,
         # which the update calls between a sweep enqueued ahead and its collection do not touch)
-        tail = self._ws[-6:-2]
+        tail = self._ws[-6:-2] if sharded else None
 
         def launch(shifted, safe=False, speculative=False):
             # sharded: no host read here — the 32-byte result record is all-gathered from
