@@ -21,6 +21,9 @@
 #include "obe_models.h"
 #include "obe_moments.h"
 
+#ifndef OBE_NORM_UNROLL
+#define OBE_NORM_UNROLL 2
+#endif
 #ifndef OBE_UPDATE_ONE_PASS_DEFAULT
 #define OBE_UPDATE_ONE_PASS_DEFAULT 0
 #endif
@@ -245,14 +248,31 @@ __global__ __launch_bounds__(kBlock) void normalize_moments_kernel(const double*
 #pragma unroll
     for (int k = 0; k < NV; ++k) v[k] = 0.0;
     double acc = 0.0;
-    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (int64_t)gridDim.x * kBlock) {
-        double xi[D];
+    // U particles per trip: the loads of all of them are issued before the first is used (a wave of the one-per-CU
+    // grid otherwise has D + 1 loads in flight and ~50 dependent FP64 instructions between two round trips to
+    // HBM); they are accumulated in the order p, p + stride, ... of the one-at-a-time loop: the same bits.
+    constexpr int U = OBE_NORM_UNROLL;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += U * stride) {
+        double xi[U][D], t[U];
 #pragma unroll
-        for (int i = 0; i < D; ++i) xi[i] = x[(int64_t)i * ld + p];
-        const double w = nan_to_num(weights[p] / total);
-        weights[p] = w;
-        acc += nan_to_num(w * w);
-        accumulate_first_moments<D>(reinterpret_cast<double(&)[2 + 2 * D]>(v), w, xi);
+        for (int u = 0; u < U; ++u) {
+            const int64_t q = p + u * stride;
+            const int64_t qq = q < n ? q : p;
+#pragma unroll
+            for (int i = 0; i < D; ++i) xi[u][i] = x[(int64_t)i * ld + qq];
+            t[u] = weights[qq];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t q = p + u * stride;
+            if (q < n) {
+                const double w = nan_to_num(t[u] / total);
+                weights[q] = w;
+                acc += nan_to_num(w * w);
+                accumulate_first_moments<D>(reinterpret_cast<double(&)[2 + 2 * D]>(v), w, xi[u]);
+            }
+        }
     }
     if constexpr (!FOLD) {
         const double s = block_sum(acc, red);
@@ -583,16 +603,30 @@ __global__ __launch_bounds__(kBlock) void mask_renorm_moments_kernel(const doubl
     double v[2 + 2 * D];
 #pragma unroll
     for (int k = 0; k < 2 + 2 * D; ++k) v[k] = 0.0;
-    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (int64_t)gridDim.x * kBlock) {
-        double xi[D];
+    constexpr int U = OBE_NORM_UNROLL;       // (as in normalize_moments_kernel)
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += U * stride) {
+        double xi[U][D], t[U];
 #pragma unroll
-        for (int i = 0; i < D; ++i) xi[i] = x[(int64_t)i * ld + p];
-        double w = weights[p];
-        if (renorm) {
-            w = w / total;
-            weights[p] = w;
+        for (int u = 0; u < U; ++u) {
+            const int64_t q = p + u * stride;
+            const int64_t qq = q < n ? q : p;
+#pragma unroll
+            for (int i = 0; i < D; ++i) xi[u][i] = x[(int64_t)i * ld + qq];
+            t[u] = weights[qq];
         }
-        accumulate_first_moments<D>(v, w, xi);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t q = p + u * stride;
+            if (q < n) {
+                double w = t[u];
+                if (renorm) {
+                    w = w / total;
+                    weights[q] = w;
+                }
+                accumulate_first_moments<D>(v, w, xi[u]);
+            }
+        }
     }
     store_block_partials<2 + 2 * D, true>(v, partials_mom);
     __shared__ int last;

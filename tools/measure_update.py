@@ -22,7 +22,7 @@ timer = ctypes.c_void_p()
 lib.call("obe_timer_create", ctypes.byref(timer))
 st, yy, ss = np.zeros(4), np.zeros(4), np.ones(4) * 500.0
 st[0], yy[0] = 3.0, 49500.0 if k == 1 else 1400.0
-for n in (5000, 50000, 262144, 1 << 20, 1 << 22, 1 << 24):
+for n in (5000, 50000, 262144, 524288, 1 << 20, 1 << 22, 1 << 24):
     rows = [g.uniform(2, 4, (k, n)), g.uniform(400, 2000, (1, n)), g.normal(500, 1000, (1, n))]
     if d > k + 2:
         rows.append(g.exponential(500, (d - k - 2, n)) + 1.0)
