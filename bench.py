@@ -309,8 +309,11 @@ def collective_report(obe, shard, backend, world, rank, ns, steps, elapsed_local
     table = table.cpu().numpy().reshape(world, -1)
 
     def span(col):
-        return {"min": float(np.nanmin(table[:, col])), "max": float(np.nanmax(table[:, col])),
-                "per_rank": [float(v) for v in table[:, col]]}
+        vals = table[:, col]
+        if np.all(np.isnan(vals)):            # (a world of one gathers nothing in its cycles: null, not NaN, in the JSON)
+            return {"min": None, "max": None, "per_rank": [None] * len(vals)}
+        return {"min": float(np.nanmin(vals)), "max": float(np.nanmax(vals)),
+                "per_rank": [None if np.isnan(v) else float(v) for v in vals]}
 
     return {"backend": dist.get_backend(), "world_size_reported_by_backend": dist.get_world_size(),
             "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None),
