@@ -98,6 +98,7 @@ class Mirror:
         self._host = arr
         self._host_valid = True
         self._dev_valid = False
+        self.host_born = True          # this version's values were written by host code (not by a kernel)
         self.version = next(_STAMP)
 
     def host(self):
@@ -111,6 +112,7 @@ class Mirror:
 
     def mark_host_written(self):
         self._dev_valid = False
+        self.host_born = True
         self.version = next(_STAMP)
 
     # -- device side ---------------------------------------------------------
@@ -120,6 +122,7 @@ class Mirror:
         self._tensor = tensor
         self._dev_valid = True
         self._host_valid = False
+        self.host_born = False
         self.version = next(_STAMP)
 
     def tensor(self):
@@ -136,4 +139,5 @@ class Mirror:
         """A kernel modified the tensor in place."""
         self._dev_valid = True
         self._host_valid = False
+        self.host_born = False
         self.version = next(_STAMP)

@@ -843,19 +843,27 @@ class OptBayesExpt(ParticlePDF):
         return None
 
     def _settings_per_lane(self, n_draws=0):
-        """Settings one lane of the sweep kernel owns on this object's slice: at most (n_draws = 0, what a full
-        sweep gets), or in a reference-semantics sweep of n_draws draws (1 on the one-workgroup path)."""
+        """Settings one lane of the sweep kernel owns on a slice of this job: at most (n_draws = 0, what a full
+        sweep gets), or in a reference-semantics sweep of n_draws draws (1 on the one-workgroup path).  A sharded
+        object answers with the LARGEST figure over all ranks' slices (they differ by at most one setting, which
+        can straddle a threshold): everything decided from it — whether kappa can say "out of range" at all — is
+        then the same decision on every rank, and the ranks' collectives stay in step."""
         cache = self.__dict__.setdefault("_spt_local", {})
         spt = cache.get(n_draws)
         if spt is None:
-            n_local = max(self._s_end - self._s_begin, 1)
-            spt = cache[n_draws] = int(self._mlib.cdll.obe_sweep_settings_per_lane_for(n_local, n_draws))
+            lengths = {max(self._s_end - self._s_begin, 1)}
+            if self._shard is not None:
+                base, extra = divmod(self._n_settings, self._shard.world_size)       # (dist.shard_bounds)
+                lengths = {max(base, 1), base + 1} if extra else {max(base, 1)}
+            spt = cache[n_draws] = max(int(self._mlib.cdll.obe_sweep_settings_per_lane_for(n, n_draws))
+                                       for n in lengths)
         return spt
 
     def _sweep_needs_range_check(self, n_draws=0):
         """Whether this sweep's fast form can leave its exact range at all (then kappa is read back and a NaN
         repeats the sweep with the model's twin): the model has such a pair of forms and a lane owns enough
-        settings for its batched arithmetic to exist (DeviceModel.safe_sweep_min_spt)."""
+        settings for its batched arithmetic to exist (DeviceModel.safe_sweep_min_spt) — on ANY rank of a
+        sharded job, whose kappa is the worst over all ranks."""
         dm = self._device_model
         return bool(dm is not None and dm.safe_sweep and self._settings_per_lane(n_draws) >= dm.safe_sweep_min_spt)
 
@@ -864,18 +872,27 @@ class OptBayesExpt(ParticlePDF):
         of a cloud the host holds (the prior, set_pdf, user-written particles) whether their fast
         sweep form stays in range: if not, the sweep starts with the safe form instead of finding
         out by a poisoned fast attempt (the kernel's range check remains the guarantee; a wrong
-        'in range' costs one repeated sweep, a wrong 'out of range' is retried after SAFE_RETRY)."""
+        'in range' costs one repeated sweep, a wrong 'out of range' is retried after SAFE_RETRY).
+
+        A sharded object must take this decision identically on every rank (the form decides how many sweeps, and
+        with them how many all-gathers, a request takes): it looks only at clouds whose values were WRITTEN by
+        host code — which every rank of an SPMD script did alike —, never at one that merely happens to have been
+        read back on this rank, and at the whole settings grid instead of its own slice."""
         hint = getattr(self._device_model, "range_hint", None)
         pm = self._particles
         state = self._sweeps
+        sharded = self._shard is not None
         if hint is None or not pm._host_valid or state.range_hint_key == pm.version:
+            return
+        if sharded and not pm.host_born:
             return
         state.range_hint_key = pm.version
         n_local = self._s_end - self._s_begin
-        if n_local <= 0:
+        if n_local <= 0 and not sharded:
             return
         spt = self._settings_per_lane()
-        state.range_hint(hint(self.allsettings[:, self._s_begin:self._s_end], pm._host, self.cons, spt))
+        settings = self.allsettings if sharded else self.allsettings[:, self._s_begin:self._s_end]
+        state.range_hint(hint(settings, pm._host, self.cons, spt))
 
     def yvar_from_parameter_draws(self):
         """Variance of the model output over parameter draws, per setting: (C, N_s)

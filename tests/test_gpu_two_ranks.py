@@ -248,3 +248,78 @@ def test_bench_line_of_a_one_rank_rccl_world_carries_the_rccl_block(hip):
     assert 0.0 < c["k1_ms_per_sweep"]["max"] < c["cycle_ms"]["max"]
     assert 0.0 < c["combine_us_idle_median"]["max"] < 5000.0
     assert out["config"]["clock_warm_up_ms_before_the_warmup_steps"] >= 100.0
+
+
+def _narrow_log(obe_mod, shard, rank, hinted):
+    """Peaks 1e40 times narrower than the settings span on a grid of 1023 settings: two ranks get 512 and 511
+    settings — 2 and 1 settings per lane —, so only rank 0's kernels can leave the fast form's range at all.
+    Rank 0 alone also reads the cloud back after every update (as a script that logs on rank 0 does)."""
+    g = np.random.default_rng(3)
+    n = 3001
+    d = 2.5e-40
+    prior = np.vstack([g.uniform(2, 4, (1, n)), g.uniform(400, 2000, (1, n)), g.normal(500, 1000, (1, n))])
+    sv = (np.linspace(1.5, 4.5, 1023),)
+    sv[0][::97] = prior[0, :sv[0][::97].size]           # a few settings ON a particle's peak
+    o = obe_mod.OptBayesExpt(obe_mod.models.lorentzian(1), sv, prior.copy(), (d,), scale=False,
+                             utility_method="variance_full", default_noise_std=500.0, settings_shard=shard)
+    o.rng = np.random.default_rng(5)
+    if not hinted:
+        o._sweeps.range_hint_key = o._particles.version      # (as if the prior had been born on the device)
+    combines = [0]
+    if shard is not None:
+        inner = shard.combine_records
+
+        def counted(record, n_settings):
+            combines[0] += 1
+            return inner(record, n_settings)
+        shard.combine_records = counted
+    sim = np.random.default_rng(6)
+    log = []
+    for cyc in range(7):
+        if cyc == 4:
+            o.resample()                                 # a cloud born on the device ...
+        x = o.opt_setting()
+        log.append((int(o.last_setting_index), bool(o.last_sweep["safe"]), combines[0]))
+        y = 700.0 + 500.0 * sim.standard_normal()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            o.pdf_update((x, y, 500.0))
+        if rank == 0:
+            assert np.isfinite(np.asarray(o.particles)).all()      # ... which only rank 0 ever reads back
+    return log, o.utility(), o.sweep_state()
+
+
+def _narrow_worker(rank, world, port, ret):
+    import datetime
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    # (ranks that disagree about the number of all-gathers would wait for each other: an error after a minute)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
+    try:
+        import optbayesexpt_amd as obe_mod
+        ret[rank] = [_narrow_log(obe_mod, obe_mod.SettingsShard(), rank, hinted) for hinted in (True, False)]
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_with_unequal_slices_take_the_same_number_of_all_gathers(hip):
+    """Which form a sweep runs in, and whether kappa can say "out of range" at all, decides how many sweeps — and
+    all-gathers — one opt_setting() takes: on a sharded object these are decided from what every rank knows alike
+    (the largest settings-per-lane figure over all slices, the whole grid, clouds written by host code), never
+    from this rank's slice length or from whether this rank happens to hold the cloud on the host."""
+    import optbayesexpt_amd as obe_mod
+    refs = [_narrow_log(obe_mod, None, 0, hinted) for hinted in (True, False)]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_narrow_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    for h, ref in enumerate(refs):
+        a, b = ret[0][h], ret[1][h]
+        assert [l[2] for l in a[0]] == [l[2] for l in b[0]], (a[0], b[0])      # all-gathers, cycle by cycle
+        assert [l[:2] for l in a[0]] == [l[:2] for l in b[0]]                   # setting and form
+        assert [l[0] for l in a[0]] == [l[0] for l in ref[0]]
+        assert any(l[1] for l in a[0])                                         # the safe form was needed
+        np.testing.assert_allclose(a[1], ref[1], rtol=1e-11)
+        np.testing.assert_array_equal(a[1], b[1])
+        for key in ("form", "safe_streak", "unshifted"):
+            assert a[2][key] == b[2][key], (key, a[2], b[2])
