@@ -98,3 +98,32 @@ def test_argument_errors_are_reported_not_crashed(lib):
     assert rc == -1
     with pytest.raises(_lib.ObeHipError):
         lib.call("obe_argmax", None, 0, None, None, None, 0, None)
+
+
+def test_sharded_objects_decide_the_range_check_from_all_slices(lib):
+    """How many sweeps (and all-gathers) an opt_setting() of a sharded object takes hangs on whether kappa can
+    report "the fast form left its range", which hangs on the settings a lane owns, which hangs on the LENGTH of a
+    slice: 1023 settings over two ranks are 512 + 511 settings, 2 and 1 per lane (obe_sweep_settings_per_lane_for,
+    a host function).  Every rank must answer with the same figure — the largest over all slices."""
+    import types
+    from optbayesexpt_amd.dist import shard_bounds
+    from optbayesexpt_amd.obe_base import OptBayesExpt
+    per_lane = lib.cdll.obe_sweep_settings_per_lane_for
+    assert (per_lane(512, 0), per_lane(511, 0)) == (2, 1)
+    dm = models.lorentzian(1)
+    assert dm.safe_sweep and dm.safe_sweep_min_spt == 2
+    for n_settings, world in ((1023, 2), (4100, 4), (2047, 2), (65536, 8), (16384, 8), (7, 3)):
+        answers = []
+        for rank in range(world):
+            b, e = shard_bounds(n_settings, rank, world)
+            fake = types.SimpleNamespace(_s_begin=b, _s_end=e, _n_settings=n_settings, _mlib=lib, _device_model=dm,
+                                         _shard=types.SimpleNamespace(rank=rank, world_size=world))
+            fake._settings_per_lane = types.MethodType(OptBayesExpt._settings_per_lane, fake)
+            answers.append((OptBayesExpt._settings_per_lane(fake), OptBayesExpt._sweep_needs_range_check(fake)))
+        assert len(set(answers)) == 1, (n_settings, world, answers)
+        lengths = [shard_bounds(n_settings, r, world) for r in range(world)]
+        assert answers[0][0] == max(per_lane(e - b, 0) for b, e in lengths)
+    # an unsharded object answers for its own grid
+    fake = types.SimpleNamespace(_s_begin=0, _s_end=511, _n_settings=511, _mlib=lib, _device_model=dm, _shard=None)
+    fake._settings_per_lane = types.MethodType(OptBayesExpt._settings_per_lane, fake)
+    assert OptBayesExpt._settings_per_lane(fake) == 1 and not OptBayesExpt._sweep_needs_range_check(fake)
