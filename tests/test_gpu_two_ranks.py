@@ -323,3 +323,23 @@ def test_ranks_with_unequal_slices_take_the_same_number_of_all_gathers(hip):
         np.testing.assert_array_equal(a[1], b[1])
         for key in ("form", "safe_streak", "unshifted"):
             assert a[2][key] == b[2][key], (key, a[2], b[2])
+
+
+def test_a_slice_of_the_randomised_runs_through_real_ranks(hip):
+    """tools/soak_ranks.py: 300 random experiments through two real processes — uneven splits around the
+    settings-per-lane thresholds, peaks far narrower than the grid, full and reference-semantics sweeps,
+    good_setting / utility() / forced resamples / set_pdf, reads done by one rank only: nobody waits for a
+    collective the others never issue, every rank logs the same settings, forms and resample decisions."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_ranks.py"), "3", "31", "2", "300"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    m = re.search(r"ranks soak: 2 ranks, (\d+) experiments, (\d+) cycles, every rank the same log \((\d+) experiments "
+                  r"with sweeps in the safe form, (\d+) with resamples", r.stdout)
+    assert m, r.stdout[-2000:]
+    print(r.stdout.strip().splitlines()[-1])
+    assert int(m.group(1)) == 300 and int(m.group(2)) > 1000 and int(m.group(3)) >= 5 and int(m.group(4)) >= 50
