@@ -5,8 +5,8 @@
 `world` processes share this box's one GPU, torch.distributed backend gloo (RCCL wants one GPU per rank; the
 collective calls are the same).  Every rank draws the same recipes from the seed: grids whose split over the
 ranks is uneven and straddles the settings-per-lane thresholds of the sweep kernel, peaks of ordinary width and
-peaks 1e12 / 1e40 times narrower than the grid (the fast sweep forms leave their range), full sweeps and
-reference-semantics sweeps, opt_setting / good_setting / utility() in any order, resamples forced and triggered,
+peaks 1e12 / 1e40 times narrower than the grid (the fast sweep forms leave their range), full sweeps,
+reference-semantics sweeps and y-space utilities, cost hooks, the three speculation modes, opt_setting / good_setting / utility() in any order, resamples forced and triggered,
 set_pdf, and READS of the cloud or its moments done by one rank only (a script that logs on rank 0).  What is
 checked: nobody hangs (a mismatch in the number of collectives is an error after 60 s), every rank logs the same
 settings, forms and resample decisions cycle by cycle, the replicas stay identical (check_replicas), and the
@@ -30,7 +30,9 @@ def recipe(g):
     return dict(
         k=k, n=int(g.choice([700, 3000, 9000, 30000])),
         ns=int(g.choice([45, 301, 511, 1023, 1025, 2047, 2049, 4097, 5003, int(g.integers(40, 6000))])),
-        d=float(g.choice([0.05, 0.05, 0.05, 2.5e-12, 2.5e-40])), full=bool(g.random() < 0.7),
+        d=float(g.choice([0.05, 0.05, 0.05, 2.5e-12, 2.5e-40])),
+        method=str(g.choice(["variance_full"] * 13 + ["variance_approx"] * 5 + ["max_min", "pseudo_utility"])),
+        cost=int(g.integers(0, 8)), speculate=[True, False, "auto", "auto"][int(g.integers(0, 4))],
         noise=bool(g.random() < 0.3), threshold=float(g.choice([0.1, 0.5, 0.9])),
         cycles=int(g.integers(5, 14)), seed=int(g.integers(1 << 30)),
         acts=g.integers(0, 10, 16).tolist(), reads=g.integers(0, 6, 16).tolist(), readers=g.integers(0, 8, 16).tolist())
@@ -46,15 +48,31 @@ def run(obe, r, shard, rank):
     sv = (np.linspace(1.5, 4.5, r["ns"]),)
     sv[0][::37] = prior[0, :sv[0][::37].size]            # some settings ON a particle's peak
     cls = obe.OptBayesExptNoiseParameter if r["noise"] else obe.OptBayesExpt
-    kw = dict(utility_method="variance_full") if r["full"] else dict(n_draws=30)
+    kw = dict(utility_method=r["method"]) if r["method"] != "variance_approx" else dict(n_draws=30)
+    full = r["method"] == "variance_full"
     if r["noise"]:
         kw["noise_parameter_index"] = k + 2
     o = cls(obe.models.lorentzian(k), sv, prior.copy(), (r["d"],), scale=False, default_noise_std=500.0,
             settings_shard=shard, resample_threshold=r["threshold"], **kw)
+    o.tuning_parameters["speculative_sweep"] = r["speculate"]
+    if r["cost"] == 0:                                   # a cost hook: per-setting values / a scalar
+        per_setting = 1.0 + np.linspace(0.0, 1.0, r["ns"]) ** 2
+        o.cost_estimate = lambda: per_setting
+    elif r["cost"] == 1:
+        o.cost_estimate = lambda: 2.5
     o.rng = np.random.default_rng(r["seed"] + 1)
     sim = np.random.default_rng(r["seed"] + 2)
     true = prior[:, 0]
     log = []
+    try:
+        return _cycles(obe, o, r, g, sim, prior, true, full, shard, rank, log)
+    except (ValueError, np.linalg.LinAlgError) as exc:
+        exc.partial_log = log
+        raise
+
+
+def _cycles(obe, o, r, g, sim, prior, true, full, shard, rank, log):
+    n = r["n"]
     for c in range(r["cycles"]):
         act, read, reader = r["acts"][c], r["reads"][c], r["readers"][c]
         if act == 0:
@@ -70,7 +88,7 @@ def run(obe, r, shard, rank):
             x = o.opt_setting()
         else:
             x = o.opt_setting()
-        sweep = dict(o.last_sweep) if r["full"] else {}
+        sweep = dict(o.last_sweep) if full else {}
         log.append((int(o.last_setting_index), bool(sweep.get("safe", False)), bool(sweep.get("shifted", True))))
         y = float(np.atleast_1d(o.model_function(x, true, (max(r["d"], 0.05),)))[0]) + 500.0 * sim.standard_normal()
         o.pdf_update((x, y) if r["noise"] else (x, y, 500.0))
@@ -113,12 +131,12 @@ def worker(rank, world, port, minutes, seed, max_recipes, ret):
                 mine = run(obe, r, obe.SettingsShard(), rank)
                 err = None
             except (ValueError, np.linalg.LinAlgError) as exc:      # (numpy's own refusals: every rank alike)
-                mine, err = None, f"{type(exc).__name__}: {exc}"[:80]
+                mine, err = None, (f"{type(exc).__name__}: {exc}"[:80], exc.partial_log)
             try:
                 ref = run(obe, r, None, 0)
                 ref_err = None
             except (ValueError, np.linalg.LinAlgError) as exc:
-                ref, ref_err = None, f"{type(exc).__name__}: {exc}"[:80]
+                ref, ref_err = None, (f"{type(exc).__name__}: {exc}"[:80], exc.partial_log)
             everyone = [None] * world
             dist.all_gather_object(everyone, (mine, err))
             for other in everyone[1:]:
@@ -126,12 +144,23 @@ def worker(rank, world, port, minutes, seed, max_recipes, ret):
                 if mine is not None:
                     assert other[0][0] == everyone[0][0][0], (r, everyone[0][0][0], other[0][0])
                     np.testing.assert_array_equal(other[0][1], everyone[0][0][1])
-            assert (err is None) == (ref_err is None), (r, err, ref_err)
+            strip = lambda lg: [e[0] if isinstance(e, tuple) else e for e in lg]       # noqa: E731
+            if (err is None) != (ref_err is None):
+                # refused on one side only: legitimate only if the two runs had parted at a tie before (then they
+                # are different experiments from there on)
+                a = strip(mine[0] if mine is not None else err[1])
+                b = strip(ref[0] if ref is not None else ref_err[1])
+                m = min(len(a), len(b))
+                assert a[:m] != b[:m], (r, err and err[0], ref_err and ref_err[0], a, b)
+                first = next(i for i in range(m) if a[i] != b[i])
+                assert first % 2 == 0, (r, first, a, b)
+                ties += 1
+                done += 1
+                continue
             if mine is not None:
                 # against the unsharded run: settings and resample decisions (the FORM may differ — a lane of the
                 # whole grid owns more settings than a lane of a slice, so its fast form leaves its range earlier)
-                a = [e[0] if isinstance(e, tuple) else e for e in mine[0]]
-                b = [e[0] if isinstance(e, tuple) else e for e in ref[0]]
+                a, b = strip(mine[0]), strip(ref[0])
                 if a != b:
                     first = next(i for i, (u, v) in enumerate(zip(a, b)) if u != v)
                     # a different setting: only as a tie (or a draw at the edge of a CDF step) moved by the
