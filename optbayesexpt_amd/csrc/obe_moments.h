@@ -120,6 +120,14 @@ constexpr int kFoldBatch = 4;
 __device__ __forceinline__ double load_published(const double* p) { return load_published_f64(p); }
 // (BATCH values per wave and trip: a 4-wave workgroup that folds inside the producing launch takes 8 at a
 // time to keep as many loads in flight as the 16-wave fold kernels do with 4)
+// Round 5 (late): the loads of ROWS = 4 row groups x BATCH values are ISSUED TOGETHER, then added in the order
+// the one-row-at-a-time loop added them (lane L: rows L, L + 64, L + 128, ...: the same bits).  The old loop's
+// `if (k < nv) s += load` compiled to load / s_waitcnt vmcnt(0) / add for every single value: the 256 rows x 23
+// values of a 10-parameter update were 24 round trips to another XCD's L2 one behind the other (~10 us of the
+// normalisation launch's 23), the 9 values of a 3-parameter one 12.  Rows and values beyond the end are loaded
+// from the last valid one and not added.  Callers that know nv at compile time pass BATCH = ceil(nv / waves): one trip, no
+// slot that is never valid.
+constexpr int kFoldRows = 4;
 template <int NT = kFoldThreads, bool PUBLISHED = false, int BATCH = kFoldBatch>
 __device__ __forceinline__ void fold_values_block(const double* partials, int nb, int nv, double* vals) {
     constexpr int NW = NT / kWave;
@@ -128,11 +136,28 @@ __device__ __forceinline__ void fold_values_block(const double* partials, int nb
         double s[BATCH];
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) s[u] = 0.0;
-        for (int b = lane; b < nb; b += kWave) {
+        for (int base = 0; base < nb; base += kWave * kFoldRows) {
+            double v[kFoldRows][BATCH];
 #pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                const int k = k0 + u * NW;
-                if (k < nv) s[u] += PUBLISHED ? load_published(partials + (int64_t)b * nv + k) : partials[(int64_t)b * nv + k];
+            for (int r = 0; r < kFoldRows; ++r) {
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u) {
+                    // (clamped, not skipped: every load is a real one whose value the selection below consumes —
+                    // an sc1 load the compiler knows to be unused still has to be performed, into a register that
+                    // is reused at once, and that costs a full s_waitcnt per row group)
+                    const int b = base + r * kWave + lane, k = k0 + u * NW;
+                    const double* q = partials + (int64_t)(b < nb ? b : nb - 1) * nv + (k < nv ? k : nv - 1);
+                    v[r][u] = PUBLISHED ? load_published(q) : *q;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < kFoldRows; ++r) {
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u) {
+                    const int b = base + r * kWave + lane, k = k0 + u * NW;
+                    const double t = s[u] + v[r][u];
+                    s[u] = b < nb && k < nv ? t : s[u];
+                }
             }
         }
 #pragma unroll

@@ -211,7 +211,7 @@ __device__ __forceinline__ void publish_and_fold_update(double (&v)[3 + 2 * D], 
     __shared__ int last;
     if (!arrive_last<false>(fold.counter, &last)) return;
     __shared__ double raw[kMaxMomentValues + 1];
-    fold_values_block<kBlock, true>(partials_mom, gridDim.x, NV, raw);
+    fold_values_block<kBlock, true, (NV + kBlock / kWave - 1) / (kBlock / kWave)>(partials_mom, gridDim.x, NV, raw);
     // delivery by ONE wave: K3 block to the device copy and to the host, one system-scope fence, then the
     // word the host watches (wait_host_word) — [0] sum t, [1] sum w'^2, [2..) K3 block
     if (threadIdx.x < kWave) {
@@ -228,7 +228,7 @@ __device__ __forceinline__ void publish_and_fold_update(double (&v)[3 + 2 * D], 
             }
         }
         if (fold.host_out) {
-            host_results_before_flag();
+            host_results_before_flag();     // (measured without it, round 5: no difference — the words are watched one by one anyway)
             if (threadIdx.x == 0) fold.host_out[1] = b;
         }
     }
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(kBlock) void mask_renorm_moments_kernel(const doubl
     __shared__ int last;
     if (!arrive_last<false>(mf.counter, &last)) return;
     __shared__ double raw[kMaxMomentValues];
-    fold_values_block<kBlock, true, 8>(partials_mom, gridDim.x, 2 + 2 * D, raw);
+    fold_values_block<kBlock, true, (2 + 2 * D + kBlock / kWave - 1) / (kBlock / kWave)>(partials_mom, gridDim.x, 2 + 2 * D, raw);
     if (threadIdx.x < kWave) {
         derive_first_moments(raw, D, mf.mom_out, mf.host_mom);
         if (mf.host_changed) {
