@@ -203,9 +203,26 @@ __device__ __forceinline__ double block_sum_all(double v, double* red) {
 }
 
 // Deterministic sum of a small device array by one block (every thread gets it).
+// (four elements per thread and trip, their loads issued together and added in the order i, i + nt, ... of the
+// one-at-a-time loop — the same bits: the 768 partial sums of the update's first pass used to be three dependent
+// round trips at the start of EVERY workgroup of its second pass)
 __device__ __forceinline__ double block_sum_array(const double* a, int n, double* red) {
     double v = 0.0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) v += a[i];
+    const int nt = blockDim.x;
+    for (int base = 0; base < n; base += 4 * nt) {
+        double x[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = base + r * nt + (int)threadIdx.x;
+            x[r] = a[i < n ? i : n - 1];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = base + r * nt + (int)threadIdx.x;
+            const double t = v + x[r];
+            v = i < n ? t : v;
+        }
+    }
     return block_sum_all(v, red);
 }
 

@@ -541,7 +541,9 @@ __global__ __launch_bounds__(FG * WS) void sweep_finalize(const double* __restri
         double a1 = 0.0, a2 = 0.0;
         if (s < ns) {
             int k = grp;
-            for (; k + 3 * FG < nchunks; k += 4 * FG) {        // 8 loads in flight
+            // (8 loads in flight.  Round 5, measured and not kept: 16 per trip — the compiler splits them 5 + 11 with a
+            // full wait in between, two round trips as before; a rank's 2048 x 1024 chunks: 12.0 us against 11.2)
+            for (; k + 3 * FG < nchunks; k += 4 * FG) {
                 double t1[4], t2[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -636,15 +638,32 @@ __global__ __launch_bounds__(kBlock) void argmax_fold(const double* __restrict__
                                                       const unsigned* abort = nullptr) {
     if (sweep_aborted(abort)) return;       // (the armed host words stay armed: nobody reads this result)
     Best best{-INFINITY, INT64_MAX};
-    for (int b = threadIdx.x; b < nb; b += kBlock) {
-        Best cand{bv[b], bi[b]};
-        if (better(cand, best)) best = cand;
+    double kmax = 0.0;                  // worst cancellation factor; NaN is sticky
+    // (the partials of four rounds of threads — value, index, kappa: up to 12 loads — in flight together; compared in
+    // the order b, b + 256, ... of the one-at-a-time loops: the same winner.  1024 partials used to be 8 dependent
+    // round trips in a one-workgroup kernel whose whole duration is latency)
+    for (int base = 0; base < nb; base += 4 * kBlock) {
+        double v[4], kk[4];
+        int64_t ix[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = base + r * kBlock + (int)threadIdx.x, bc = b < nb ? b : nb - 1;
+            v[r] = bv[bc];
+            ix[r] = bi[bc];
+            kk[r] = bk ? bk[bc] : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = base + r * kBlock + (int)threadIdx.x;
+            if (b < nb) {
+                const Best cand{v[r], ix[r]};
+                if (better(cand, best)) best = cand;
+                kmax = kappa_worst(kmax, kk[r]);
+            }
+        }
     }
     block_argmax(best, out_v, out_i);   // gridDim.x == 1 -> writes element 0
     __shared__ double kred[kBlock];
-    double kmax = 0.0;                  // worst cancellation factor; NaN is sticky
-    if (bk)
-        for (int b = threadIdx.x; b < nb; b += kBlock) kmax = kappa_worst(kmax, bk[b]);
     kred[threadIdx.x] = kmax;
     __syncthreads();
     for (int o = kBlock / 2; o > 0; o >>= 1) {
