@@ -239,9 +239,23 @@ __device__ __forceinline__ T block_exclusive_scan_inplace(T* __restrict__ data, 
     for (int64_t i = b; i < e; ++i) sum = sum + data[i];
     lds[t] = sum;
     __syncthreads();
-    if (t == 0) {                       // <= 256 serial adds in LDS: ~1 us
+    if (t == 0) {
+        // <= 256 serial adds.  Eight LDS reads are issued together and then added one after the other — the same
+        // left-to-right sum: read / wait / add / write per element made this loop ~100 cycles per element, 11 us
+        // of a 13 us kernel for the 256 block sums of a 524 288-particle CDF (rocprofv3 trace, round 5).
         T run = T(0);
-        for (int k = 0; k < nt; ++k) {
+        int k = 0;
+        for (; k + 8 <= nt; k += 8) {
+            T s[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] = lds[k + j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                lds[k + j] = run;
+                run = run + s[j];
+            }
+        }
+        for (; k < nt; ++k) {
             const T s = lds[k];
             lds[k] = run;
             run = run + s;

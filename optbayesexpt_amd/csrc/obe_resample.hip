@@ -109,8 +109,14 @@ __global__ __launch_bounds__(kBlock) void scan_offsets(double* __restrict__ bloc
         for (int64_t i = threadIdx.x; i < nb; i += kBlock) m = fmin(m, block_mins[i]);
     mins[threadIdx.x] = m;
     const double total = block_exclusive_scan_inplace<double>(block_sums, nb, lds);     // (synchronises)
+    // (a tree, not thread 0 walking 255 LDS words one read at a time: ~4 us of this one-workgroup kernel; the minimum
+    // does not depend on the order)
+    for (int o = kBlock / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) mins[threadIdx.x] = fmin(mins[threadIdx.x], mins[threadIdx.x + o]);
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
-        for (int i = 1; i < kBlock; ++i) m = fmin(m, mins[i]);
+        m = mins[0];
         scalars[0] = total;
         scalars[1] = total_for_validation(total, m);
         if (host_total) *host_total = scalars[1];
