@@ -408,7 +408,17 @@ __global__ __launch_bounds__(kBlock) void resample_kernel(NudgeArgs na, const do
         const int64_t p = p0 + threadIdx.x;
         const int64_t run = (n - p0 < kBlock ? n - p0 : kBlock) * D;
         __syncthreads();       // the previous trip's rows have been consumed
-        for (int64_t e = threadIdx.x; e < run; e += kBlock) zs[e] = z[p0 * D + e];
+        if (run == (int64_t)kBlock * D) {
+            // a full tile: the D loads of a thread in flight together (as a loop it compiled to load / wait / LDS
+            // store, D dependent round trips to HBM in front of every gather — 10 of them for the 10-parameter model)
+            double t[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) t[j] = z[p0 * D + threadIdx.x + j * kBlock];
+#pragma unroll
+            for (int j = 0; j < D; ++j) zs[threadIdx.x + j * kBlock] = t[j];
+        } else {
+            for (int64_t e = threadIdx.x; e < run; e += kBlock) zs[e] = z[p0 * D + e];
+        }
         __syncthreads();
         if (p >= n) continue;
         int64_t src = idx[p];

@@ -445,6 +445,26 @@ __global__ __launch_bounds__(kBlock) void zig_compact_kernel(const uint8_t* __re
     __shared__ double sval[kFlagTile];
     __shared__ double sout[kFlagTile];
     const int64_t tile0 = (int64_t)blockIdx.x * kFlagTile;
+    // This tile's first rank = the number of starts in all tiles before it.  Round 5: every workgroup adds up the
+    // tile counts in front of it itself (zig_starts_kernel left them in block_off[]; <= ~2600 values = 10 KB that
+    // live in L2, exact integer arithmetic) instead of a one-workgroup exclusive scan in a launch of its own
+    // between the two kernels: 8 us + a launch boundary off the longest chain of a resample.  The loads — four
+    // per thread and trip, in flight together — are issued FIRST, ahead of the tile's own loads from HBM: as a
+    // loop of one load / wait / add behind the tile scan they were up to ten dependent round trips per workgroup.
+    uint32_t before = 0;
+    for (unsigned base = 0; base < blockIdx.x; base += 4 * kBlock) {
+        uint32_t x[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned j = base + r * kBlock + threadIdx.x;
+            x[r] = block_off[j < blockIdx.x ? j : 0];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned j = base + r * kBlock + threadIdx.x;
+            before += j < blockIdx.x ? x[r] : 0u;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < kFlagItems; ++j) {
         const int64_t i = tile0 + threadIdx.x + j * kBlock;
@@ -457,13 +477,6 @@ __global__ __launch_bounds__(kBlock) void zig_compact_kernel(const uint8_t* __re
 #pragma unroll
     for (int k = 0; k < kFlagItems; ++k) f[k] = v[k] = (uint32_t)((packed >> (8 * k)) & 1u);
     const uint32_t total = flag_tile_scan(v, lds);       // (contains the barriers that publish sval)
-    // This tile's first rank = the number of starts in all tiles before it.  Round 5: every workgroup adds up the
-    // tile counts in front of it itself (zig_starts_kernel left them in block_off[]; <= ~2600 values = 10 KB that
-    // live in L2, ten independent loads per thread at most, exact integer arithmetic) instead of a one-workgroup
-    // exclusive scan in a launch of its own between the two kernels: 8 us + a launch boundary off the longest
-    // chain of a resample.
-    uint32_t before = 0;
-    for (unsigned j = threadIdx.x; j < blockIdx.x; j += kBlock) before += block_off[j];
     for (int o = kWave / 2; o > 0; o >>= 1) before += __shfl_down(before, o, kWave);
     __shared__ uint32_t woff[kBlock / kWave];
     __syncthreads();                                     // (lds[] of the tile scan has been consumed)
