@@ -769,13 +769,32 @@ __global__ __launch_bounds__(kBlock) void sweep_small_kernel(SweepArgs a, UtilAr
 __global__ __launch_bounds__(kBlock) void yspace_var_kernel(const double* __restrict__ ysp, int64_t nd,
                                                             int64_t row /* C*Ns */, double* __restrict__ yvar) {
     for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < row; e += (int64_t)gridDim.x * kBlock) {
+        // (eight draws' loads in flight together, added in draw order as before: one load / wait / add per draw
+        // made the 30 draws of a reference-semantics cycle 60 dependent round trips)
         double sum = 0.0;
-        for (int64_t d = 0; d < nd; ++d) sum += ysp[d * row + e];
+        for (int64_t d0 = 0; d0 < nd; d0 += 8) {
+            double t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = ysp[(d0 + j < nd ? d0 + j : nd - 1) * row + e];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const double n = sum + t[j];
+                sum = d0 + j < nd ? n : sum;
+            }
+        }
         const double mean = sum / (double)nd;
         double acc = 0.0;
-        for (int64_t d = 0; d < nd; ++d) {
-            const double dv = ysp[d * row + e] - mean;
-            acc += dv * dv;
+        for (int64_t d0 = 0; d0 < nd; d0 += 8) {
+            double t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = ysp[(d0 + j < nd ? d0 + j : nd - 1) * row + e];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const double dv = t[j] - mean;
+                const double sq = dv * dv;
+                const double n = acc + sq;
+                acc = d0 + j < nd ? n : acc;
+            }
         }
         yvar[e] = acc / (double)nd;
     }

@@ -53,10 +53,16 @@ __global__ __launch_bounds__(kBlock) void maxmin_kernel(const double* __restrict
                                                         double* __restrict__ out) {
     for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < row; e += (int64_t)gridDim.x * kBlock) {
         double lo = ysp[e], hi = lo;
-        for (int64_t d = 1; d < nd; ++d) {
-            const double v = ysp[d * row + e];
-            lo = v < lo ? v : lo;          // np.max / np.min propagate NaN; a NaN model output is
-            hi = v > hi ? v : hi;          // outside the supported domain here
+        for (int64_t d0 = 1; d0 < nd; d0 += 8) {           // (eight draws' loads in flight together)
+            double t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = ysp[(d0 + j < nd ? d0 + j : nd - 1) * row + e];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {                  // (a clamped repeat of the last draw changes nothing)
+                const double v = t[j];
+                lo = v < lo ? v : lo;          // np.max / np.min propagate NaN; a NaN model output is
+                hi = v > hi ? v : hi;          // outside the supported domain here
+            }
         }
         const double span = hi - lo;
         out[e] = span * span;
