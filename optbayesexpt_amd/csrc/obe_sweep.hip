@@ -557,10 +557,22 @@ __global__ __launch_bounds__(FG * WS) void sweep_finalize(const double* __restri
                     a2 += t2[u];
                 }
             }
-            for (; k < nchunks; k += FG) {
-                const int64_t o = ((int64_t)k * nc + c) * ns + s;
-                a1 += part1[o];
-                a2 += part2[o];
+            if (k < nchunks) {          // the last 1-3 chunks of this group: one batch (clamped, added selectively)
+                double t1[3], t2[3];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int kk = k + u * FG;
+                    const int64_t o = ((int64_t)(kk < nchunks ? kk : k) * nc + c) * ns + s;
+                    t1[u] = part1[o];
+                    t2[u] = part2[o];
+                }
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const double n1 = a1 + t1[u], n2 = a2 + t2[u];
+                    const bool ok = k + u * FG < nchunks;
+                    a1 = ok ? n1 : a1;
+                    a2 = ok ? n2 : a2;
+                }
             }
         }
         acc1[c][grp][lane] = a1;
