@@ -270,7 +270,7 @@ def launch_ranks(n, argv):
     return 0
 
 
-def collective_report(obe, shard, backend, world, rank, ns, steps, elapsed_local, k1_total_ms, k1_launches):
+def collective_report(obe, shard, backend, world, rank, ns, steps, elapsed_local, k1_total_ms, k1_launches, k1_cycles):
     """The "rccl" block of an N > 1 line: proof that the communicator saw N ranks, and where each rank's time
     went.  (1) an all-gather in which every rank contributes its rank id; (2) the arg-max combine of the timed
     cycles: device microseconds between this rank's record being ready and everybody's having arrived (events
@@ -298,7 +298,7 @@ def collective_report(obe, shard, backend, world, rank, ns, steps, elapsed_local
     in_cycle_host = [b for _, b in timing]
     cycle_ms = 1e3 * elapsed_local / steps
     k1_ms = k1_total_ms / max(k1_launches, 1)
-    k1_per_cycle = k1_total_ms / steps
+    k1_per_cycle = k1_total_ms / max(k1_cycles, 1)       # (K1 and the combine: events in k1_cycles further cycles)
     mine = torch.tensor([cycle_ms, k1_ms, cycle_ms - k1_per_cycle,
                          float(np.median(in_cycle_dev)) if in_cycle_dev else float("nan"),
                          float(np.max(in_cycle_dev)) if in_cycle_dev else float("nan"),
@@ -318,7 +318,11 @@ def collective_report(obe, shard, backend, world, rank, ns, steps, elapsed_local
     return {"backend": dist.get_backend(), "world_size_reported_by_backend": dist.get_world_size(),
             "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None),
             "all_gather_rank_ids": ids, "all_gather_rank_ids_ok": ids == list(range(world)),
-            "combines_in_timed_steps": int(table[0, 6]), "sweep_launches_in_timed_steps": int(table[0, 7]),
+            "instrumented_cycles": int(k1_cycles),
+            "instrumented_cycles_note": "the timed steps run without events; K1 (events around the sweep kernel) and the "
+                                        "combine (events around the all-gather) are measured in this many further cycles "
+                                        "of the same experiment right after them",
+            "combines_in_instrumented_cycles": int(table[0, 6]), "sweep_launches_in_instrumented_cycles": int(table[0, 7]),
             "cycle_ms": span(0), "k1_ms_per_sweep": span(1), "non_k1_ms_per_cycle": span(2),
             "combine_us_in_cycle_median": span(3), "combine_us_in_cycle_max": span(4),
             "combine_us_in_cycle_note": "events on the launch stream around the 32-byte all-gather of the arg-max "
@@ -537,10 +541,14 @@ def main():
     for k in range(max(args.warmup, 0)):
         one_step(boundary=k == args.warmup - 1)
     barrier()
-    # K1 inside the timed cycles: HIP events around every sweep-kernel launch on its own stream
-    obe._mlib.call("obe_sweep_timing", 1, None, None)
-    if shard is not None:
-        shard.timing = []                 # ... and events around every arg-max all-gather (dist.SettingsShard.timing)
+    # K1 inside the timed cycles: HIP events around every sweep-kernel launch on its own stream.  One GPU: in the
+    # timed steps themselves (two barrier packets per sweep: 0.1 % of a 14 ms cycle).  Sharded (N > 1): a rank's
+    # cycle is 1.3-2 ms and carries a second pair of events around the arg-max all-gather — ~25 us per cycle, 1-2 %
+    # that the one-GPU line does not pay and that would come off the scaling ratio —, so the timed steps run
+    # uninstrumented and K1 / the combine are measured in further cycles of the same experiment right after them.
+    instrument_in_timed_steps = not use_dist
+    if instrument_in_timed_steps:
+        obe._mlib.call("obe_sweep_timing", 1, None, None)
     t0 = time.perf_counter()
     resamples = 0
     step_ms, step_resampled = [], []
@@ -552,6 +560,14 @@ def main():
         resamples += r
     barrier()
     elapsed = time.perf_counter() - t0
+    k1_cycles = args.steps
+    if not instrument_in_timed_steps:
+        k1_cycles = max(4, min(args.steps, 12))
+        obe._mlib.call("obe_sweep_timing", 1, None, None)
+        shard.timing = []                 # events around every arg-max all-gather (dist.SettingsShard.timing)
+        for k in range(k1_cycles):
+            one_step(boundary=k == k1_cycles - 1)
+        barrier()
     k1_total_ms, k1_launches = ctypes.c_double(0.0), ctypes.c_int64(0)
     obe._mlib.call("obe_sweep_timing", 0, ctypes.byref(k1_total_ms), ctypes.byref(k1_launches))
     rccl = None
@@ -561,7 +577,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         rccl = collective_report(obe, shard, backend, world, rank, ns, args.steps, elapsed_local,
-                                 k1_total_ms.value, k1_launches.value)
+                                 k1_total_ms.value, k1_launches.value, k1_cycles)
 
     n_draws = obe.N_DRAWS if obe.utility_method == "variance_approx" else n_p
     evals_per_step = ns * n_draws + n_p
@@ -605,8 +621,11 @@ def main():
                 "frac": flop / k1_s / 1e12 / FP64_VALU_PEAK_TFLOPS,
                 "flop_per_eval": FLOP_PER_EVAL[model], "evals_per_launch": n_local * n_p,
                 "launch_ms": ms.value,
-                "launch_timing": (f"HIP events around each of the {k1_launches.value} sweep-kernel launches of the timed "
-                                  "steps, on the launch stream" if in_cycle else
+                "launch_timing": ((f"HIP events around each of the {k1_launches.value} sweep-kernel launches of the timed "
+                                   "steps, on the launch stream" if instrument_in_timed_steps else
+                                   f"HIP events around each of the {k1_launches.value} sweep-kernel launches of {k1_cycles} "
+                                   "further cycles right after the timed steps, on the launch stream (N > 1: the timed "
+                                   "steps run uninstrumented)") if in_cycle else
                                   "5 back-to-back launches between two HIP events on the launch stream"),
                 "launch_ms_back_to_back": k1_back_to_back_ms,
                 "variant": "shifted" if shifted else "unshifted", "form": "safe" if safe_form else "fast",
