@@ -508,6 +508,7 @@ def main():
             os.close(saved)
         from optbayesexpt_amd import SettingsShard
         shard = SettingsShard()
+        shard.always_collective = True        # (--force-dist, a world of one: still through the backend's collectives)
 
     from optbayesexpt_amd import _lib
     from optbayesexpt_amd.particlepdf import _ptr

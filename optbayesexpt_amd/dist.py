@@ -62,6 +62,10 @@ class SettingsShard:
         #: on the launch stream around the all-gather —, host microseconds of the whole call incl. the wait
         #: for this rank's own sweep)
         self.timing = None
+        #: True: a world of ONE still goes through the backend's collectives (all-gather of the record from the
+        #: workspace view into the page-locked landing zone, row gathers, broadcasts) instead of the local
+        #: shortcuts — how the RCCL code path is executed on a one-GPU box (tests, `bench.py --force-dist`)
+        self.always_collective = False
         self._starts = {}             # n_settings -> first global index of every rank's slice
 
     def bounds(self, n_settings):
@@ -70,7 +74,10 @@ class SettingsShard:
     def connected(self):
         """True when there are other ranks to talk to (a shard built with an explicit rank / world_size in
         a process without torch.distributed — one slice of a sweep computed on its own — has none)."""
-        return self.world_size > 1 and dist.is_available() and dist.is_initialized()
+        return (self.world_size > 1 or self.always_collective) and dist.is_available() and dist.is_initialized()
+
+    def _through_backend(self):
+        return self.always_collective and dist.is_available() and dist.is_initialized()
 
     def _comm_device(self, device):
         backend = dist.get_backend(self.group)
@@ -100,7 +107,7 @@ class SettingsShard:
         """(world, 4) host array of every rank's record (valid until the next call: the page-locked landing zone
         itself — combine_records() consumes it at once)."""
         w = self.world_size
-        if w == 1:
+        if w == 1 and not self._through_backend():
             return record.cpu().numpy().reshape(1, 4)
         dev = self._comm_device(record.device)        # nccl: stay on the GPU; gloo: host tensors
         bufs = self._record_bufs
@@ -137,7 +144,7 @@ class SettingsShard:
         """Rank 0's host array on every rank (same shape and dtype everywhere): used for random
         draws that must be taken once for the whole job."""
         values = np.ascontiguousarray(values)
-        if self.world_size == 1:
+        if self.world_size == 1 and not self._through_backend():
             return values
         dev = self._comm_device(device)
         t = torch.from_numpy(values.copy()).to(dev)
@@ -147,7 +154,7 @@ class SettingsShard:
 
     def broadcast_object_from_rank0(self, obj, device="cpu"):
         """Rank 0's picklable object on every rank (generator states: a dict with 128-bit integers)."""
-        if self.world_size == 1:
+        if self.world_size == 1 and not self._through_backend():
             return obj
         box = [obj if self.rank == 0 else None]
         src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
@@ -158,7 +165,7 @@ class SettingsShard:
     def all_gather_int64(self, values, device="cpu"):
         """(world, len(values)) host array of every rank's int64 values (replica checks)."""
         v = np.ascontiguousarray(values, dtype=np.int64)
-        if self.world_size == 1:
+        if self.world_size == 1 and not self._through_backend():
             return v.reshape(1, -1)
         dev = self._comm_device(device)
         gathered = torch.empty(self.world_size * v.size, dtype=torch.int64, device=dev)
@@ -177,7 +184,7 @@ class SettingsShard:
     def gather_rows(self, local, n_settings):
         """All ranks' (rows, n_local) slices assembled into a host (rows, n_settings) array."""
         rows = local.shape[0]
-        if self.world_size == 1:
+        if self.world_size == 1 and not self._through_backend():
             return local.cpu().numpy()
         dev = self._comm_device(local.device)
         widest = shard_bounds(n_settings, 0, self.world_size)

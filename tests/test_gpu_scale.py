@@ -388,8 +388,10 @@ def test_c1_literal_workload_forty_cycles(obe):
 
 def test_sharded_path_through_rccl_world_of_one(obe):
     """The sharded opt_setting code path with a real NCCL (= RCCL) process group of one rank:
-    the device-side all-gather of the result record, the row gather and the barrier run on
-    the GPU exactly as they do with N ranks (N > 1 is covered with gloo on the CPU)."""
+    the device-side all-gather of the result record (straight from the workspace view into the page-locked
+    landing zone), the row gather, the generator broadcast and the replica check run through the backend on
+    the GPU exactly as they do with N ranks — `always_collective` switches the world-of-one shortcuts off
+    (N > 1 is covered with gloo, in real processes)."""
     import torch
     import torch.distributed as dist
     import bench as bench_mod
@@ -400,9 +402,18 @@ def test_sharded_path_through_rccl_world_of_one(obe):
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
         created = True
+    inner = dist.all_gather_into_tensor
     try:
         settings, prior, cons, true, sigma = bench_mod.make_workload("c2")
-        sharded = bench_mod.build_obe("c2", obe.SettingsShard(), settings, prior.copy(), cons)
+        shard = obe.SettingsShard()
+        shard.always_collective = True          # no local shortcuts for a world of one: every collective goes through RCCL
+        calls = []
+
+        def counted(out, inp, *a, **kw):
+            calls.append((tuple(inp.shape), inp.device.type))
+            return inner(out, inp, *a, **kw)
+        dist.all_gather_into_tensor = counted
+        sharded = bench_mod.build_obe("c2", shard, settings, prior.copy(), cons)
         plain = bench_mod.build_obe("c2", None, settings, prior.copy(), cons)
         for o in (sharded, plain):
             o.rng = np.random.default_rng(3)
@@ -416,8 +427,13 @@ def test_sharded_path_through_rccl_world_of_one(obe):
             o.rng = np.random.default_rng(11)
         for _ in range(3):                      # good_setting through the gathered utility vector
             assert sharded.good_setting(pickiness=19) == plain.good_setting(pickiness=19)
+        assert sharded.check_replicas()
         dist.barrier()
+        # the 32-byte records went through the backend from device memory (>= 6 sweeps), and so did the row gathers
+        assert sum(1 for shape, dev in calls if shape == (4,) and dev == "cuda") >= 6, calls
+        assert any(shape != (4,) and dev == "cuda" for shape, dev in calls), calls
     finally:
+        dist.all_gather_into_tensor = inner
         if created:
             dist.destroy_process_group()
 
