@@ -428,6 +428,8 @@ def test_sharded_path_through_rccl_world_of_one(obe):
         for _ in range(3):                      # good_setting through the gathered utility vector
             assert sharded.good_setting(pickiness=19) == plain.good_setting(pickiness=19)
         assert sharded.check_replicas()
+        x_random = sharded.random_setting()                  # rank 0's draw, broadcast through the backend
+        assert x_random[0] in settings[0]
         dist.barrier()
         # the 32-byte records went through the backend from device memory (>= 6 sweeps), and so did the row gathers
         assert sum(1 for shape, dev in calls if shape == (4,) and dev == "cuda") >= 6, calls
