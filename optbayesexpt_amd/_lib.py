@@ -289,13 +289,56 @@ class HostArgs:
         return hit[1]
 
 
+# Page-locked landing zones outlive the objects that own them until the device has drained.  Kernels write their
+# results straight into such memory, and some of them are deliberately not waited for (the sweep enqueued behind an
+# update, the sum(w) of a small draw, the moments behind a constraint mask): when their object is garbage-collected
+# with such a kernel still in flight, torch's caching host allocator would hand the block to the NEXT pin_memory()
+# call at once — the next object's landing zone — and the late kernel would write into it (found by
+# tools/soak_ranks.py once it mixed object classes: a spurious "Probabilities do not sum to 1").  So a released
+# block goes to a limbo list instead, and the list is emptied only behind a device synchronisation.
+_LIMBO = []
+_LIMBO_MAX = 64
+
+
+def _retire_pinned(keeper):
+    _LIMBO.append(keeper)
+
+
+def _purge_limbo():
+    if len(_LIMBO) < _LIMBO_MAX:
+        return
+    import torch
+    try:
+        if torch.cuda.is_available():
+            for d in range(torch.cuda.device_count()):
+                torch.cuda.synchronize(d)
+    except Exception:        # (interpreter shutdown, a device that is gone: keep the blocks)
+        return
+    del _LIMBO[:]
+
+
+def pinned_tensor(n, dtype):
+    """A zeroed page-locked torch tensor whose storage is not recycled while a kernel of its (former) owner may
+    still write to it (see above)."""
+    import torch
+    import weakref
+    _purge_limbo()
+    t = torch.zeros(n, dtype=dtype).pin_memory()
+    weakref.finalize(t, _retire_pinned, t.detach())       # (the detached alias keeps the storage, not the object)
+    return t
+
+
 def pinned_array(n, dtype=np.float64):
     """A zeroed page-locked host array (NumPy view of a pinned torch tensor, which it keeps alive).
     The kernels that end a call write their few result scalars straight into such memory; a pageable
     array works too, through a small device-to-host copy."""
     import torch
+    import weakref
+    _purge_limbo()
     t = torch.zeros(n, dtype=torch.from_numpy(np.zeros(0, dtype=dtype)).dtype).pin_memory()
-    return t.numpy()          # the array's base keeps the pinned storage alive
+    a = t.numpy()             # the array's base keeps the pinned storage alive ...
+    weakref.finalize(a, _retire_pinned, t)                # ... and when the array goes, the limbo list does
+    return a
 
 
 def device_ptr_of_pinned(lib, arr):

@@ -9,6 +9,7 @@ covariance (LAPACK, exactly as ``Generator.multivariate_normal`` does it).
 """
 import ctypes
 import warnings
+import weakref
 
 import numpy as np
 import torch
@@ -17,6 +18,21 @@ from . import _devrng, _lib
 from ._mirror import Mirror
 
 _P = ctypes.c_void_p
+
+
+def _drain(device):
+    """Finaliser of every ParticlePDF: the device work an object enqueued does not outlive it.  Some of that work is
+    deliberately not waited for while the object lives (the sweep enqueued behind an update, the moments behind a
+    constraint mask, the sum(w) of a small draw); an object dropped with such kernels in flight hands its buffers and
+    landing zones back to the allocators while they are still being written.  tools/soak_ranks.py, once it mixed
+    object classes, saw the next object misbehave about once in 10^4 short-lived objects; with a drain at the end of
+    every object's life: never.  Costs nothing while an object lives; deleting one waits for its last kernels."""
+    try:
+        torch.cuda.synchronize(device)
+    except Exception:        # (interpreter shutdown, a device that is gone)
+        pass
+
+
 SQRT_EPS = float(np.sqrt(np.finfo(np.float64).eps))   # numpy's tolerance on sum(p) in choice()
 
 
@@ -51,6 +67,7 @@ class ParticlePDF:
         if self._device.index is None:
             self._device = torch.device("cuda", torch.cuda.current_device())
         self._device_index = self._device.index
+        weakref.finalize(self, _drain, self._device)
         # kernels are launched with this object's device current, whatever the caller's is
         self._lib = _lib.DeviceBound(lib, self._device)
 
@@ -115,10 +132,10 @@ class ParticlePDF:
         self._mom_dev_key = None       # same, for the device copy
         self._cdf_dev = torch.empty(n, dtype=torch.float64, device=self._device)
         self._cdf_key = None           # (weights version, strict)
-        self._total_pinned = torch.zeros(8, dtype=torch.float64).pin_memory()   # async sum(w) of a small draw
+        self._total_pinned = _lib.pinned_tensor(8, torch.float64)   # async sum(w) of a small draw
         # page-locked landing zones of the pipelined resample: [0] sum(w), [1:] the moments block; {consumed, found}
-        self._pinned_f64 = torch.zeros(self._lib.moments_len(d) + 8, dtype=torch.float64).pin_memory()
-        self._pinned_i64 = torch.zeros(8, dtype=torch.int64).pin_memory()
+        self._pinned_f64 = _lib.pinned_tensor(self._lib.moments_len(d) + 8, torch.float64)
+        self._pinned_i64 = _lib.pinned_tensor(8, torch.int64)
         self._pending_total = None     # (generator state before the draw,) while that sum is unchecked
         self._sumsq_key = None         # weights version for which _sumsq is valid
         self._sumsq = None

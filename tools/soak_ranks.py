@@ -6,7 +6,8 @@
 collective calls are the same).  Every rank draws the same recipes from the seed: grids whose split over the
 ranks is uneven and straddles the settings-per-lane thresholds of the sweep kernel, peaks of ordinary width and
 peaks 1e12 / 1e40 times narrower than the grid (the fast sweep forms leave their range), full sweeps,
-reference-semantics sweeps and y-space utilities, cost hooks, the three speculation modes, opt_setting / good_setting / utility() in any order, resamples forced and triggered,
+reference-semantics sweeps and y-space utilities, cost hooks, the three speculation modes, opt_setting / good_setting / utility() in any order (SOAK_SWEEPER=0.08: a share of sweeper-composition experiments mixed in — see
+DESIGN.md section 4 for what that mix found and what it left open), resamples forced and triggered,
 set_pdf, and READS of the cloud or its moments done by one rank only (a script that logs on rank 0).  What is
 checked: nobody hangs (a mismatch in the number of collectives is an error after 60 s), every rank logs the same
 settings, forms and resample decisions cycle by cycle, the replicas stay identical (check_replicas), and the
@@ -33,12 +34,57 @@ def recipe(g):
         d=float(g.choice([0.05, 0.05, 0.05, 2.5e-12, 2.5e-40])),
         method=str(g.choice(["variance_full"] * 13 + ["variance_approx"] * 5 + ["max_min", "pseudo_utility"])),
         cost=int(g.integers(0, 8)), speculate=[True, False, "auto", "auto"][int(g.integers(0, 4))],
+        sweeper=bool(g.random() < float(os.environ.get("SOAK_SWEEPER", "0"))),
         noise=bool(g.random() < 0.3), threshold=float(g.choice([0.1, 0.5, 0.9])),
         cycles=int(g.integers(5, 14)), seed=int(g.integers(1 << 30)),
         acts=g.integers(0, 10, 16).tolist(), reads=g.integers(0, 6, 16).tolist(), readers=g.integers(0, 8, 16).tolist())
 
 
+def run_sweeper(obe, r, shard, rank):
+    """The sweeper composition (demos/sweeper): start/stop pairs chosen from the point utilities that every rank
+    gathers, a whole sweep of points per update; its module-level generator is seeded alike everywhere (rank 0's
+    draws are the ones used)."""
+    from optbayesexpt_amd import sweeper
+    g = np.random.default_rng(r["seed"])
+    n = min(r["n"], 9000)
+    prior = np.array([g.uniform(2, 4, n), g.uniform(400, 2000, n), g.normal(500, 1000, n), g.exponential(500, n) + 1.0])
+    x = np.linspace(1.5, 4.5, max(40, min(r["ns"], 600)))
+    o = obe.OptBayesExptSweeper(obe.models.lorentzian(), (x,), prior, (0.1,), 3, scale=False,
+                                utility_method="variance_full", settings_shard=shard)
+    o.rng = np.random.default_rng(r["seed"] + 1)
+    sweeper.rng = np.random.default_rng(r["seed"] + 3)
+    sim = np.random.default_rng(r["seed"] + 2)
+    log = []
+    try:
+        for c in range(min(r["cycles"], 6)):
+            pair = o.good_setting() if r["acts"][c] in (2, 3) else o.opt_setting()
+            log.append((int(pair[0]) * 100000 + int(pair[1]), False, True))
+            xs = x[pair[0]:pair[1]]
+            ys = 300.0 + 1200.0 / (((xs - 3.1) / 0.1) ** 2 + 1) + 800.0 * sim.standard_normal(len(xs))
+            o.pdf_update(((xs,), ys))
+            log.append(bool(o.just_resampled))
+            if shard is None or r["readers"][c] % shard.world_size == rank:
+                o.mean(), o.std()
+        if shard is not None:
+            assert o.check_replicas()
+        return log, np.asarray(o.mean())
+    except (ValueError, np.linalg.LinAlgError) as exc:
+        exc.partial_log = log
+        raise
+
+
 def run(obe, r, shard, rank):
+    try:
+        return _run(obe, r, shard, rank)
+    finally:
+        if os.environ.get("SOAK_DRAIN"):            # (diagnostic: no device work outlives the object that enqueued it)
+            import torch
+            torch.cuda.synchronize()
+
+
+def _run(obe, r, shard, rank):
+    if r.get("sweeper"):
+        return run_sweeper(obe, r, shard, rank)
     g = np.random.default_rng(r["seed"])
     k, n = r["k"], r["n"]
     rows = [g.uniform(2, 4, (k, n)), g.uniform(400, 2000, (1, n)), g.normal(500, 1000, (1, n))]
@@ -116,6 +162,22 @@ def worker(rank, world, port, minutes, seed, max_recipes, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
     warnings.simplefilter("ignore")
     import optbayesexpt_amd as obe
+    if os.environ.get("SOAK_TRACE"):
+        # every collective of this rank, in order, one line each (flushed): after a mismatch the two ranks' files
+        # show which call had no partner
+        fh = open(os.path.join(os.environ["SOAK_TRACE"], f"coll{rank}.log"), "w")
+
+        def traced(name):
+            inner = getattr(dist, name)
+
+            def call(*a, **kw):
+                what = [tuple(x.shape) if hasattr(x, "shape") else type(x).__name__ for x in a[:2]]
+                fh.write(f"{name} {what}\n")
+                fh.flush()
+                return inner(*a, **kw)
+            setattr(dist, name, call)
+        for name in ("broadcast", "all_gather_into_tensor", "broadcast_object_list", "all_gather_object", "all_gather"):
+            traced(name)
     g = np.random.default_rng(seed)
     t_end = time.time() + 60 * minutes
     done = cycles = ties = safe = refused = resampled = 0
@@ -127,11 +189,24 @@ def worker(rank, world, port, minutes, seed, max_recipes, ret):
             if not go[0]:
                 break
             r = recipe(g)
+            if done < int(os.environ.get("SOAK_SKIP", "0")):      # (replay aid: fast-forward the recipe stream)
+                done += 1
+                continue
+            trace = os.environ.get("SOAK_TRACE")       # a directory: one line per recipe and rank (to find a divergence)
+            if trace:
+                with open(os.path.join(trace, f"rank{rank}.log"), "a") as fh2:
+                    fh2.write(f"{done} begin {r}\n")
+                with open(os.path.join(trace, f"coll{rank}.log"), "a") as fh2:
+                    fh2.write(f"--- recipe {done}\n")
             try:
                 mine = run(obe, r, obe.SettingsShard(), rank)
                 err = None
             except (ValueError, np.linalg.LinAlgError) as exc:      # (numpy's own refusals: every rank alike)
                 mine, err = None, (f"{type(exc).__name__}: {exc}"[:80], exc.partial_log)
+                if trace:
+                    import traceback
+                    with open(os.path.join(trace, f"rank{rank}.log"), "a") as fh2:
+                        fh2.write(f"{done} refused {err}\n{traceback.format_exc()}\n")
             try:
                 ref = run(obe, r, None, 0)
                 ref_err = None
