@@ -1100,9 +1100,12 @@ class OptBayesExpt(ParticlePDF):
         total = self._total_pinned
         stream = self._stream()
         self._lib.call("obe_host_word_arm", idx_hptr)        # the index is the search kernel's last word: watched, not synchronised
+        total_ptr = _P(total.data_ptr() + 8)
+        self._lib.call("obe_host_word_arm", total_ptr)       # ... and so is sum(p), which an EARLIER kernel of the call stores:
         self._lib.call("obe_draw_indices", _ptr(prob), n, 0, 0, _ptr(cdf), _lib.host_ptr(uni), 1,
-                       idx_dev, _P(total.data_ptr() + 8), _ptr(self._ws), self._ws_bytes, stream)
+                       idx_dev, total_ptr, _ptr(self._ws), self._ws_bytes, stream)
         self._lib.call("obe_host_word_wait", idx_hptr, stream)
+        self._lib.call("obe_host_word_wait", total_ptr, stream)   # (the order of two stores is not the order of their arrival)
         self._check_pending_total()
         try:
             self._validate_total(float(total[1]))      # all-zero / NaN utilities: p = 0/0, ValueError in the reference

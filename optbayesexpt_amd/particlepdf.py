@@ -368,6 +368,7 @@ class ParticlePDF:
             return
         (state,), self._pending_total = self._pending_total, None
         try:
+            self._lib.call("obe_host_word_wait", _P(self._total_pinned.data_ptr()), self._stream())
             self._validate_total(float(self._total_pinned[0]))
         except ValueError:
             if state is not None:
@@ -405,6 +406,10 @@ class ParticlePDF:
             if not fresh and hasattr(self.rng, "bit_generator"):
                 state = self.rng.bit_generator.state
             u = np.atleast_1d(self.rng.random(n_draws))
+            if not fresh:
+                # (watched like every other result word: a store of an EARLIER kernel is not guaranteed to be visible to
+                # the host before the words a later kernel stores — _check_pending_total waits for this one itself)
+                self._lib.call("obe_host_word_arm", _P(self._total_pinned.data_ptr()))
             self._lib.call("obe_draw_indices", _ptr(w), self.n_particles, 1 if strict else 0, 1 if fresh else 0,
                            _ptr(self._cdf_dev), _lib.host_ptr(u), n_draws, _ptr(idx),
                            None if fresh else _P(self._total_pinned.data_ptr()), _ptr(self._ws), self._ws_bytes,

@@ -7,7 +7,7 @@ collective calls are the same).  Every rank draws the same recipes from the seed
 ranks is uneven and straddles the settings-per-lane thresholds of the sweep kernel, peaks of ordinary width and
 peaks 1e12 / 1e40 times narrower than the grid (the fast sweep forms leave their range), full sweeps,
 reference-semantics sweeps and y-space utilities, cost hooks, the three speculation modes, opt_setting / good_setting / utility() in any order (SOAK_SWEEPER=0.08: a share of sweeper-composition experiments mixed in — see
-DESIGN.md section 4 for what that mix found and what it left open), resamples forced and triggered,
+DESIGN.md section 4 for what that mix found), resamples forced and triggered,
 set_pdf, and READS of the cloud or its moments done by one rank only (a script that logs on rank 0).  What is
 checked: nobody hangs (a mismatch in the number of collectives is an error after 60 s), every rank logs the same
 settings, forms and resample decisions cycle by cycle, the replicas stay identical (check_replicas), and the
