@@ -1101,7 +1101,7 @@ class OptBayesExpt(ParticlePDF):
         stream = self._stream()
         self._lib.call("obe_host_word_arm", idx_hptr)        # the index is the search kernel's last word: watched, not synchronised
         total_ptr = _P(total.data_ptr() + 8)
-        self._lib.call("obe_host_word_arm", total_ptr)       # ... and so is sum(p), which an EARLIER kernel of the call stores:
+        self._lib.call("obe_host_word_arm", total_ptr)       # ... and so is sum(p), a store of its own to a line of its own:
         self._lib.call("obe_draw_indices", _ptr(prob), n, 0, 0, _ptr(cdf), _lib.host_ptr(uni), 1,
                        idx_dev, total_ptr, _ptr(self._ws), self._ws_bytes, stream)
         self._lib.call("obe_host_word_wait", idx_hptr, stream)

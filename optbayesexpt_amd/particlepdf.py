@@ -407,8 +407,8 @@ class ParticlePDF:
                 state = self.rng.bit_generator.state
             u = np.atleast_1d(self.rng.random(n_draws))
             if not fresh:
-                # (watched like every other result word: a store of an EARLIER kernel is not guaranteed to be visible to
-                # the host before the words a later kernel stores — _check_pending_total waits for this one itself)
+                # (watched like every other result word: a store issued earlier is not guaranteed to reach the host before
+                # one issued later, by the same kernel or the next — _check_pending_total waits for this one itself)
                 self._lib.call("obe_host_word_arm", _P(self._total_pinned.data_ptr()))
             self._lib.call("obe_draw_indices", _ptr(w), self.n_particles, 1 if strict else 0, 1 if fresh else 0,
                            _ptr(self._cdf_dev), _lib.host_ptr(u), n_draws, _ptr(idx),
