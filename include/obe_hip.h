@@ -272,7 +272,9 @@ int obe_interval_utility(const double* d_cum, int64_t n_settings, const int64_t*
  * 14 336 particles scan and search are one launch (beyond that the three-kernel scan is faster).  Same CDF bits and indices as
  * obe_weight_cdf + obe_cdf_search.  Never synchronises: when the CDF is rebuilt and
  * h_total_pinned != NULL (pinned host memory: written by the last kernel itself; pageable: an asynchronous copy), sum(w) lands there and is
- * valid after the caller's next synchronisation of the stream. */
+ * valid after the caller's next synchronisation of the stream — or, for pinned memory, once the word itself has arrived: arm it with
+ * obe_host_word_arm() before the call and wait for IT with obe_host_word_wait().  The arrival of another word (the indices copied
+ * back, a later call's result) does not imply this one's: stores to host memory do not arrive in the order they were issued. */
 int obe_draw_indices(const double* d_weights, int64_t n_particles, int32_t strict_order,
                      int32_t cdf_is_fresh, double* d_cdf, const double* h_uniforms,
                      int32_t n_draws, int64_t* d_idx, double* h_total_pinned,
