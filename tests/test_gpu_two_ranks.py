@@ -336,8 +336,9 @@ def test_a_slice_of_the_randomised_runs_through_real_ranks(hip):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_ranks.py"), "3", "31", "2", "300"], env=env,
-                       capture_output=True, text=True, timeout=600)
+    # (the tool stops at 300 experiments — seconds on a healthy box — or after 10 minutes, whichever comes first)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_ranks.py"), "10", "31", "2", "300"], env=env,
+                       capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     m = re.search(r"ranks soak: 2 ranks, (\d+) experiments, (\d+) cycles, every rank the same log \((\d+) experiments "
                   r"with sweeps in the safe form, (\d+) with resamples", r.stdout)
