@@ -559,3 +559,32 @@ def test_sweepstate_form_policy():
     assert st.form is ss.Form.FAST and st.safe_streak == 2          # one fast attempt; a failure pins it again
     st.fast_form_left_its_range()
     assert st.form is ss.Form.SAFE
+
+
+def test_released_landing_zones_wait_in_limbo(monkeypatch):
+    """Page-locked landing zones that an object releases are not handed back to the allocator while a kernel of
+    that object may still write to them (_lib.pinned_array / pinned_tensor): the storage moves to a limbo list
+    when its array is collected, and the list is emptied only when it has grown to its limit (behind a device
+    synchronisation on a GPU box; here the page-locking itself is replaced by a no-op)."""
+    import gc
+    import torch
+    from optbayesexpt_amd import _lib
+    monkeypatch.setattr(torch.Tensor, "pin_memory", lambda self, *a, **k: self)
+    monkeypatch.setattr(_lib, "_LIMBO", [])
+    a = _lib.pinned_array(4)
+    view = a[1:3]
+    t = _lib.pinned_tensor(3, torch.int64)
+    assert a.shape == (4,) and a.dtype == np.float64 and not a.any() and t.dtype == torch.int64
+    del a
+    gc.collect()
+    assert _lib._LIMBO == []                   # a view keeps the array, and with it the storage, with its owner
+    del view, t
+    gc.collect()
+    assert len(_lib._LIMBO) == 2               # both storages are parked, not freed
+    monkeypatch.setattr(_lib, "_LIMBO_MAX", 5)
+    for _ in range(3):                         # ... until the list reaches its limit: the next allocation empties it
+        _lib.pinned_array(1)                   # (dropped at once: parked)
+    gc.collect()
+    assert len(_lib._LIMBO) == 5
+    keep = _lib.pinned_array(2)
+    assert len(_lib._LIMBO) == 0 and keep.shape == (2,)
