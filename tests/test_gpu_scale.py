@@ -60,7 +60,7 @@ def _csweep_or_skip():
     return csweep
 
 
-def _host_grid(csweep, settings, particles, weights, d, n_peaks, what, budget_s=150.0):
+def _host_grid(csweep, settings, particles, weights, d, n_peaks, what, budget_s=75.0):
     """oracle/csweep.c over the WHOLE settings grid on the host cores (18 s for c3 on the GPU box's 128 threads).  A
     short probe first: on a box with few usable cores the full grid would take tens of minutes — then, and only
     then, an evenly spaced subset sized for the budget is computed and the test says so (the arg-max check needs the
