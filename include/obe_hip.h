@@ -34,7 +34,14 @@
 extern "C" {
 #endif
 
-#define OBE_ABI_VERSION 1
+/* The only symbols the library (and every per-model plugin) exports: everything else is compiled with
+ * -fvisibility=hidden (optbayesexpt_amd/build.py), tests/test_capi_symbols.py checks `nm -D` against this header. */
+#define OBE_API __attribute__((visibility("default")))
+
+/* 2 (round 6): obe_resample_begin gained d_aos; the sweep / arg-max calls write a 32-byte record into the
+ * workspace tail and the speculative pair keeps its abort word there (OBE_WS_RESULT_TAIL, OBE_WS_ABORT_WORD);
+ * limits raised.  A client compiled against another version must not call in: compare obe_abi_version(). */
+#define OBE_ABI_VERSION 2
 #define OBE_MAX_CONSTS 8
 #define OBE_MAX_CHANNELS 4
 #define OBE_MAX_SETDIMS 4
@@ -67,26 +74,26 @@ typedef struct obe_model {
 } obe_model;
 
 /* Checks id/aux/n_* consistency; fills n_setdims/n_channels if they are 0. */
-int obe_model_validate(obe_model* m);
+OBE_API int obe_model_validate(obe_model* m);
 
 /* ---- library ---- */
-int obe_abi_version(void);
+OBE_API int obe_abi_version(void);
 /* Hash of the kernel sources this binary was compiled from (optbayesexpt_amd/build.py); the
  * loader compares it with the sources next to it and refuses a stale library. */
-const char* obe_source_fingerprint(void);
-const char* obe_last_error(void);
+OBE_API const char* obe_source_fingerprint(void);
+OBE_API const char* obe_last_error(void);
 /* Deferred host results (per calling thread).  While on, the entry points that deliver results
  * to host memory and would synchronise `stream` for it — obe_moments (h_out), obe_weight_cdf
  * (h_total), obe_ziggurat_normal (h_consumed[2]) — only enqueue the copy and return; the values
  * are valid once the caller has synchronised the stream (pass page-locked host memory, or the
  * copy itself blocks).  resample() uses it to keep the device busy while the host factorises the
  * covariance.  Returns the previous state. */
-int obe_defer_host_sync(int32_t on);
+OBE_API int obe_defer_host_sync(int32_t on);
 /* The address under which kernels of the current device reach a page-locked host buffer
  * (hipHostMalloc / hipHostRegister; fails for pageable memory).  A `d_*` output argument that is
  * only a few values — the index of obe_draw_indices for good_setting() — may be given as this
  * address: the kernel then delivers the result to the host itself, with no copy back. */
-int obe_host_device_pointer(const void* h_pinned, void** d_out);
+OBE_API int obe_host_device_pointer(const void* h_pinned, void** d_out);
 /* Waiting for such results by watching them: obe_host_words_arm stores a bit pattern no result has
  * (0x7ff8c0dec0dec0de: a NaN payload / an impossible index) into EVERY 8-byte word of a page-locked result
  * block, the call whose kernels write those words is enqueued, and obe_host_words_wait spins until none of
@@ -99,17 +106,17 @@ int obe_host_device_pointer(const void* h_pinned, void** d_out);
  * obe_argmax, obe_bayes_update_*, obe_weight_sums) wait this way themselves; obe_resample_begin and
  * obe_mask_nonpositive_moments arm their result words and leave the waiting to the caller.
  * obe_host_word_arm / _wait: the same for a single word. */
-int obe_host_words_arm(void* h_pinned_words, int64_t n_words);
-int obe_host_words_wait(const void* h_pinned_words, int64_t n_words, void* stream);
-int obe_host_word_arm(void* h_pinned_word);
-int obe_host_word_wait(const void* h_pinned_word, void* stream);
+OBE_API int obe_host_words_arm(void* h_pinned_words, int64_t n_words);
+OBE_API int obe_host_words_wait(const void* h_pinned_words, int64_t n_words, void* stream);
+OBE_API int obe_host_word_arm(void* h_pinned_word);
+OBE_API int obe_host_word_wait(const void* h_pinned_word, void* stream);
 /* Name, CU count and memory of the current device; returns 0 if a gfx950 device is current. */
-int obe_device_info(char* name, int name_len, int* n_cu, int64_t* hbm_bytes);
+OBE_API int obe_device_info(char* name, int name_len, int* n_cu, int64_t* hbm_bytes);
 
 /* Scratch (device) bytes any call below may need for these sizes.  The sweep keeps its draws,
  * packed once per call, in the workspace: pass n_particles >= the number of draws of any sweep
  * (N_DRAWS may exceed the particle count).  A plugin library answers for its own model. */
-int64_t obe_workspace_bytes(int64_t n_particles, int64_t n_settings, int32_t n_channels, int32_t n_dims);
+OBE_API int64_t obe_workspace_bytes(int64_t n_particles, int64_t n_settings, int32_t n_channels, int32_t n_dims);
 
 /* ---- K2: Bayes update  (obe_base.py:385-394 eval_over_all_parameters + likelihood +
  *      particlepdf.py:136-139 _normalized_product + :243-244 N_eff) ------------------
@@ -121,7 +128,7 @@ int64_t obe_workspace_bytes(int64_t n_particles, int64_t n_settings, int32_t n_c
  * n_lik_channels = number of channels entering the product (zip truncation,
  * obe_base.py:453-455).  choke: NaN = none (obe_base.py:458-459).
  * h_out[0] = sum t, h_out[1] = sum nan_to_num(w'^2)  (host; stream is synchronised). */
-int obe_bayes_update_model(const obe_model* m,
+OBE_API int obe_bayes_update_model(const obe_model* m,
                            const double* d_particles, int64_t ld_p, int64_t n_particles,
                            double* d_weights,
                            const double* h_setting, const double* h_y_meas,
@@ -141,7 +148,7 @@ int obe_bayes_update_model(const obe_model* m,
  * workgroup partials (one per CU) and can differ from obe_bayes_update_model()'s h_out[1] in the last
  * few ulp — never in a resample decision over the experiments tested
  * (tests/test_gpu_units.py::test_fused_and_unfused_update_take_the_same_resample_decisions). */
-int obe_bayes_update_model_moments(const obe_model* m,
+OBE_API int obe_bayes_update_model_moments(const obe_model* m,
                                    const double* d_particles, int64_t ld_p, int64_t n_particles,
                                    double* d_weights,
                                    const double* h_setting, const double* h_y_meas,
@@ -159,7 +166,7 @@ int obe_bayes_update_model_moments(const obe_model* m,
  * co-resident grid, and the first-moment passes on the update's grid: OBE_FIRST_MOM_PER_CU=3), the two launches
  * otherwise; on = 0 — always two launches.  The results are the same bits either way.  Returns the previous
  * setting; on = -1 changes nothing and returns what the thread's last fused update did (1: one launch, 2: two). */
-int obe_update_one_pass(int32_t on);
+OBE_API int obe_update_one_pass(int32_t on);
 
 /* The same update, enqueued only: returns without waiting.  h_pinned_out (page-locked, 5 + 4 n_params
  * doubles) is armed here and written by the update's last kernel: [0] sum t, [1] sum w'^2, [2..) the K3
@@ -177,7 +184,7 @@ int obe_update_one_pass(int32_t on);
  * the stream (device allocation failed; a full table of 256 streams per device hands its least recently
  * used entry on after a device synchronisation, so it never refuses). */
 #define OBE_WS_ABORT_WORD(d_ws, ws_bytes) ((unsigned*)((char*)(d_ws) + ((ws_bytes) & ~(int64_t)7) - 8))
-int obe_bayes_update_model_moments_enqueue(const obe_model* m, const double* d_particles, int64_t ld_p,
+OBE_API int obe_bayes_update_model_moments_enqueue(const obe_model* m, const double* d_particles, int64_t ld_p,
                                            int64_t n_particles, double* d_weights, const double* h_setting,
                                            const double* h_y_meas, const double* h_sigma,
                                            const int32_t* h_noise_rows, int32_t n_lik_channels, double choke,
@@ -192,7 +199,7 @@ int obe_bayes_update_model_moments_enqueue(const obe_model* m, const double* d_p
  * n_eff / N < resample_threshold the remaining points are skipped (their kernels return at once).  h_out[0] = sum t and h_out[1] = sum w'^2 of the last point applied,
  * h_out[2] = 1 if a resample is due, h_out[3] = points applied (>= 1); the caller resamples and
  * submits the rest.  Sync. */
-int obe_bayes_update_sweep(const obe_model* m, const double* d_particles, int64_t ld_p,
+OBE_API int obe_bayes_update_sweep(const obe_model* m, const double* d_particles, int64_t ld_p,
                            int64_t n_particles, double* d_weights, const double* h_settings,
                            const double* h_y_meas, const double* h_sigma,
                            const int32_t* h_noise_rows, int32_t n_lik_channels, double choke,
@@ -200,7 +207,7 @@ int obe_bayes_update_sweep(const obe_model* m, const double* d_particles, int64_
                            void* d_ws, int64_t ws_bytes, double* h_out, void* stream);
 /* Same update from precomputed model outputs d_y (C, N_p) row-major, ld_y between
  * channels  (pdf_update(..., y_model_data), obe_base.py:384-385). */
-int obe_bayes_update_y(const double* d_y, int64_t ld_y, int32_t n_channels,
+OBE_API int obe_bayes_update_y(const double* d_y, int64_t ld_y, int32_t n_channels,
                        const double* d_particles, int64_t ld_p, int64_t n_particles,
                        double* d_weights, const double* h_y_meas,
                        const double* h_sigma, const int32_t* h_noise_rows,
@@ -209,27 +216,27 @@ int obe_bayes_update_y(const double* d_y, int64_t ld_y, int32_t n_channels,
 
 /* ParticlePDF.bayesian_update(likelihood) with a caller-supplied likelihood array
  * (particlepdf.py:216-234). */
-int obe_bayes_update_lik(const double* d_lik, int64_t n_particles, double* d_weights,
+OBE_API int obe_bayes_update_lik(const double* d_lik, int64_t n_particles, double* d_weights,
                          void* d_ws, int64_t ws_bytes, double* h_out, void* stream);
 
 /* OptBayesExpt.likelihood(y_model, record) as an array (obe_base.py:418-461). */
-int obe_likelihood_y(const double* d_y, int64_t ld_y, int32_t n_channels,
+OBE_API int obe_likelihood_y(const double* d_y, int64_t ld_y, int32_t n_channels,
                      const double* d_particles, int64_t ld_p, int64_t n_particles,
                      const double* h_y_meas, const double* h_sigma,
                      const int32_t* h_noise_rows, int32_t n_lik_channels, double choke,
                      double* d_lik_out, void* stream);
 
 /* h_out[0] = sum nan_to_num(w^2) (resample_test, particlepdf.py:243-244), h_out[1] = sum w. */
-int obe_weight_sums(const double* d_weights, int64_t n_particles,
+OBE_API int obe_weight_sums(const double* d_weights, int64_t n_particles,
                     void* d_ws, int64_t ws_bytes, double* h_out, void* stream);
 
 /* ---- model evaluation wrappers (obe_base.py:298-338) ---- */
 /* d_y_out (C, N_p): model(one setting; all particles). */
-int obe_eval_over_particles(const obe_model* m, const double* d_particles, int64_t ld_p,
+OBE_API int obe_eval_over_particles(const obe_model* m, const double* d_particles, int64_t ld_p,
                             int64_t n_particles, const double* h_setting,
                             double* d_y_out, int64_t ld_y, void* stream);
 /* d_y_out (C, N_s): model(all settings; one parameter set h_params[D]). */
-int obe_eval_over_settings(const obe_model* m, const double* d_settings, int64_t ld_s,
+OBE_API int obe_eval_over_settings(const obe_model* m, const double* d_settings, int64_t ld_s,
                            int64_t n_settings, const double* h_params,
                            double* d_y_out, int64_t ld_y, void* stream);
 
@@ -241,8 +248,8 @@ int obe_eval_over_settings(const obe_model* m, const double* d_settings, int64_t
  * want_cov = 2: d_out already holds the first moments of these particles and weights (from an earlier
  * call or from obe_bayes_update_model_moments): only the covariance pass runs, about the mean found
  * there; of h_out only the covariance part is then written by a page-locked delivery. */
-int64_t obe_moments_len(int32_t n_dims);
-int obe_moments(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t n_particles,
+OBE_API int64_t obe_moments_len(int32_t n_dims);
+OBE_API int obe_moments(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t n_particles,
                 const double* d_weights, int32_t want_cov,
                 double* d_out, double* h_out, void* d_ws, int64_t ws_bytes, void* stream);
 
@@ -252,7 +259,7 @@ int obe_moments(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t
  * blocked scan (same value to ~1e-13, indices identical unless a uniform falls
  * inside that gap).  h_total (nullable) receives what numpy validates of p (sync): sum(w) — NaN if any
  * weight is NaN — or -inf when some weight is negative ("Probabilities are not non-negative"). */
-int obe_weight_cdf(const double* d_weights, int64_t n_particles, int32_t strict_order,
+OBE_API int obe_weight_cdf(const double* d_weights, int64_t n_particles, int32_t strict_order,
                    double* d_cdf, double* h_total, void* d_ws, int64_t ws_bytes, void* stream);
 /* ---- sweeper composition (demos/sweeper/obe_sweeper.py:122-149) ----
  * obe_cumsum: out = np.cumsum(x) (strict_order as above; no normalisation).
@@ -261,9 +268,9 @@ int obe_weight_cdf(const double* d_weights, int64_t n_particles, int32_t strict_
  * `(ends[:, 1] - ends[:, 0]) / cost` of sweep_utility(); cost_i = d_cost[i], or
  * stop_i - start_i + cost_of_new_sweep (sweep_cost_estimate(), obe_sweeper.py:106-120)
  * when d_cost == NULL.  Follow with obe_argmax. */
-int obe_cumsum(const double* d_x, int64_t n, int32_t strict_order, double* d_out,
+OBE_API int obe_cumsum(const double* d_x, int64_t n, int32_t strict_order, double* d_out,
                void* d_ws, int64_t ws_bytes, void* stream);
-int obe_interval_utility(const double* d_cum, int64_t n_settings, const int64_t* d_pairs,
+OBE_API int obe_interval_utility(const double* d_cum, int64_t n_settings, const int64_t* d_pairs,
                          int64_t n_pairs, const double* d_cost, double cost_of_new_sweep,
                          double* d_utility, void* stream);
 /* The index part of randdraw() for a small draw (n_draws <= 64; the reference's N_DRAWS = 30,
@@ -275,23 +282,23 @@ int obe_interval_utility(const double* d_cum, int64_t n_settings, const int64_t*
  * valid after the caller's next synchronisation of the stream — or, for pinned memory, once the word itself has arrived: arm it with
  * obe_host_word_arm() before the call and wait for IT with obe_host_word_wait().  The arrival of another word (the indices copied
  * back, a later call's result) does not imply this one's: stores to host memory do not arrive in the order they were issued. */
-int obe_draw_indices(const double* d_weights, int64_t n_particles, int32_t strict_order,
+OBE_API int obe_draw_indices(const double* d_weights, int64_t n_particles, int32_t strict_order,
                      int32_t cdf_is_fresh, double* d_cdf, const double* h_uniforms,
                      int32_t n_draws, int64_t* d_idx, double* h_total_pinned,
                      void* d_ws, int64_t ws_bytes, void* stream);
 /* Systematic resampling (extension; BASELINE.json north_star names it, the reference itself is
  * multinomial): idx[i] = searchsorted(cdf, (i + u0) / n_draws, 'right') for ONE uniform u0 in
  * [0, 1).  Selected with tuning_parameters['resample_method'] = 'systematic'. */
-int obe_systematic_indices(const double* d_cdf, int64_t n, double u0, int64_t n_draws,
+OBE_API int obe_systematic_indices(const double* d_cdf, int64_t n, double u0, int64_t n_draws,
                            int64_t* d_idx_out, void* stream);
 /* idx[j] = #{i : cdf[i] <= u[j]}  (searchsorted side='right'), int64.  d_ws (nullable): with at
  * least n / 2 + 8 bytes of scratch, a search of many draws (n_draws >= n / 4, n >= 32 768: a
  * resample) first builds a guide table of n / 8 + 1 bucket starts and then searches only the handful
  * of entries a draw's bucket spans — the same indices, ~3 instead of ~11 cold accesses per draw. */
-int obe_cdf_search(const double* d_cdf, int64_t n, const double* d_uniforms, int64_t n_draws,
+OBE_API int obe_cdf_search(const double* d_cdf, int64_t n, const double* d_uniforms, int64_t n_draws,
                    int64_t* d_idx_out, void* d_ws, int64_t ws_bytes, void* stream);
 /* randdraw gather: d_out (D, n_draws) = particles[:, idx]  (particlepdf.py:332-343). */
-int obe_gather_columns(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t n_particles,
+OBE_API int obe_gather_columns(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t n_particles,
                        const int64_t* d_idx, int64_t n_draws,
                        double* d_out, int64_t ld_out, void* stream);
 /* resample(): new[i,p] = old[i, idx[p]] + sum_j z[p,j] F[i,j]   (F = u*sqrt(s) of the
@@ -300,7 +307,7 @@ int obe_gather_columns(const double* d_particles, int64_t ld_p, int32_t n_dims, 
  * d_ws (nullable): with 8 * n_dims * n_particles bytes of scratch a large cloud is first copied
  * to (N, D) order, so that the gather of a particle touches one or two 64-byte sectors instead
  * of n_dims of them. */
-int obe_resample_particles(const double* d_old, int64_t ld_old, int32_t n_dims, int64_t n_particles,
+OBE_API int obe_resample_particles(const double* d_old, int64_t ld_old, int32_t n_dims, int64_t n_particles,
                            const int64_t* d_idx, const double* d_normals,
                            const double* h_factor, const double* h_mean,
                            double a_param, int32_t scale,
@@ -308,7 +315,7 @@ int obe_resample_particles(const double* d_old, int64_t ld_old, int32_t n_dims, 
                            void* d_ws, int64_t ws_bytes, void* stream);
 /* The same with the (N, D) copy of the old cloud already made (obe_resample_begin's d_aos): no copy pass in
  * front of the gather. */
-int obe_resample_particles_aos(const double* d_old_aos, int32_t n_dims, int64_t n_particles,
+OBE_API int obe_resample_particles_aos(const double* d_old_aos, int32_t n_dims, int64_t n_particles,
                                const int64_t* d_idx, const double* d_normals,
                                const double* h_factor, const double* h_mean,
                                double a_param, int32_t scale,
@@ -320,7 +327,7 @@ int obe_resample_particles_aos(const double* d_old_aos, int32_t n_dims, int64_t 
  * the caller's) receives the partial sums {sum w, count} that obe_mask_nonpositive()'s first kernel would leave —
  * same grid, same order, same bits — for obe_mask_renorm_moments().  ONLY for a resample that the constraint
  * follows: the reference's resample() on its own leaves uniform weights. */
-int obe_resample_particles_aos_masked(const double* d_old_aos, int32_t n_dims, int64_t n_particles,
+OBE_API int obe_resample_particles_aos_masked(const double* d_old_aos, int32_t n_dims, int64_t n_particles,
                                       const int64_t* d_idx, const double* d_normals,
                                       const double* h_factor, const double* h_mean,
                                       double a_param, int32_t scale,
@@ -343,7 +350,7 @@ int obe_resample_particles_aos_masked(const double* d_old_aos, int32_t n_dims, i
  * obe_resample_particles_aos() — made here, while the host factorises, instead of in front of the gather; on
  * large clouds the covariance and this copy then run as a third chain beside the CDF / search and the random
  * numbers.  Same kernels, same numbers as the calls one by one. */
-int obe_resample_begin(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t n_particles,
+OBE_API int obe_resample_begin(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t n_particles,
                        const double* d_weights, const uint64_t* h_pcg_state4, int32_t strict_cdf,
                        int32_t cdf_is_fresh, int32_t have_first_moments, int64_t n_raw,
                        double* d_cdf, double* d_uniforms, int64_t* d_idx, const void* d_zig_tables,
@@ -354,7 +361,7 @@ int obe_resample_begin(const double* d_particles, int64_t ld_p, int32_t n_dims, 
  * enforce_parameter_constraints (obe_noiseparam.py:57-79): zero the weight of every
  * particle whose row h_rows[k] <= 0 for any k, renormalise if anything changed.
  * *h_changed = number of particles zeroed (sync). */
-int obe_mask_nonpositive(const double* d_particles, int64_t ld_p, int64_t n_particles,
+OBE_API int obe_mask_nonpositive(const double* d_particles, int64_t ld_p, int64_t n_particles,
                          const int32_t* h_rows, int32_t n_rows, double* d_weights,
                          int64_t* h_changed, void* d_ws, int64_t ws_bytes, void* stream);
 
@@ -364,7 +371,7 @@ int obe_mask_nonpositive(const double* d_particles, int64_t ld_p, int64_t n_part
  * 173-214).  Does not wait: page-locked h_changed (1 word) and h_moments (the K3 block's 2 + 4 n_dims
  * first-moment values; either may be NULL) are armed here and written by the second kernel — the caller
  * waits with obe_host_words_wait() on each.  Pageable host buffers: the two calls above, synchronously. */
-int obe_mask_nonpositive_moments(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t n_particles,
+OBE_API int obe_mask_nonpositive_moments(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t n_particles,
                                  const int32_t* h_rows, int32_t n_rows, double* d_weights, double* d_moments,
                                  double* h_moments, int64_t* h_changed, void* d_ws, int64_t ws_bytes,
                                  void* stream);
@@ -376,14 +383,14 @@ int obe_mask_nonpositive_moments(const double* d_particles, int64_t ld_p, int32_
  * (obe_resample_particles_aos_masked).  Refused (-1) before any launch without an arrival counter for the stream or
  * with pageable host outputs: the caller then calls obe_mask_nonpositive_moments(), which on weights the gather has
  * already masked zeroes the same particles and leaves the same bits. */
-int obe_mask_renorm_moments(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t n_particles,
+OBE_API int obe_mask_renorm_moments(const double* d_particles, int64_t ld_p, int32_t n_dims, int64_t n_particles,
                             const double* d_mask_partials, double* d_weights, double* d_moments,
                             double* h_moments, int64_t* h_changed, void* d_ws, int64_t ws_bytes, void* stream);
-int obe_noise_var_from_moments(const double* d_moments, int32_t n_dims, const int32_t* h_rows,
+OBE_API int obe_noise_var_from_moments(const double* d_moments, int32_t n_dims, const int32_t* h_rows,
                                int32_t n_rows, double* d_out, void* stream);
 
 /* ---- good_setting (obe_base.py:781-784): p = nan_to_num(u ** exponent); p /= sum(p) ---- */
-int obe_power_normalize(const double* d_u, int64_t n, double exponent, double* d_p_out,
+OBE_API int obe_power_normalize(const double* d_u, int64_t n, double exponent, double* d_p_out,
                         void* d_ws, int64_t ws_bytes, void* stream);
 
 /* ---- K1 + K5: utility sweep and argmax (obe_base.py:463-489, 628-655, 733-756) ----
@@ -460,12 +467,12 @@ int obe_power_normalize(const double* d_u, int64_t n, double exponent, double* d
  * few draws may use fewer): the number of denominators a model's fast form inverts together, which a
  * caller that predicts whether a settings grid stays inside that form's range needs
  * (optbayesexpt_amd/models.py: range_hint). */
-int obe_sweep_settings_per_lane(int64_t n_settings);
+OBE_API int obe_sweep_settings_per_lane(int64_t n_settings);
 /* ... and for a reference-semantics sweep of n_draws draws (obe_base.py:463-489 with N_DRAWS draws): 1 when the
  * one-workgroup kernel serves it.  A model whose fast form shares nothing but the reciprocal of a lane's
  * settings is IEEE as it is when this returns 1: no range check, no repeat (models.py: safe_sweep_min_spt). */
-int obe_sweep_settings_per_lane_for(int64_t n_settings, int64_t n_draws);
-int obe_sweep_utility(const obe_model* m,
+OBE_API int obe_sweep_settings_per_lane_for(int64_t n_settings, int64_t n_draws);
+OBE_API int obe_sweep_utility(const obe_model* m,
                       const double* d_settings, int64_t ld_s, int64_t n_settings,
                       const double* d_particles, int64_t ld_p, int64_t n_particles,
                       const double* d_weights, const int64_t* d_draw_idx, int64_t n_draws,
@@ -478,37 +485,37 @@ int obe_sweep_utility(const obe_model* m,
 
 /* Variance over the draw axis of a caller-filled y-space (N_d, C, N_s) — the
  * np.var(utility_y_space, axis=0) of obe_base.py:488 for host-callable models. */
-int obe_yspace_variance(const double* d_yspace, int64_t n_draws, int32_t n_channels,
+OBE_API int obe_yspace_variance(const double* d_yspace, int64_t n_draws, int32_t n_channels,
                         int64_t n_settings, double* d_yvar, void* stream);
 /* utility + argmax from an existing yvar (same conventions as obe_sweep_utility). */
-int obe_utility_argmax(const double* d_yvar, int32_t n_channels, int64_t n_settings,
+OBE_API int obe_utility_argmax(const double* d_yvar, int32_t n_channels, int64_t n_settings,
                        const double* d_noise_var, int64_t noise_ld,
                        const double* d_cost, double cost_scalar,
                        double* d_utility, double* h_best, int64_t* h_best_idx,
                        void* d_ws, int64_t ws_bytes, void* stream);
 /* first-maximum argmax of an arbitrary device vector (np.argmax semantics incl. NaN). */
-int obe_argmax(const double* d_v, int64_t n, double* h_best, int64_t* h_best_idx,
+OBE_API int obe_argmax(const double* d_v, int64_t n, double* h_best, int64_t* h_best_idx,
                void* d_ws, int64_t ws_bytes, void* stream);
 
 /* ---- the non-default utilities on the explicit y-space ----
  * d_yspace (N_d, C, N_s) row-major = utility_y_space of the reference (obe_base.py:293-295). */
 /* y[d][c][s] = model(setting s; particle d_draw_idx[d]) — the loop of obe_base.py:483-484
  * (eval_over_all_settings per drawn parameter set), exact NumPy operation order. */
-int obe_eval_draws(const obe_model* m, const double* d_settings, int64_t ld_s, int64_t n_settings,
+OBE_API int obe_eval_draws(const obe_model* m, const double* d_settings, int64_t ld_s, int64_t n_settings,
                    const double* d_particles, int64_t ld_p, int64_t n_particles,
                    const int64_t* d_draw_idx, int64_t n_draws, double* d_yspace, void* stream);
 /* y[d][c][:] += d_noise[d][c]  (utility_full_kld, obe_base.py:714-715). */
-int obe_yspace_add_noise(double* d_yspace, int64_t n_draws, int32_t n_channels, int64_t n_settings,
+OBE_API int obe_yspace_add_noise(double* d_yspace, int64_t n_draws, int32_t n_channels, int64_t n_settings,
                          const double* d_noise, void* stream);
 /* yvar_max_min (obe_base.py:520-535): (max - min)^2 over the draws, per column (C*N_s columns). */
-int obe_yspace_maxmin(const double* d_yspace, int64_t n_draws, int64_t n_columns, double* d_span2, void* stream);
+OBE_API int obe_yspace_maxmin(const double* d_yspace, int64_t n_draws, int64_t n_columns, double* d_span2, void* stream);
 /* scipy.stats.differential_entropy(axis=0, method='auto') per column (obe_base.py:516, 717-718);
  * as_variance != 0 returns exp(2H)/(2 pi e) (yvar_from_entropy, obe_base.py:517).
  * d_scratch: n_draws * n_columns doubles.  n_draws <= 2048. */
-int obe_yspace_entropy(const double* d_yspace, int64_t n_draws, int64_t n_columns, int32_t as_variance,
+OBE_API int obe_yspace_entropy(const double* d_yspace, int64_t n_draws, int64_t n_columns, int32_t as_variance,
                        double* d_scratch, double* d_out, void* stream);
 /* utility_full_kld (obe_base.py:720): exp(H_y[c,s] - H_noise[c]) - 1. */
-int obe_kld_utility(const double* d_entropy_y, int32_t n_channels, int64_t n_settings,
+OBE_API int obe_kld_utility(const double* d_entropy_y, int32_t n_channels, int64_t n_settings,
                     const double* d_entropy_noise, double* d_utility, void* stream);
 
 /* ---- device-side continuation of the caller's numpy PCG64 stream ----
@@ -516,18 +523,18 @@ int obe_kld_utility(const double* d_entropy_y, int32_t n_channels, int64_t n_set
  * draws, particlepdf.py:330) and rng.standard_normal((n, d)) (inside multivariate_normal,
  * particlepdf.py:300).  h_state4 = {state_hi, state_lo, inc_hi, inc_lo} of
  * rng.bit_generator.state; d_raw[i] = the (i+1)-th next_uint64 of that generator. */
-int obe_pcg64_raw(const uint64_t* h_state4, int64_t n_raw, uint64_t* d_raw, void* stream);
+OBE_API int obe_pcg64_raw(const uint64_t* h_state4, int64_t n_raw, uint64_t* d_raw, void* stream);
 /* d_out[i] = (d_raw[i] >> 11) * 2^-53  (numpy next_double / Generator.random). */
-int obe_pcg64_uniform(const uint64_t* d_raw, int64_t n, double* d_out, void* stream);
+OBE_API int obe_pcg64_uniform(const uint64_t* d_raw, int64_t n, double* d_out, void* stream);
 /* The same draws without a buffer of raw values, in two stages (what obe_resample_begin enqueues): stage 1 —
  * ONE launch for the n_uniform uniforms of Generator.choice and the classification of the n_raw_normal raw
  * positions behind them, every thread carrying the generator state of its position (h_state4 as for
  * obe_pcg64_raw); stage 2 — start flags, scan and compaction of the first n normals into d_out, h_consumed as
  * for obe_ziggurat_normal.  d_ws of obe_ziggurat_workspace_bytes(n_raw_normal) bytes, the same for both. */
-int obe_pcg64_uniforms_classify(const uint64_t* h_state4, int64_t n_uniform, int64_t n_raw_normal,
+OBE_API int obe_pcg64_uniforms_classify(const uint64_t* h_state4, int64_t n_uniform, int64_t n_raw_normal,
                                 double* d_uniforms, const void* d_tables, void* d_ws, int64_t ws_bytes,
                                 void* stream);
-int obe_ziggurat_finish(int64_t n_raw_normal, int64_t n, double* d_out, int64_t* h_consumed, void* d_ws,
+OBE_API int obe_ziggurat_finish(int64_t n_raw_normal, int64_t n, double* d_out, int64_t* h_consumed, void* d_ws,
                         int64_t ws_bytes, void* stream);
 /* n standard normals by numpy's ziggurat from d_raw[offset...]: bit-identical values and
  * the exact number of raw values consumed (*h_consumed; sync), so the host generator can
@@ -536,17 +543,17 @@ int obe_ziggurat_finish(int64_t n_raw_normal, int64_t n, double* d_out, int64_t*
  * With obe_defer_host_sync on: h_consumed[0..1] receive {raw values consumed, normals found}
  * asynchronously and the return value only reports launch errors; after synchronising, the
  * caller checks them with obe_ziggurat_check (1 = buffer too short). */
-int64_t obe_ziggurat_workspace_bytes(int64_t n_raw);
-int obe_ziggurat_normal(const uint64_t* d_raw, int64_t n_raw, int64_t offset, const void* d_tables,
+OBE_API int64_t obe_ziggurat_workspace_bytes(int64_t n_raw);
+OBE_API int obe_ziggurat_normal(const uint64_t* d_raw, int64_t n_raw, int64_t offset, const void* d_tables,
                         int64_t n, double* d_out, int64_t* h_consumed,
                         void* d_ws, int64_t ws_bytes, void* stream);
-int obe_ziggurat_check(int64_t consumed, int64_t found, int64_t n, int64_t n_raw, int64_t offset);
+OBE_API int obe_ziggurat_check(int64_t consumed, int64_t found, int64_t n, int64_t n_raw, int64_t offset);
 
 /* ---- timing on the launch stream (bench.py roofline leg) ---- */
-int obe_timer_create(void** timer);
-int obe_timer_start(void* timer, void* stream);
-int obe_timer_stop(void* timer, void* stream, float* ms);   /* records, syncs, returns elapsed */
-int obe_timer_destroy(void* timer);
+OBE_API int obe_timer_create(void** timer);
+OBE_API int obe_timer_start(void* timer, void* stream);
+OBE_API int obe_timer_stop(void* timer, void* stream, float* ms);   /* records, syncs, returns elapsed */
+OBE_API int obe_timer_destroy(void* timer);
 /* Timing of the dominant sweep kernel inside real cycles: while enabled, every obe_sweep_utility
  * call that returns its result to the host brackets the sweep kernel with two events on its
  * stream and adds the elapsed time to a running total (the events are read after the stream
@@ -554,11 +561,11 @@ int obe_timer_destroy(void* timer);
  * launches accumulated so far, then: enable > 0 starts a fresh accumulation, enable == 0 stops
  * it, enable < 0 leaves the state alone (read only).  One accumulation per process (per loaded
  * library: a plugin keeps its own), not thread-safe.  bench.py: roofline.achieved. */
-int obe_sweep_timing(int32_t enable, double* h_total_ms, int64_t* h_launches);
+OBE_API int obe_sweep_timing(int32_t enable, double* h_total_ms, int64_t* h_launches);
 /* Launches only the dominant sweep kernel `iters` times between two events on `stream`
  * and returns the average per-launch duration in ms; iters < 0: -iters isolated launches
  * (the stream is drained before each one), as a measurement cycle issues them. */
-int obe_sweep_kernel_time(const obe_model* m,
+OBE_API int obe_sweep_kernel_time(const obe_model* m,
                           const double* d_settings, int64_t ld_s, int64_t n_settings,
                           const double* d_particles, int64_t ld_p, int64_t n_particles,
                           const double* d_weights, const double* d_moments, int32_t shifted,

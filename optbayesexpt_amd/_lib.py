@@ -15,10 +15,20 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libobe_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "obe_hip.h")
 
-OBE_MAX_CONSTS = 8
-OBE_MAX_CHANNELS = 4
-OBE_MAX_SETDIMS = 4
-OBE_MAX_DIMS = 16
+
+
+def _header_constants(path=HEADER_PATH):
+    """The #define'd integers of include/obe_hip.h (one source of truth for limits and the ABI version)."""
+    text = open(path).read()
+    return {k: int(v) for k, v in re.findall(r"^#define\s+(OBE_[A-Z_]+)\s+(-?\d+)\s*$", text, flags=re.M)}
+
+
+_H = _header_constants()
+OBE_ABI_VERSION = _H["OBE_ABI_VERSION"]
+OBE_MAX_CONSTS = _H["OBE_MAX_CONSTS"]
+OBE_MAX_CHANNELS = _H["OBE_MAX_CHANNELS"]
+OBE_MAX_SETDIMS = _H["OBE_MAX_SETDIMS"]
+OBE_MAX_DIMS = _H["OBE_MAX_DIMS"]
 OBE_WS_RESULT_OFFSET = 2      # doubles; include/obe_hip.h
 HOST_SENTINEL = 0x7ff8c0dec0dec0de     # the value of an armed host result word (csrc/obe_common.h: kHostSentinel)
 OBE_SWEEP_SHIFTED, OBE_SWEEP_SAFE, OBE_SWEEP_SPECULATIVE, OBE_SWEEP_NOWAIT = 1, 2, 8, 16      # bits of obe_sweep_utility's `shifted` argument
@@ -28,7 +38,16 @@ c_void_p, c_int, c_int32, c_int64, c_double = (ctypes.c_void_p, ctypes.c_int, ct
 
 
 class ObeHipError(RuntimeError):
-    """A libobe_hip call returned a non-zero status."""
+    """A libobe_hip call returned a non-zero status (``status``: -1 = the call was refused on its arguments
+    BEFORE anything was launched, include/obe_hip.h; anything else is a hipError_t of a launch or a wait)."""
+
+    def __init__(self, message, status=None):
+        RuntimeError.__init__(self, message)
+        self.status = status
+
+    @property
+    def refused_before_launch(self):
+        return self.status == -1
 
 
 class ObeModelStruct(ctypes.Structure):
@@ -161,8 +180,8 @@ class HipLib:
             fn.restype = restype
             fn.argtypes = argtypes
         abi = self.cdll.obe_abi_version()
-        if abi != 1:
-            raise ImportError(f"libobe_hip ABI {abi} does not match this package (1)")
+        if abi != OBE_ABI_VERSION:
+            raise ImportError(f"libobe_hip ABI {abi} does not match this package ({OBE_ABI_VERSION})")
         from . import build
         built_from = self.cdll.obe_source_fingerprint().decode()
         #: extra compiler flags of a tools/build_variant.py library ("" for the product build); such a
@@ -181,7 +200,7 @@ class HipLib:
     def call(self, name, *args):
         rc = getattr(self.cdll, name)(*args)
         if rc != 0:
-            raise ObeHipError(f"{name} failed (status {rc}): {self.last_error()}")
+            raise ObeHipError(f"{name} failed (status {rc}): {self.last_error()}", rc)
         return rc
 
     def workspace_bytes(self, n_particles, n_settings, n_channels, n_dims):

@@ -27,8 +27,22 @@ LIB = os.path.join(OUT_DIR, "libobe_hip.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
-         "-Wall", "-Wno-unused-function", f"-I{INCLUDE}"]
+# -fvisibility=hidden: the only dynamic symbols of the library (and of a plugin) are the entry points
+# include/obe_hip.h marks OBE_API; the C++ helpers and the kernels' host stubs stay internal
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",
+         "-fvisibility-inlines-hidden", "-Wall", "-Wno-unused-function", f"-I{INCLUDE}"]
+
+
+def _export_map(directory):
+    """Linker version script: the dynamic symbol table holds the obe_* entry points and nothing else.
+    (-fvisibility=hidden covers the C++ helpers; the host-side handle objects clang emits for every
+    __global__ kernel keep default visibility whatever the flag says, hence the list at link time.)"""
+    path = os.path.join(directory, "obe_exports.map")
+    text = "{ global: obe_*; local: *; };\n"
+    if not os.path.exists(path) or open(path).read() != text:
+        with open(path, "w") as f:
+            f.write(text)
+    return path
 
 
 def sources():
@@ -111,7 +125,8 @@ def build(force=False, verbose=False, only_if_stale=False):
             objs = list(ex.map(_compile, srcs))
         if force or _stale(LIB, objs):
             tmp = f"{LIB}.tmp{os.getpid()}"
-            cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp]
+            cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC",
+                   f"-Wl,--version-script={_export_map(OBJ_DIR)}"] + objs + ["-o", tmp]
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 if os.path.exists(tmp):
@@ -208,10 +223,12 @@ def build_plugin(header_text, model_digest, verbose=False):
 
             with concurrent.futures.ThreadPoolExecutor(max_workers=4) as ex:
                 objs = list(ex.map(one, PLUGIN_SOURCES))
-            # -Bsymbolic: calls between the plugin's own entry points must not be interposed by
-            # the same-named symbols of libobe_hip.so already loaded in the process
+            # -Bsymbolic: the entry points call one another (obe_model_validate from every model-dependent
+            # call, ...) and those calls must stay inside the plugin: libobe_hip.so, loaded RTLD_GLOBAL
+            # before it, exports the same names.  (Everything that is not an entry point is hidden.)
             tmp = os.path.join(scratch, os.path.basename(lib))
-            r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic"] + objs
+            r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic",
+                                f"-Wl,--version-script={_export_map(scratch)}"] + objs
                                + ["-o", tmp], capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError(f"plugin link failed:\n{r.stdout}\n{r.stderr}")

@@ -497,7 +497,9 @@ class OptBayesExpt(ParticlePDF):
             self._drop_speculative_sweep()
             try:
                 self._sweep_device(False, speculate="after_resample")
-            except _lib.ObeHipError:
+            except _lib.ObeHipError as exc:
+                if not exc.refused_before_launch:
+                    raise
                 self._sweeps.library_refused()
         return _LazyState(self)
 
@@ -569,9 +571,13 @@ class OptBayesExpt(ParticlePDF):
             self._mlib.call("obe_bayes_update_model_moments_enqueue", *args, _ptr(self._moments_dev),
                             _ptr(self._ws), self._ws_bytes, p_out, 1 if tp["auto_resample"] else 0,
                             float(tp["resample_threshold"]), st)
-        except _lib.ObeHipError:
-            # refused before anything was launched (no arrival counter for this stream, a workspace without the
-            # spare tail word): the weights are untouched — the plain form, now and from now on
+        except _lib.ObeHipError as exc:
+            if not exc.refused_before_launch:
+                # a launch (or the device) failed AFTER pass A may have multiplied the weights in place: re-running
+                # the update would apply the likelihood twice and hide the real error
+                raise
+            # refused before anything was launched (status -1: no arrival counter for this stream, a workspace
+            # without the spare tail word): the weights are untouched — the plain form, now and from now on
             self._sweeps.library_refused()
             self._mlib.call("obe_bayes_update_model_moments", *args, _ptr(self._moments_dev), _ptr(self._ws),
                             self._ws_bytes, p_out, st)
@@ -583,7 +589,9 @@ class OptBayesExpt(ParticlePDF):
         if self._speculation_wanted():
             try:
                 self._sweep_device(False, speculate=True)
-            except _lib.ObeHipError:
+            except _lib.ObeHipError as exc:
+                if not exc.refused_before_launch:
+                    raise
                 self._sweeps.library_refused()        # (nothing of the sweep was enqueued: refused before any launch)
         self._lib.call("obe_host_words_wait", p_out, 5 + 4 * d, st)
         self._sweeps.update_delivered(resampled=self._upd_host[4 + 4 * d] != 0.0)

@@ -72,8 +72,10 @@ class OptBayesExptNoiseParameter(OptBayesExpt):
                                    self._hargs.ptr_keep(self._moments_host), _lib.host_ptr(changed), _ptr(self._ws),
                                    self._ws_bytes, self._stream())
                     done = True
-                except _lib.ObeHipError:
-                    pass          # (refused before any launch: the full form below finds the same particles)
+                except _lib.ObeHipError as exc:
+                    if not exc.refused_before_launch:
+                        raise
+                    # (refused before any launch: the full form below finds the same particles)
             if not done:
                 self._lib.call("obe_mask_nonpositive_moments", _ptr(par), par.shape[1], self.n_dims, self.n_particles,
                                _lib.host_ptr(self._noise_rows), self.n_channels, _ptr(w), _ptr(self._moments_dev),

@@ -31,7 +31,46 @@ def test_library_exports_every_declared_symbol(lib):
     for name in declared:
         assert hasattr(lib.cdll, name), f"{name} declared in obe_hip.h but not exported"
     assert set(declared) == set(_lib._SIGNATURES), "ctypes table and header disagree"
-    assert lib.cdll.obe_abi_version() == 1
+    assert lib.cdll.obe_abi_version() == _lib.OBE_ABI_VERSION == 2
+
+
+def _dynamic_symbols(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+
+
+def test_library_exports_nothing_but_the_declared_entry_points(lib):
+    """`nm -D --defined-only` of libobe_hip.so == the names include/obe_hip.h declares (OBE_API), no more: the
+    C++ helpers (obe::wait_host_words, obe::stream_control_words, ...), the kernels' host stubs and handle objects
+    are internal (-fvisibility=hidden + the link-time export list, optbayesexpt_amd/build.py)."""
+    import shutil
+    if shutil.which("nm") is None:
+        pytest.skip("no nm on this box")
+    declared = _lib.declared_symbols()
+    assert _dynamic_symbols(lib.path) == declared
+
+
+def test_plugin_exports_nothing_but_the_declared_entry_points(lib):
+    """... and the same for a per-model plugin library: it defines a SUBSET of the header's names (the
+    model-dependent entry points + the three library queries) and nothing else, so that two plugins and the library
+    in one process cannot interpose one another's internals."""
+    import os
+    import shutil
+    from optbayesexpt_amd import build
+    if shutil.which("nm") is None:
+        pytest.skip("no nm on this box")
+    model = None
+    try:
+        model = models.from_expression("b + a / (((x - x0) / d)**2 + 1)", settings=("x",),
+                                       parameters=("x0", "a", "b"), constants=("d",))
+    except RuntimeError:
+        if os.path.exists(build.HIPCC):
+            raise
+        pytest.skip("plugin not prebuilt and no hipcc here")
+    syms = _dynamic_symbols(model.plugin_path)
+    assert set(_lib.MODEL_ENTRY_POINTS) | {"obe_abi_version", "obe_last_error", "obe_source_fingerprint"} <= set(syms)
+    assert set(syms) <= set(_lib.declared_symbols()), sorted(set(syms) - set(_lib.declared_symbols()))
 
 
 def test_ctypes_argument_counts_match_header():

@@ -168,9 +168,23 @@ def test_c5_ten_parameter_noise_model_matches_oracle_on_the_whole_grid(obe):
     nv = oracle.mean_noise_variance(o.particles, 9, o.particle_weights)
     assert_allclose(o.yvar_noise_model(), nv, rtol=1e-12)
     assert_allclose(o.utility(), yvar[0] / nv[0, 0], rtol=1e-12)
-    csweep = _csweep_or_skip()
-    pick, ref = _host_grid(csweep, settings, np.array(o.particles), np.array(o.particle_weights), cons[0], 7, "c5")
+    pick, ref = _c5_reference(settings, np.array(o.particles), np.array(o.particle_weights), cons)
     _full_grid_check(o, ref, ref / nv[0, 0], "c5", pick)
+
+
+_C5_REF = {}
+
+
+def _c5_reference(settings, particles, weights, cons):
+    """oracle/csweep.c over the whole c5 grid for this posterior, computed once per test session: the whole-grid test
+    and the 8-shard test build the same posterior (same seeds, same bits — checked here) and share the 7 s of host time."""
+    hit = _C5_REF.get("c5")
+    if hit is not None and np.array_equal(hit[0], weights) and np.array_equal(hit[1], particles):
+        return hit[2], hit[3]
+    csweep = _csweep_or_skip()
+    pick, ref = _host_grid(csweep, settings, particles, weights, cons[0], 7, "c5")
+    _C5_REF["c5"] = (weights, particles, pick, ref)
+    return pick, ref
 
 
 def test_sweep_invariances_at_c2_size(obe):
@@ -233,7 +247,8 @@ def test_c4_the_eight_settings_shards_of_c3(obe):
     this GPU: each of the 8 ranks sweeps its 8 192-setting slice of the real c3 posterior (three updates).  The
     union of the slices is the one-GPU sweep (1e-13: only the chunk partial-sum order differs), the first
     maximum over the 8 rank records is the global arg-max (np.argmax's tie rule), and after one more update
-    through every rank the replicated clouds are bit-identical to the one-GPU run's."""
+    through every rank the replicated clouds are bit-identical to the one-GPU run's — and after a further update that
+    is forced to RESAMPLE (particlepdf.py:260-310) they still are: indices, particles, weights, generator state."""
     from optbayesexpt_amd.dist import first_max, shard_bounds
     settings, prior, cons, true, sigma = bench.make_workload("c3")
     ns = settings[0].size
@@ -251,6 +266,8 @@ def test_c4_the_eight_settings_shards_of_c3(obe):
     record = (x, float(full.model_function(x, true, cons)) + 123.0, sigma)
     full.pdf_update(record)
     w_after = np.array(full.particle_weights)
+    record2 = ((3.02,), float(full.model_function((3.02,), true, cons)) - 77.0, sigma)
+    after = _forced_resample(full, record2)               # (auto_resample on, threshold 1.0: this update resamples)
     OneRank = _one_rank_class()
     vals, idxs, parts, utils = [], [], [], []
     for r in range(8):
@@ -267,11 +284,107 @@ def test_c4_the_eight_settings_shards_of_c3(obe):
         assert o._s_begin <= i < o._s_end and v == utils[-1][i - o._s_begin]
         o.pdf_update(record)                              # the replica's update: the same bits as the one-GPU run
         assert_array_equal(np.array(o.particle_weights), w_after)
+        _assert_same_resample(o, after, record2, f"c4 rank {r}")       # ... and a resampling update, the same bits too
         del o
     assert_allclose(np.concatenate(parts), base, rtol=1e-13, atol=0.0)
     assert_allclose(np.concatenate(utils), util, rtol=1e-13, atol=0.0)
     k = first_max(np.array(vals), np.array(idxs))
     assert idxs[k] == best and vals[k] == pytest.approx(util[best], rel=1e-13)
+
+
+RESAMPLE_SEED = 77
+
+
+def _forced_resample(o, record):
+    """One more pdf_update() with the resample test on and a threshold that forces the resample
+    (particlepdf.py:236-310; obe_noiseparam.py:57-79 behind it for the noise-parameter class): the device
+    continuation of the caller's generator, the (masked) gather, the nudge, the constraint renormalisation.
+    Returns everything a replica must reproduce BIT FOR BIT."""
+    o.tuning_parameters["auto_resample"] = True
+    o.tuning_parameters["resample_threshold"] = 1.0
+    o.rng = np.random.default_rng(RESAMPLE_SEED)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        o.pdf_update(record)
+    assert o.just_resampled
+    out = dict(indices=o.last_resample_indices_device.cpu().numpy().copy(), particles=np.array(o.particles),
+               weights=np.array(o.particle_weights), rng=o.rng.bit_generator.state,
+               mean=o.mean(), std=o.std())
+    if hasattr(o, "last_constraint_count"):
+        out["constraint_count"] = o.last_constraint_count
+    return out
+
+
+def _assert_same_resample(o, want, record, what):
+    got = _forced_resample(o, record)
+    assert set(got) == set(want)
+    assert_array_equal(got["indices"], want["indices"], err_msg=f"{what}: resample indices")
+    assert_array_equal(got["particles"], want["particles"], err_msg=f"{what}: resampled particles")
+    assert_array_equal(got["weights"], want["weights"], err_msg=f"{what}: weights after the resample")
+    assert got["rng"] == want["rng"], f"{what}: generator state after the resample"
+    assert_array_equal(got["mean"], want["mean"], err_msg=f"{what}: mean")
+    assert_array_equal(got["std"], want["std"], err_msg=f"{what}: std")
+    if "constraint_count" in want:
+        assert got["constraint_count"] == want["constraint_count"], what
+
+
+def test_c5_eight_noise_parameter_shards_at_full_size(obe):
+    """BASELINE config c5 in the form BASELINE.json states it: 16 384 settings x 524 288 particles x 10 parameters,
+    OptBayesExptNoiseParameter, the settings axis in 8 shards of 2 048 (one rank at a time on this GPU; the noise
+    variance of every rank's utility comes from the replicated moment block, obe_noiseparam.py:122-136).
+    (a) union of the 8 slices == the one-GPU sweep at 1e-13 and the first maximum over the 8 rank records == the
+    arg-max of the INDEPENDENT host vector (oracle/csweep.c, shared with the whole-grid test);
+    (b) one more pdf_update() through every replica that is forced to resample (device RNG continuation, masked
+    gather, nudge, constraint renormalisation — obe_noiseparam.py:57-136, particlepdf.py:260-310): resample indices,
+    particles, weights, last_constraint_count and the generator state bit-identical on all 8 replicas and the
+    one-GPU run."""
+    from optbayesexpt_amd.dist import first_max, shard_bounds
+    settings, prior, cons, true, sigma = bench.make_workload("c5")
+    ns = settings[0].size
+    full = bench.build_obe("c5", None, settings, prior.copy(), cons)
+    full.rng = np.random.default_rng(5)
+    full.tuning_parameters["auto_resample"] = False
+    _updated(full, true, cons, sigma, noise=False)
+    w = np.array(full.particle_weights)
+    assert 0.0 < 1.0 / np.sum(w * w) / w.size < 0.9
+    base = full.yvar_from_parameter_draws()[0]
+    util = full.utility()
+    x = full.opt_setting()
+    best = full.last_setting_index
+    assert best == int(np.argmax(util))
+    shifted = bool(full.last_sweep["shifted"])
+    nv = oracle.mean_noise_variance(full.particles, 9, w)
+    pick, ref = _c5_reference(settings, np.array(full.particles), w, cons)
+    independent_best = int(np.argmax(ref / nv[0, 0])) if pick.size == ns else None
+    record = (x, float(full.model_function(x, true, cons)) + 40.0)
+    after = _forced_resample(full, record)
+    assert after["constraint_count"] > 0                  # (sigma ~ Exp(500): the nudge pushes some sigma below zero)
+    assert np.sum(after["weights"] == 0.0) == after["constraint_count"]
+    OneRank = _one_rank_class()
+    vals, idxs, parts, utils = [], [], [], []
+    for r in range(8):
+        o = bench.build_obe("c5", OneRank(rank=r, world_size=8), settings, prior.copy(), cons)
+        assert type(o).__name__ == "OptBayesExptNoiseParameter"
+        assert (o._s_begin, o._s_end) == shard_bounds(ns, r, 8) == (r * 2048, (r + 1) * 2048)
+        o.tuning_parameters["auto_resample"] = False
+        o.tuning_parameters["sweep_shift"] = "always" if shifted else "never"
+        o.particle_weights = w
+        v, i = o._sweep_device(True)
+        vals.append(v)
+        idxs.append(i)
+        parts.append(o._yvar_dev.cpu().numpy()[0].copy())
+        utils.append(o._utility_dev.cpu().numpy().copy())
+        assert o._s_begin <= i < o._s_end and v == utils[-1][i - o._s_begin]
+        _assert_same_resample(o, after, record, f"c5 rank {r}")
+        del o
+    assert_allclose(np.concatenate(parts), base, rtol=1e-13, atol=0.0)
+    assert_allclose(np.concatenate(utils), util, rtol=1e-13, atol=0.0)
+    k = first_max(np.array(vals), np.array(idxs))
+    assert idxs[k] == best and vals[k] == pytest.approx(util[best], rel=1e-13)
+    if independent_best is not None:
+        assert idxs[k] == independent_best, (idxs[k], independent_best)
+    else:
+        print("c5 shards: the host was too slow for the full independent grid; arg-max checked against the one-GPU sweep only")
 
 
 def test_update_and_resample_at_one_million_particles(obe):
