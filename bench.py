@@ -29,8 +29,11 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   other_configs — (default c3 run, N = 1) the cycle loops of c1, c2 and c5 after the timed region, each with its
                   own bounded CPU leg.
   rccl          — (N > 1, or --force-dist) what the communicator itself reports: its world size, an all-gather of
-                  the rank ids, the measured arg-max combine (in the timed cycles and on an idle stream) and
-                  every rank's cycle / K1 / everything-else milliseconds.
+                  the rank ids, the measured arg-max combine (in the timed cycles and on an idle stream),
+                  every rank's cycle / K1 / everything-else milliseconds and the CPU affinity each rank gave itself
+                  (the cores of its GPU's NUMA node, before torch was imported).
+  projection    — (N > 1) what ONE rank's measured cycle on one GPU predicted for this config and world size
+                  (profiles/shard_projection.json, tools/shard_cycle.py) next to what this run measured.
 With --gpus N > 1 and no launcher around it (no WORLD_SIZE in the environment) the script starts its N
 ranks itself, as fresh child processes, before anything here touches the GPU.
 """
@@ -215,6 +218,87 @@ def published_workload(cycles=1500, warm=100):
             "speedup_vs_published_numpy": (13109.0 / 3000) / ms}
 
 
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the kernel's cpulist format)."""
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def format_cpulist(cpus):
+    cpus, parts = sorted(set(cpus)), []
+    i = 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        parts.append(str(cpus[i]) if i == j else f"{cpus[i]}-{cpus[j]}")
+        i = j + 1
+    return ",".join(parts)
+
+
+def gpu_local_cpus(index, sysfs="/sys"):
+    """(cpus, numa node) local to HIP device ``index`` of this node, read from sysfs ONLY — no HIP, no torch, no
+    rocm-smi: this runs in the launcher, and in every rank before anything has touched the GPU.  The runtime
+    enumerates GPUs in KFD topology order (the nodes with SIMDs under /sys/class/kfd/kfd/topology/nodes); each
+    names its DRM render node, whose PCI device directory carries local_cpulist / numa_node.  ROCR_VISIBLE_DEVICES
+    / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES lists of integers are applied in that order.  None if anything is
+    missing (a container without /sys/class/kfd, UUID-style visibility lists): then nothing is pinned."""
+    try:
+        nodes = os.path.join(sysfs, "class/kfd/kfd/topology/nodes")
+        gpus = []
+        for name in sorted(os.listdir(nodes), key=int):
+            props = dict(line.split()[:2] for line in open(os.path.join(nodes, name, "properties")) if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                gpus.append(int(props["drm_render_minor"]))
+        order = list(range(len(gpus)))
+        for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+            val = os.environ.get(var)
+            if val is None or (var == "CUDA_VISIBLE_DEVICES" and "HIP_VISIBLE_DEVICES" in os.environ):
+                continue
+            order = [order[int(k)] for k in val.split(",") if k.strip() != ""]
+        dev = os.path.join(sysfs, f"class/drm/renderD{gpus[order[index]]}/device")
+        cpus = parse_cpulist(open(os.path.join(dev, "local_cpulist")).read())
+        node = int(open(os.path.join(dev, "numa_node")).read())
+        return (cpus, node) if cpus else None
+    except (OSError, ValueError, KeyError, IndexError):
+        return None
+
+
+def pin_to_gpu_numa_node(local_rank):
+    """Before any torch / HIP import of a rank of an N > 1 run: restrict this process (and every thread it will
+    start) to the cores of its GPU's NUMA node.  A rank's cycle holds ~0.25 ms that does not shard — host round
+    trips, spin-waits on page-locked result words that the GPU writes over PCIe, the Python between two library
+    calls — and a rank scheduled on the far socket pays the inter-socket hop on every one of them.  OBE_BENCH_CPUS
+    (a cpulist, set by this script's own launcher) wins; OBE_BENCH_PIN=0 switches it off.  Returns what was done,
+    for the "rccl" block of the line."""
+    if os.environ.get("OBE_BENCH_PIN", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return {"pinned": False, "why": "switched off" if hasattr(os, "sched_setaffinity") else "no sched_setaffinity"}
+    node = None
+    given = os.environ.get("OBE_BENCH_CPUS")
+    if given:
+        cpus = parse_cpulist(given)
+        node = int(os.environ.get("OBE_BENCH_NUMA_NODE", "-1"))
+    else:
+        found = gpu_local_cpus(local_rank)
+        if found is None:
+            return {"pinned": False, "why": "no KFD topology / local_cpulist in sysfs"}
+        cpus, node = found
+    allowed = os.sched_getaffinity(0)
+    want = sorted(set(cpus) & allowed)
+    if not want:
+        return {"pinned": False, "why": "the GPU's local cores are outside this process's cpuset", "numa_node": node}
+    try:
+        os.sched_setaffinity(0, want)
+    except OSError as exc:
+        return {"pinned": False, "why": str(exc), "numa_node": node}
+    return {"pinned": True, "numa_node": node, "cpus": format_cpulist(want), "n_cpus": len(want)}
+
+
 def launch_ranks(n, argv):
     """``python bench.py --gpus N`` without a launcher around it: start one child process per GPU
     (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment, as torch.distributed.run would set
@@ -231,7 +315,18 @@ def launch_ranks(n, argv):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OBE_BENCH_CHILD="1")
+        # This pool's host driver only supports dmabuf IPC: with the legacy mode RCCL's intra-node transport (and any
+        # device-tensor sharing across processes) fails at communicator set-up with `hipIpcGetMemHandle: invalid
+        # argument`.  The image exports the variable already; a rank started from a scrubbed environment needs it too
+        # ("More than one GPU").  Harmless where the legacy mode works: it only selects the other path.
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # the cores of the rank's GPU, found here (the launcher never touches a GPU) and applied by the child before
+        # it imports torch (pin_to_gpu_numa_node)
+        local = None if os.environ.get("OBE_BENCH_ONE_DEVICE") else gpu_local_cpus(r)
+        if local is None and os.environ.get("OBE_BENCH_ONE_DEVICE"):
+            local = gpu_local_cpus(0)
+        if local is not None and "OBE_BENCH_CPUS" not in os.environ:
+            env["OBE_BENCH_CPUS"], env["OBE_BENCH_NUMA_NODE"] = format_cpulist(local[0]), str(local[1])
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr))
     out0 = procs[0].stdout
@@ -270,7 +365,34 @@ def launch_ranks(n, argv):
     return 0
 
 
-def collective_report(obe, shard, backend, world, rank, ns, steps, elapsed_local, k1_total_ms, k1_launches, k1_cycles):
+def projection_from_one_rank(cfg, world, measured_ms_per_step, combine_us):
+    """What tools/shard_cycle.py predicted for this (config, world size) from ONE rank's measured cycle on ONE GPU
+    (profiles/shard_projection.json, committed with the round's profiles), put next to what this run measured, so
+    that a SCALE line can be read against the projection without another round: predicted speed-up = one-GPU
+    cycle / (rank cycle + all-gather), for the all-gather latencies the projection brackets and for the combine
+    THIS run measured on an idle stream."""
+    path = os.path.join(ROOT, "profiles", "shard_projection.json")
+    try:
+        e = json.load(open(path))[cfg][str(world)]
+    except (OSError, KeyError, ValueError):
+        return {"available": False, "why": f"no entry for {cfg} x {world} ranks in profiles/shard_projection.json"}
+    one, rank_ms = e["one_gpu_ms_per_cycle"], e["rank_ms_per_cycle"]
+    out = {"available": True, "source": "profiles/shard_projection.json (tools/shard_cycle.py: one rank's slice through "
+                                        "the same cycles on one GPU, the collective replaced by a device-to-host read)",
+           "projection_cycles": {"steps": e["steps"], "warmup": e["warmup"], "resamples": e["resamples"]},
+           "one_gpu_ms_per_cycle_then": one, "rank_ms_per_cycle_then": rank_ms,
+           "predicted_speedup_from_rank_cycle": {f"{us}us_all_gather": one / (rank_ms + 1e-3 * us) for us in (0, 30, 60, 100)},
+           "measured_ms_per_step_now": measured_ms_per_step,
+           "measured_speedup_vs_one_gpu_cycle_then": one / measured_ms_per_step,
+           "note": "the driver computes the scaling ratio itself from its own N = 1 run; this block only says what one "
+                   "rank's measured cycle predicted, under the cycle mix (resamples) the projection was made with"}
+    if combine_us is not None:
+        out["predicted_speedup_with_this_runs_idle_combine"] = one / (rank_ms + 1e-3 * combine_us)
+    return out
+
+
+def collective_report(obe, shard, backend, world, rank, ns, steps, elapsed_local, k1_total_ms, k1_launches, k1_cycles,
+                      affinity=None):
     """The "rccl" block of an N > 1 line: proof that the communicator saw N ranks, and where each rank's time
     went.  (1) an all-gather in which every rank contributes its rank id; (2) the arg-max combine of the timed
     cycles: device microseconds between this rank's record being ready and everybody's having arrived (events
@@ -315,7 +437,12 @@ def collective_report(obe, shard, backend, world, rank, ns, steps, elapsed_local
         return {"min": float(np.nanmin(vals)), "max": float(np.nanmax(vals)),
                 "per_rank": [None if np.isnan(v) else float(v) for v in vals]}
 
+    masks = [None] * world
+    dist.all_gather_object(masks, affinity)
     return {"backend": dist.get_backend(), "world_size_reported_by_backend": dist.get_world_size(),
+            "cpu_affinity_per_rank": masks,
+            "cpu_affinity_note": "set by each rank before it imported torch: the cores of its GPU's NUMA node (sysfs: KFD "
+                                 "topology -> DRM render node -> local_cpulist); OBE_BENCH_PIN=0 switches it off",
             "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None),
             "all_gather_rank_ids": ids, "all_gather_rank_ids_ok": ids == list(range(world)),
             "instrumented_cycles": int(k1_cycles),
@@ -466,11 +593,15 @@ def main():
         # no launcher around this process: be the launcher (nothing here has touched the GPU yet)
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
-    import torch
-    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    affinity = {"pinned": False, "why": "one rank: the CPU baselines of an N = 1 line use every core"}
+    if world > 1 or os.environ.get("OBE_BENCH_PIN") == "1":
+        # BEFORE torch / HIP are imported (threads started later inherit the mask; nothing here touches the GPU)
+        affinity = pin_to_gpu_numa_node(0 if os.environ.get("OBE_BENCH_ONE_DEVICE") else local_rank)
+    import torch
+    import torch.distributed as dist
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launched by a torch.distributed.run with "
                  f"a different --nproc-per-node?)")
@@ -483,7 +614,7 @@ def main():
     shard = None
     use_dist = world > 1 or args.force_dist
     if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (dmabuf IPC only on this pool: see launch_ranks)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", "0")
@@ -537,6 +668,8 @@ def main():
         if use_dist:
             dist.barrier()
 
+    if os.environ.get("OBE_BENCH_DIE_RANK") == str(rank) and world > 1:
+        os._exit(17)       # test hook (tests/test_gpu_two_ranks.py): a rank that dies while its peers head for a collective
     warmed_ms = warm_clocks(obe)          # (untimed; see warm_clocks: the chip's clocks, not the code's caches)
     # state for the benchmark: a few real updates (non-uniform weights), SURVEY §8(d)
     for k in range(max(args.warmup, 0)):
@@ -578,7 +711,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         rccl = collective_report(obe, shard, backend, world, rank, ns, args.steps, elapsed_local,
-                                 k1_total_ms.value, k1_launches.value, k1_cycles)
+                                 k1_total_ms.value, k1_launches.value, k1_cycles, affinity)
 
     n_draws = obe.N_DRAWS if obe.utility_method == "variance_approx" else n_p
     evals_per_step = ns * n_draws + n_p
@@ -737,6 +870,9 @@ def main():
            "roofline": roofline, "roofline_update": roofline_update}
     if rccl is not None:
         out["rccl"] = rccl
+        if world > 1:
+            out["projection"] = projection_from_one_rank(cfg, world, 1e3 * elapsed / args.steps,
+                                                         rccl["combine_us_idle_median"]["max"])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # (before the CPU legs: the 128-thread OpenMP run leaves the host busy for a while, and this loop is
         # ~25 us of host time per cycle)

@@ -201,6 +201,8 @@ class HipLib:
         rc = getattr(self.cdll, name)(*args)
         if rc != 0:
             raise ObeHipError(f"{name} failed (status {rc}): {self.last_error()}", rc)
+        if _AUDIT_ON:
+            audit.after_call(name, args)          # OBE_CHECK_DELIVERY=1 (_audit.py): which host words are armed now
         return rc
 
     def workspace_bytes(self, n_particles, n_settings, n_channels, n_dims):
@@ -250,6 +252,8 @@ class DeviceBound:
 
 
 import contextlib                         # noqa: E402
+from ._audit import audit                 # noqa: E402
+_AUDIT_ON = audit.on
 _NO_GUARD = contextlib.nullcontext()
 
 _LIB = None
@@ -311,43 +315,52 @@ class HostArgs:
 # Page-locked landing zones outlive the objects that own them until the device has drained.  Kernels write their
 # results straight into such memory, and some of them are deliberately not waited for (the sweep enqueued behind an
 # update, the sum(w) of a small draw, the moments behind a constraint mask): when their object is garbage-collected
-# with such a kernel still in flight, torch's caching host allocator would hand the block to the NEXT pin_memory()
-# call at once — the next object's landing zone — and the late kernel would write into it (found by
-# tools/soak_ranks.py once it mixed object classes: a spurious "Probabilities do not sum to 1").  So a released
-# block goes to a limbo list instead, and the list is emptied only behind a device synchronisation.
-_LIMBO = []
+# with such a kernel still in flight, torch's caching host allocator — which knows nothing of kernels that write host
+# memory themselves — would hand the block to the NEXT pin_memory() call at once, i.e. the next object's landing
+# zone, and the late kernel would write into it (found by tools/soak_ranks.py once it mixed object classes: a
+# spurious "Probabilities do not sum to 1").  So a released block goes to a limbo list instead, with the device
+# whose kernels write it, and the list is emptied only behind a synchronisation of exactly those devices.
+# (Device memory needs no such care: torch's device allocator reuses a block on the stream it was used on, and every
+# kernel of this package runs on that stream or on a side stream that is joined back before the call returns.)
+_LIMBO = []                # (keeper, device index)
 _LIMBO_MAX = 64
+_NO_LIMBO = os.environ.get("OBE_NO_LIMBO") == "1"
 
 
-def _retire_pinned(keeper):
-    _LIMBO.append(keeper)
+def _current_device_index():
+    import torch
+    try:
+        return torch.cuda.current_device() if torch.cuda.is_available() else None
+    except Exception:
+        return None
 
 
-def _purge_limbo():
-    if len(_LIMBO) < _LIMBO_MAX:
+def _retire_pinned(keeper, device):
+    audit.zone_released(keeper)
+    if _NO_LIMBO:            # (test hook: the behaviour before round 5's fix — the block goes straight back to the allocator)
+        audit.zone_freed(keeper, drained=False)
+        return
+    _LIMBO.append((keeper, device))
+
+
+def _purge_limbo(force=False):
+    """Empties the limbo list once it holds _LIMBO_MAX blocks: synchronises the devices those blocks belong to —
+    and no others: a rank of a multi-GPU job sees every GPU of the node, and touching one it does not use would
+    create a context there — and only then lets the allocator have them."""
+    if len(_LIMBO) < _LIMBO_MAX and not force:
         return
     import torch
     try:
-        if torch.cuda.is_available():
-            for d in range(torch.cuda.device_count()):
-                torch.cuda.synchronize(d)
+        for d in sorted({d for _, d in _LIMBO if d is not None}):
+            torch.cuda.synchronize(d)
     except Exception:        # (interpreter shutdown, a device that is gone: keep the blocks)
         return
+    for keeper, _ in _LIMBO:
+        audit.zone_freed(keeper, drained=True)
     del _LIMBO[:]
 
 
-def pinned_tensor(n, dtype):
-    """A zeroed page-locked torch tensor whose storage is not recycled while a kernel of its (former) owner may
-    still write to it (see above)."""
-    import torch
-    import weakref
-    _purge_limbo()
-    t = torch.zeros(n, dtype=dtype).pin_memory()
-    weakref.finalize(t, _retire_pinned, t.detach())       # (the detached alias keeps the storage, not the object)
-    return t
-
-
-def pinned_array(n, dtype=np.float64):
+def pinned_array(n, dtype=np.float64, device=None):
     """A zeroed page-locked host array (NumPy view of a pinned torch tensor, which it keeps alive).
     The kernels that end a call write their few result scalars straight into such memory; a pageable
     array works too, through a small device-to-host copy."""
@@ -355,8 +368,10 @@ def pinned_array(n, dtype=np.float64):
     import weakref
     _purge_limbo()
     t = torch.zeros(n, dtype=torch.from_numpy(np.zeros(0, dtype=dtype)).dtype).pin_memory()
-    a = t.numpy()             # the array's base keeps the pinned storage alive ...
-    weakref.finalize(a, _retire_pinned, t)                # ... and when the array goes, the limbo list does
+    a = audit.wrap(t.numpy())             # the array's base keeps the pinned storage alive ...
+    dev = _current_device_index() if device is None else device
+    weakref.finalize(a, _retire_pinned, t, dev)            # ... and when the array goes, the limbo list does
+    audit.zone_created(t.data_ptr(), t.numel() * t.element_size(), t)
     return a
 
 

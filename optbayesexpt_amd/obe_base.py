@@ -101,12 +101,13 @@ class _SweepIO:
 
     @staticmethod
     def still_armed(block):
-        words = block.view(np.int64)
+        words = _lib.audit.raw(block).view(np.int64)          # (a poll of armed words, on purpose)
         armed = _lib.HOST_SENTINEL                                        # (positive as a signed word too)
         return bool(words[0] == armed or words[1] == armed or words[2] == armed)
 
     def synchronize(self):
         torch.cuda.synchronize(self._owner._device)
+        _lib.audit.synchronized()
 
 
 class OptBayesExpt(ParticlePDF):
@@ -1108,7 +1109,7 @@ class OptBayesExpt(ParticlePDF):
         total = self._total_pinned
         stream = self._stream()
         self._lib.call("obe_host_word_arm", idx_hptr)        # the index is the search kernel's last word: watched, not synchronised
-        total_ptr = _P(total.data_ptr() + 8)
+        total_ptr = self._total_ptrs[1]
         self._lib.call("obe_host_word_arm", total_ptr)       # ... and so is sum(p), a store of its own to a line of its own:
         self._lib.call("obe_draw_indices", _ptr(prob), n, 0, 0, _ptr(cdf), _lib.host_ptr(uni), 1,
                        idx_dev, total_ptr, _ptr(self._ws), self._ws_bytes, stream)

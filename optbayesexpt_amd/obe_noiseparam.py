@@ -98,13 +98,16 @@ class OptBayesExptNoiseParameter(OptBayesExpt):
 
     def _resample_mask_rows(self):
         """The gather of a resample may apply this class's constraint itself when that constraint is certain to
-        follow: the resample runs inside pdf_update() (which calls enforce_parameter_constraints() right after it —
-        a resample() called on its own must leave uniform weights, like the reference's), the hook is this class's
-        own, and tuning_parameters['mask_in_gather'] (default True) does not say otherwise."""
-        if not self.__dict__.get("_constraint_follows") or not self.tuning_parameters.get("mask_in_gather", True) \
+        follow: the resample is the one resample_test() runs and reports through ``just_resampled``, inside this
+        class's pdf_update() (which then calls enforce_parameter_constraints() — a resample() reached any other way,
+        on its own or from an overriding hook, must leave uniform weights, like the reference's), every hook on that
+        path is the class's own, and tuning_parameters['mask_in_gather'] (default True) does not say otherwise."""
+        if not self.__dict__.get("_constraint_follows") or not self.__dict__.get("_in_reported_resample") \
+                or not self.tuning_parameters.get("mask_in_gather", True) \
                 or _overridden(self, "enforce_parameter_constraints", OptBayesExpt, OptBayesExptNoiseParameter) \
-                or _overridden(self, "resample_test", ParticlePDF) or _overridden(self, "resample", ParticlePDF):
-            return None           # (a replaced resample test might resample without reporting it: no constraint would follow)
+                or _overridden(self, "resample_test", ParticlePDF) or _overridden(self, "resample", ParticlePDF) \
+                or _overridden(self, "bayesian_update", ParticlePDF):
+            return None           # (a replaced hook might resample without reporting it: no constraint would follow)
         return self._noise_rows, self.n_channels
 
     def pdf_update(self, measurement_record, y_model_data=None):
@@ -114,6 +117,13 @@ class OptBayesExptNoiseParameter(OptBayesExpt):
             return OptBayesExpt.pdf_update(self, measurement_record, y_model_data)
         finally:
             self._constraint_follows = False
+            masked = self.__dict__.get("_masked_by_gather")
+            if masked is not None:
+                # a gather masked the weights and no enforce_parameter_constraints() consumed it (an exception between
+                # the two): what the reference's resample() leaves behind is uniform weights (particlepdf.py:308-309)
+                self._masked_by_gather = None
+                if masked == (self._particles.version, self._weights.version):
+                    self.particle_weights = np.ones(self.n_particles) / self.n_particles
 
     @property
     def last_constraint_count(self):

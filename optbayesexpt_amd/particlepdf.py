@@ -9,7 +9,6 @@ covariance (LAPACK, exactly as ``Generator.multivariate_normal`` does it).
 """
 import ctypes
 import warnings
-import weakref
 
 import numpy as np
 import torch
@@ -18,19 +17,6 @@ from . import _devrng, _lib
 from ._mirror import Mirror
 
 _P = ctypes.c_void_p
-
-
-def _drain(device):
-    """Finaliser of every ParticlePDF: the device work an object enqueued does not outlive it.  Some of that work is
-    deliberately not waited for while the object lives (the sweep enqueued behind an update, the moments behind a
-    constraint mask, the sum(w) of a small draw); an object dropped with such kernels in flight hands its buffers and
-    landing zones back to the allocators while they are still being written.  tools/soak_ranks.py, once it mixed
-    object classes, saw the next object misbehave about once in 10^4 short-lived objects; with a drain at the end of
-    every object's life: never.  Costs nothing while an object lives; deleting one waits for its last kernels."""
-    try:
-        torch.cuda.synchronize(device)
-    except Exception:        # (interpreter shutdown, a device that is gone)
-        pass
 
 
 SQRT_EPS = float(np.sqrt(np.finfo(np.float64).eps))   # numpy's tolerance on sum(p) in choice()
@@ -67,7 +53,6 @@ class ParticlePDF:
         if self._device.index is None:
             self._device = torch.device("cuda", torch.cuda.current_device())
         self._device_index = self._device.index
-        weakref.finalize(self, _drain, self._device)
         # kernels are launched with this object's device current, whatever the caller's is
         self._lib = _lib.DeviceBound(lib, self._device)
 
@@ -132,10 +117,9 @@ class ParticlePDF:
         self._mom_dev_key = None       # same, for the device copy
         self._cdf_dev = torch.empty(n, dtype=torch.float64, device=self._device)
         self._cdf_key = None           # (weights version, strict)
-        self._total_pinned = _lib.pinned_tensor(8, torch.float64)   # async sum(w) of a small draw
-        # page-locked landing zones of the pipelined resample: [0] sum(w), [1:] the moments block; {consumed, found}
-        self._pinned_f64 = _lib.pinned_tensor(self._lib.moments_len(d) + 8, torch.float64)
-        self._pinned_i64 = _lib.pinned_tensor(8, torch.int64)
+        # [0] the asynchronous sum(w) of a small draw, [1] sum(p) of good_setting(): page-locked, each watched on its own
+        self._total_pinned = _lib.pinned_array(8)
+        self._total_ptrs = (_P(self._total_pinned.ctypes.data), _P(self._total_pinned.ctypes.data + 8))
         self._pending_total = None     # (generator state before the draw,) while that sum is unchecked
         self._sumsq_key = None         # weights version for which _sumsq is valid
         self._sumsq = None
@@ -307,13 +291,22 @@ class ParticlePDF:
                           f"N_eff = {n_eff:.2f}. "
                           "Particle impoverishment may lead to errors.",
                           RuntimeWarning)
-            self.resample()
-            self.just_resampled = True
+            self._resample_reported()
         elif n_eff / self.n_particles < self.tuning_parameters["resample_threshold"]:
-            self.resample()
-            self.just_resampled = True
+            self._resample_reported()
         else:
             self.just_resampled = False
+
+    def _resample_reported(self):
+        """The resample of resample_test(): the only one whose outcome is reported through ``just_resampled`` — and
+        therefore the only one a caller (OptBayesExpt.pdf_update) is certain to follow with its parameter
+        constraints (see OptBayesExptNoiseParameter._resample_mask_rows)."""
+        self._in_reported_resample = True
+        try:
+            self.resample()
+        finally:
+            self._in_reported_resample = False
+        self.just_resampled = True
 
     # --------------------------------------------------------------- resample
     def _cdf(self):
@@ -368,7 +361,7 @@ class ParticlePDF:
             return
         (state,), self._pending_total = self._pending_total, None
         try:
-            self._lib.call("obe_host_word_wait", _P(self._total_pinned.data_ptr()), self._stream())
+            self._lib.call("obe_host_word_wait", self._total_ptrs[0], self._stream())
             self._validate_total(float(self._total_pinned[0]))
         except ValueError:
             if state is not None:
@@ -409,16 +402,17 @@ class ParticlePDF:
             if not fresh:
                 # (watched like every other result word: a store issued earlier is not guaranteed to reach the host before
                 # one issued later, by the same kernel or the next — _check_pending_total waits for this one itself)
-                self._lib.call("obe_host_word_arm", _P(self._total_pinned.data_ptr()))
+                self._lib.call("obe_host_word_arm", self._total_ptrs[0])
             self._lib.call("obe_draw_indices", _ptr(w), self.n_particles, 1 if strict else 0, 1 if fresh else 0,
                            _ptr(self._cdf_dev), _lib.host_ptr(u), n_draws, _ptr(idx),
-                           None if fresh else _P(self._total_pinned.data_ptr()), _ptr(self._ws), self._ws_bytes,
+                           None if fresh else self._total_ptrs[0], _ptr(self._ws), self._ws_bytes,
                            self._stream())
             if not fresh:
                 self._cdf_key = key
                 self._pending_total = (state,)
                 if not defer_validation:
                     torch.cuda.current_stream(self._device).synchronize()
+                    _lib.audit.synchronized()
                     self._check_pending_total()
             self.last_draw_indices_device = idx
             return idx

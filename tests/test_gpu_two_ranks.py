@@ -198,33 +198,61 @@ def test_unseeded_sharded_objects_stay_one_experiment(hip):
     assert "generator state" in a[5] and "ranks [1]" in a[5] and a[5] == b[5]
 
 
-def test_bench_starts_its_own_ranks(hip):
-    """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's command):
-    two ranks share this box's one GPU over gloo (the numbers of such a run mean nothing), one JSON
-    line, exit code 0."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_starts_its_own_ranks(hip, world):
+    """`python bench.py --gpus N` with no launcher around it (the shape of the driver's command), N = 2 and N = 8
+    (the driver's largest run): the ranks share this box's one GPU over gloo (the numbers of such a run mean
+    nothing), one JSON line, exit code 0.  Eight fresh interpreters at once also exercise what eight real ranks do
+    to the shared files — the library / plugin build locks — and the launcher's bookkeeping of its children."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(OBE_BENCH_BACKEND="gloo", OBE_BENCH_ONE_DEVICE="1")
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "c2", "--steps", "4",
-                        "--warmup", "2"], env=env, capture_output=True, text=True, timeout=900)
+    steps = 4 if world == 2 else 3
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--config", "c2", "--steps",
+                        str(steps), "--warmup", "2"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["config"]["settings_per_rank"] == 2048
+    assert out["n_gpus"] == world and out["steps"] == steps and out["config"]["settings_per_rank"] == 4096 // world
     assert out["value"] > 0 and "roofline" in out
     # the block that makes an N > 1 line self-proving: the communicator's own rank count, the rank-id all-gather,
     # the measured arg-max combine and where each rank's time went
     c = out["rccl"]
-    assert c["backend"] == "gloo" and c["world_size_reported_by_backend"] == 2
-    assert c["all_gather_rank_ids"] == [0, 1] and c["all_gather_rank_ids_ok"] is True
+    assert c["backend"] == "gloo" and c["world_size_reported_by_backend"] == world
+    assert c["all_gather_rank_ids"] == list(range(world)) and c["all_gather_rank_ids_ok"] is True
     assert c["instrumented_cycles"] == 4       # (the timed steps of an N > 1 run carry no events)
     assert c["combines_in_instrumented_cycles"] >= 4 and c["sweep_launches_in_instrumented_cycles"] >= 4
     for key in ("cycle_ms", "k1_ms_per_sweep", "non_k1_ms_per_cycle", "combine_us_in_cycle_median", "combine_us_idle_median"):
-        assert len(c[key]["per_rank"]) == 2 and 0.0 < c[key]["min"] <= c[key]["max"], (key, c[key])
+        assert len(c[key]["per_rank"]) == world and 0.0 < c[key]["min"] <= c[key]["max"], (key, c[key])
+    # every rank reports what it did about its CPU affinity before it imported torch (pinned to the cores of the
+    # GPU's NUMA node where sysfs names them; a reason where not) ...
+    masks = c["cpu_affinity_per_rank"]
+    assert len(masks) == world and all(isinstance(m, dict) and "pinned" in m for m in masks), masks
+    assert all(m["pinned"] and m["n_cpus"] >= 1 or m.get("why") for m in masks), masks
+    print(f"bench.py --gpus {world}: cpu affinity per rank: {masks[0]} ...")
+    # ... and the line carries the one-rank projection block next to the measured value (c2 has no entry: it says so)
+    assert "projection" in out and ("available" in out["projection"])
+
+
+def test_bench_launcher_ends_the_job_when_a_rank_dies(hip):
+    """A rank that dies leaves its peers waiting in a collective for ever: the launcher notices the exit code,
+    gives the others ten seconds, ends exactly the processes it started and returns non-zero (no stray ranks)."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(OBE_BENCH_BACKEND="gloo", OBE_BENCH_ONE_DEVICE="1", OBE_BENCH_DIE_RANK="1")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--config", "c2", "--steps", "3",
+                        "--warmup", "2"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "ranks failed" in r.stderr, (r.returncode, r.stderr[-1500:])
+    assert time.time() - t0 < 240.0
+    assert not [l for l in r.stdout.splitlines() if l.strip().startswith("{")]      # no line from a broken job
 
 
 def test_bench_line_of_a_one_rank_rccl_world_carries_the_rccl_block(hip):

@@ -563,28 +563,33 @@ def test_sweepstate_form_policy():
 
 def test_released_landing_zones_wait_in_limbo(monkeypatch):
     """Page-locked landing zones that an object releases are not handed back to the allocator while a kernel of
-    that object may still write to them (_lib.pinned_array / pinned_tensor): the storage moves to a limbo list
-    when its array is collected, and the list is emptied only when it has grown to its limit (behind a device
-    synchronisation on a GPU box; here the page-locking itself is replaced by a no-op)."""
+    that object may still write to them (_lib.pinned_array): the storage moves to a limbo list — with the device
+    whose kernels write it — when its array is collected, and the list is emptied only when it has grown to its
+    limit, behind a synchronisation of exactly the devices named in it (a rank of an 8-GPU job must not
+    create a context on the seven GPUs it does not use).  Here the page-locking itself is replaced by a no-op."""
     import gc
     import torch
     from optbayesexpt_amd import _lib
     monkeypatch.setattr(torch.Tensor, "pin_memory", lambda self, *a, **k: self)
     monkeypatch.setattr(_lib, "_LIMBO", [])
-    a = _lib.pinned_array(4)
+    synced = []
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda d=None: synced.append(d))
+    a = _lib.pinned_array(4, device=3)
     view = a[1:3]
-    t = _lib.pinned_tensor(3, torch.int64)
-    assert a.shape == (4,) and a.dtype == np.float64 and not a.any() and t.dtype == torch.int64
+    b = _lib.pinned_array(3, np.int64, device=3)
+    assert a.shape == (4,) and a.dtype == np.float64 and not a.any() and b.dtype == np.int64
     del a
     gc.collect()
     assert _lib._LIMBO == []                   # a view keeps the array, and with it the storage, with its owner
-    del view, t
+    del view, b
     gc.collect()
     assert len(_lib._LIMBO) == 2               # both storages are parked, not freed
+    assert [d for _, d in _lib._LIMBO] == [3, 3]
     monkeypatch.setattr(_lib, "_LIMBO_MAX", 5)
     for _ in range(3):                         # ... until the list reaches its limit: the next allocation empties it
-        _lib.pinned_array(1)                   # (dropped at once: parked)
+        _lib.pinned_array(1, device=5)         # (dropped at once: parked)
     gc.collect()
-    assert len(_lib._LIMBO) == 5
-    keep = _lib.pinned_array(2)
+    assert len(_lib._LIMBO) == 5 and synced == []
+    keep = _lib.pinned_array(2, device=5)
     assert len(_lib._LIMBO) == 0 and keep.shape == (2,)
+    assert synced == [3, 5]                    # the devices of the parked blocks, each once — and no other

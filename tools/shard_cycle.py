@@ -113,6 +113,20 @@ def main():
               f"({full['ms'] / t / world:.0%} of linear)")
     print("  (the 32-byte all-gather through a real RCCL communicator of one rank: tools/profile_collective.py; "
           "8 ranks over xGMI add the ring latency — 30-60 us brackets it)")
+    # machine-readable, merged into the file `bench.py --gpus N` quotes next to its measured value
+    # (OBE_PROJECTION_OUT=path; default: print only)
+    entry = dict(config=cfg, world=world, steps=steps, warmup=warmup, resamples=int(full["resamples"]),
+                 one_gpu_ms_per_cycle=full["ms"], one_gpu_k1_ms=full["k1"], rank_ms_per_cycle=bare["ms"],
+                 rank_k1_ms=rank["k1"], rank_plain_ms=bare["plain"], rank_resample_ms=bare["resample"],
+                 settings_per_rank=int(rank["n_local"]))
+    import json
+    print("PROJECTION " + json.dumps(entry))
+    out = os.environ.get("OBE_PROJECTION_OUT")
+    if out:
+        table = json.load(open(out)) if os.path.exists(out) else {}
+        table.setdefault(cfg, {})[str(world)] = entry
+        with open(out, "w") as f:
+            json.dump(table, f, indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
