@@ -168,6 +168,17 @@ OBE_API int obe_bayes_update_model_moments(const obe_model* m,
  * setting; on = -1 changes nothing and returns what the thread's last fused update did (1: one launch, 2: two). */
 OBE_API int obe_update_one_pass(int32_t on);
 
+/* strict sums (per calling thread; returns the previous setting, on < 0 only asks): while on, the UNFUSED updates —
+ * obe_bayes_update_model, obe_bayes_update_y, obe_bayes_update_lik — form sum t and sum nan_to_num(w'^2) in the order
+ * in which np.sum adds a contiguous float64 vector (pairwise_sum: pieces of 8192, runs of <= 128 in eight interleaved
+ * running sums, halves split at multiples of 8; restated in oracle/obe_oracle.py: numpy_pairwise_sum and pinned there
+ * against np.sum for every length to 5000), by one workgroup: the normalised weights t / np.sum(t) and N_eff are then
+ * the reference's BITS (particlepdf.py:136-139, 243-244; its own tests compare them with assert_array_equal,
+ * tests/test_optbayesexpt.py:58-69) wherever t itself is.  Meant for small clouds (the host side switches it on up to
+ * 4096 particles: tuning_parameters['strict_sums']); any size works, one workgroup's speed.  The fused forms
+ * (obe_bayes_update_model_moments*) ignore it. */
+OBE_API int obe_strict_sums(int32_t on);
+
 /* The same update, enqueued only: returns without waiting.  h_pinned_out (page-locked, 5 + 4 n_params
  * doubles) is armed here and written by the update's last kernel: [0] sum t, [1] sum w'^2, [2..) the K3
  * first-moment block, and [4 + 4 n_params] = 1.0 if auto_resample != 0 and the resample test of

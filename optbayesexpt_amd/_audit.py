@@ -233,6 +233,12 @@ def _rule_resample_begin(a, args):
     a._mark(_addr(args[19]), 2, True)
 
 
+def _rule_draw_indices(a, args):
+    if not _int(args[3]) and _addr(args[8]) is not None:
+        a._mark(_addr(args[8]), 1, True)                 # sum(p): delivered by the call's kernels, never waited for by it
+    a._mark(_addr(args[7]), _int(args[6]), True)         # the indices, when d_idx is the device view of a landing zone
+
+
 def _rule_mask_moments(h_mom, h_changed, n_dims):
     def rule(a, args):
         d = _int(args[n_dims])
@@ -255,6 +261,7 @@ _RULES = {
     "obe_bayes_update_model_moments_enqueue": _rule_update_enqueue,
     "obe_sweep_utility": _rule_sweep,
     "obe_resample_begin": _rule_resample_begin,
+    "obe_draw_indices": _rule_draw_indices,
     "obe_mask_nonpositive_moments": _rule_mask_moments(8, 9, 2),
     "obe_mask_renorm_moments": _rule_mask_moments(7, 8, 2),
     # synchronous forms: they wait for their own words before they return
@@ -269,3 +276,13 @@ _RULES = {
 
 
 audit = _Audit() if os.environ.get("OBE_CHECK_DELIVERY") == "1" else _NoAudit()
+
+if audit.on and os.environ.get("OBE_AUDIT_REPORT"):
+    import atexit
+    import json
+
+    def _report(path=os.environ["OBE_AUDIT_REPORT"]):
+        # (appended: a test run starts several processes — ranks, tools — that all audit)
+        with open(path, "a") as f:
+            f.write(json.dumps(dict(audit.counts, pid=os.getpid(), pending_violations=audit.violations)) + "\n")
+    atexit.register(_report)

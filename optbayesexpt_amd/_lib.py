@@ -71,6 +71,7 @@ _SIGNATURES = {
     "obe_last_error": (ctypes.c_char_p, []),
     "obe_defer_host_sync": (c_int, [c_int32]),
     "obe_update_one_pass": (c_int, [c_int32]),
+    "obe_strict_sums": (c_int, [c_int32]),
     "obe_source_fingerprint": (ctypes.c_char_p, []),
     "obe_model_validate": (c_int, [ctypes.POINTER(ObeModelStruct)]),
     "obe_device_info": (c_int, [ctypes.c_char_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int64)]),
@@ -154,6 +155,7 @@ _SIGNATURES = {
 MODEL_ENTRY_POINTS = ("obe_model_validate", "obe_workspace_bytes", "obe_sweep_settings_per_lane",
                       "obe_sweep_settings_per_lane_for", "obe_bayes_update_model",
                       "obe_bayes_update_model_moments", "obe_bayes_update_model_moments_enqueue", "obe_update_one_pass",
+                      "obe_strict_sums",
                       "obe_bayes_update_sweep",
                       "obe_eval_over_particles",
                       "obe_eval_over_settings", "obe_sweep_utility", "obe_sweep_kernel_time", "obe_sweep_timing",

@@ -764,7 +764,147 @@ static int try_onepass(const obe_model& mm, const SettingArg& sa, const LikArgs&
 
 #endif  // OBE_ONE_PASS_UPDATE
 
+// ---- strict sums (obe_strict_sums; tuning_parameters['strict_sums']): np.sum's ORDER of additions ----------------
+// particlepdf.py:138 divides by np.sum(tmp) and :243 tests 1 / np.sum(wsquared).  NumPy adds a contiguous float64
+// vector in a fixed order (numpy/_core/src/umath/loops_utils.h.src, pairwise_sum; restated and pinned against
+// np.sum itself in oracle/obe_oracle.py: numpy_pairwise_sum): the vector in pieces of 8192 elements, res = 0.0,
+// res += pairwise(piece); pairwise(n < 8) = the elements one after the other from 0.0; pairwise(n <= 128) = eight
+// interleaved running sums combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and the last n % 8 elements added one by
+// one; longer runs split at n/2 rounded down to a multiple of 8 and the halves are added.  One workgroup does
+// exactly that: a (sub)tree of at most 4104 elements is staged in LDS, its leaves (runs of <= 128) are summed by one
+// thread each, thread 0 adds them up the tree.  The reference's own tests compare updated weights with
+// assert_array_equal (tests/test_optbayesexpt.py:58-69) — with these sums the device holds that, bit for bit.
+constexpr int kNpPiece = 8192, kNpLeaf = 128, kNpStage = 4104;
+
+template <bool SQUARE>
+__device__ __forceinline__ double np_element(double x) { return SQUARE ? nan_to_num(x * x) : x; }
+
+// pairwise_sum of a run of <= 128 staged elements
+__device__ __forceinline__ double np_leaf_sum(const double* a, int n) {
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res = res + a[i];
+        return res;
+    }
+    double r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = r[j] + a[i + j];
+    }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res = res + a[i];
+    return res;
+}
+
+struct NpRun {
+    int lo, n;
+};
+
+// the leaves of pairwise_sum's recursion over n elements, left to right: f(leaf index, first element, length)
+template <class F>
+__device__ __forceinline__ int np_for_each_leaf(int n, F f) {
+    NpRun stack[20];
+    int sp = 0, idx = 0;
+    stack[sp++] = NpRun{0, n};
+    while (sp > 0) {
+        const NpRun nd = stack[--sp];
+        if (nd.n <= kNpLeaf) {
+            f(idx++, nd.lo, nd.n);
+            continue;
+        }
+        int n2 = nd.n / 2;
+        n2 -= n2 % 8;
+        stack[sp++] = NpRun{nd.lo + n2, nd.n - n2};      // (popped second: the right half)
+        stack[sp++] = NpRun{nd.lo, n2};
+    }
+    return idx;
+}
+
+// the leaf sums added up the recursion tree, left + right at every node (thread 0; leaves in left-to-right order)
+__device__ __forceinline__ double np_combine(const double* leaf, int n) {
+    // post-order without recursion: a node is expanded once (its halves pushed), then found again with its halves'
+    // sums on the value stack
+    NpRun stack[20];
+    bool expanded[20];
+    double vals[20];
+    int sp = 0, vp = 0, idx = 0;
+    stack[sp] = NpRun{0, n};
+    expanded[sp++] = false;
+    while (sp > 0) {
+        const NpRun nd = stack[sp - 1];
+        if (nd.n <= kNpLeaf) {
+            vals[vp++] = leaf[idx++];
+            --sp;
+        } else if (!expanded[sp - 1]) {
+            expanded[sp - 1] = true;
+            int n2 = nd.n / 2;
+            n2 -= n2 % 8;
+            stack[sp] = NpRun{nd.lo + n2, nd.n - n2};
+            expanded[sp++] = false;
+            stack[sp] = NpRun{nd.lo, n2};
+            expanded[sp++] = false;
+        } else {
+            const double right = vals[--vp], left = vals[--vp];
+            vals[vp++] = left + right;
+            --sp;
+        }
+    }
+    return vals[0];
+}
+
+// pairwise_sum of a run of <= kNpStage elements of a[] (global), element transform applied while staging; valid in thread 0
+template <bool SQUARE>
+__device__ __forceinline__ double np_staged_sum(const double* __restrict__ a, int n, double* stage, double* leaf) {
+    __syncthreads();                                     // (the previous run's stage and leaves have been consumed)
+    for (int i = threadIdx.x; i < n; i += blockDim.x) stage[i] = np_element<SQUARE>(a[i]);
+    __syncthreads();
+    np_for_each_leaf(n, [&](int idx, int lo, int len) {
+        if (idx % (int)blockDim.x == (int)threadIdx.x) leaf[idx] = np_leaf_sum(stage + lo, len);
+    });
+    __syncthreads();
+    return threadIdx.x == 0 ? np_combine(leaf, n) : 0.0;
+}
+
+template <bool SQUARE>
+__global__ __launch_bounds__(kBlock) void numpy_order_sum_kernel(const double* __restrict__ a, int64_t n,
+                                                                 double* __restrict__ out) {
+    __shared__ double stage[kNpStage];
+    __shared__ double leaf[kNpStage / 64 + 8];           // (a leaf holds at least 64 elements unless it is the whole run)
+    double res = 0.0;
+    for (int64_t lo = 0; lo < n; lo += kNpPiece) {
+        const int m = (int)(n - lo < kNpPiece ? n - lo : kNpPiece);
+        double piece;
+        if (m <= kNpStage) {
+            piece = np_staged_sum<SQUARE>(a + lo, m, stage, leaf);
+        } else {                                         // the first split of pairwise_sum, its halves staged in turn
+            int n2 = m / 2;
+            n2 -= n2 % 8;
+            const double left = np_staged_sum<SQUARE>(a + lo, n2, stage, leaf);
+            const double right = np_staged_sum<SQUARE>(a + lo + n2, m - n2, stage, leaf);
+            piece = left + right;
+        }
+        res = res + piece;
+    }
+    if (threadIdx.x == 0) out[0] = res;
+}
+
+// whether the calling thread's unfused updates sum in np.sum's order (obe_strict_sums)
+static thread_local int g_strict_sums = 0;
+
 static int finish_update(const UpdateWs& w, int nb, int64_t n, double* d_weights, double* h_out, hipStream_t st) {
+    if (g_strict_sums) {
+        // sum t in np.sum's order -> pa[0]; the normalisation divides by exactly that; sum nan_to_num(w'^2) likewise
+        numpy_order_sum_kernel<false><<<1, kBlock, 0, st>>>(d_weights, n, w.pa);
+        OBE_CHECK_LAUNCH("numpy_order_sum_kernel");
+        normalize_kernel<<<nb, kBlock, 0, st>>>(w.pa, 1, n, d_weights, w.pb, nullptr);
+        OBE_CHECK_LAUNCH("normalize_kernel");
+        numpy_order_sum_kernel<true><<<1, kBlock, 0, st>>>(d_weights, n, w.pb);
+        OBE_CHECK_LAUNCH("numpy_order_sum_kernel");
+        return fold2_to_host(w.pa, w.pb, 1, w.scalars, h_out, st);
+    }
     normalize_kernel<<<nb, kBlock, 0, st>>>(w.pa, nb, n, d_weights, w.pb, nullptr);
     OBE_CHECK_LAUNCH("normalize_kernel");
     return fold2_to_host(w.pa, w.pb, nb, w.scalars, h_out, st);
@@ -907,6 +1047,12 @@ delivered:
         OBE_HIP_TRY(hipStreamSynchronize(st));
     }
     return 0;
+}
+
+int obe_strict_sums(int32_t on) {
+    const int prev = g_strict_sums;
+    if (on >= 0) g_strict_sums = on != 0;
+    return prev;
 }
 
 int obe_update_one_pass(int32_t on) {

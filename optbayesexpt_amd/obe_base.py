@@ -451,7 +451,8 @@ class OptBayesExpt(ParticlePDF):
                     self.n_particles, _ptr(w), hp(self._setting_array(onesetting)),
                     hp(yy), None if s is None else hp(s),
                     None if rows is None else hp(rows), n, self._choke_value())
-            if self._parameters is self._particles and self.tuning_parameters.get("fused_moments", True):
+            if self._parameters is self._particles and self.tuning_parameters.get("fused_moments", True) \
+                    and not self._strict_sums():
                 # ... and the first moments of the posterior in the same pass over the cloud: the next
                 # sweep's shift, mean(), std() and the noise-parameter variance need no launch of their own
                 self._drop_speculative_sweep()
@@ -465,9 +466,11 @@ class OptBayesExpt(ParticlePDF):
                     self._mlib.call("obe_bayes_update_model_moments", *args, _ptr(self._moments_dev), _ptr(self._ws),
                                     self._ws_bytes, self._hargs.ptr_keep(self._upd_host), self._stream())
                     self._after_weight_update(self._upd_host[1], moments_fresh=True)
-            else:       # (a stale `parameters` alias after set_pdf, obe_base.py:185,395: not the cloud the moments describe)
-                self._mlib.call("obe_bayes_update_model", *args, _ptr(self._ws), self._ws_bytes,
-                                hp(self._host_out), self._stream())
+            else:
+                # (a stale `parameters` alias after set_pdf, obe_base.py:185,395: not the cloud the moments describe;
+                # or a small cloud whose sums are formed in np.sum's order: tuning_parameters['strict_sums'])
+                self._unfused_update(self._mlib, "obe_bayes_update_model", *args, _ptr(self._ws), self._ws_bytes,
+                                     hp(self._host_out), self._stream())
                 self._after_weight_update(self._host_out[1])
         else:
             if y_model_data is None:
@@ -480,11 +483,11 @@ class OptBayesExpt(ParticlePDF):
                 n, yy, s, rows = self._likelihood_inputs(measurement_record)
                 par = self._parameters.tensor()
                 w = self._weights.tensor()
-                self._lib.call("obe_bayes_update_y", _ptr(y_dev), y_dev.shape[1], self.n_channels,
-                               _ptr(par), par.shape[1], self.n_particles, _ptr(w), _lib.host_ptr(yy),
-                               None if s is None else _lib.host_ptr(s),
-                               None if rows is None else _lib.host_ptr(rows), n, self._choke_value(),
-                               _ptr(self._ws), self._ws_bytes, _lib.host_ptr(self._host_out), self._stream())
+                self._unfused_update(self._lib, "obe_bayes_update_y", _ptr(y_dev), y_dev.shape[1], self.n_channels,
+                                     _ptr(par), par.shape[1], self.n_particles, _ptr(w), _lib.host_ptr(yy),
+                                     None if s is None else _lib.host_ptr(s),
+                                     None if rows is None else _lib.host_ptr(rows), n, self._choke_value(),
+                                     _ptr(self._ws), self._ws_bytes, _lib.host_ptr(self._host_out), self._stream())
                 self._after_weight_update(self._host_out[1])
         self._parameters = self._particles
         if self.just_resampled:

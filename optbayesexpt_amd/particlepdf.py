@@ -36,6 +36,10 @@ class ParticlePDF:
     Extension, ``tuning_parameters['strict_cdf']`` (default ``False``): build the
     resampling CDF in np.cumsum's serial rounding order (bit-identical CDF, ~ms at 1e6
     particles) instead of the parallel blocked scan.
+    Extension, ``tuning_parameters['strict_sums']`` (``'auto'`` — on up to 4096 particles —, ``True``, ``False``):
+    the update's sum(t) and the sum(w^2) of the resample test are formed in the order np.sum adds (particlepdf.py:138,
+    243; csrc/obe_update.hip: numpy_order_sum_kernel), so that the normalised weights are the reference's bits —
+    its own unit tests compare them with assert_array_equal.  One workgroup: for small clouds.
     Extension, ``tuning_parameters['resample_method']`` (default ``'multinomial'``, the
     reference's ``rng.choice``): ``'systematic'`` draws the N new particles at the stratified
     CDF points (i + u0)/N from ONE uniform of ``self.rng`` (lower resampling variance; the
@@ -87,9 +91,27 @@ class ParticlePDF:
             self._weights = Mirror(self._device, host=np.ones(self.n_particles))
             lik = torch.from_numpy(np.array(weights, dtype=np.float64)).to(self._device)
             w = self._weights.tensor()
-            self._lib.call("obe_bayes_update_lik", _ptr(lik), self.n_particles, _ptr(w), _ptr(self._ws),
-                           self._ws_bytes, _lib.host_ptr(self._host_out), self._stream())
+            self._unfused_update(self._lib, "obe_bayes_update_lik", _ptr(lik), self.n_particles, _ptr(w), _ptr(self._ws),
+                                 self._ws_bytes, _lib.host_ptr(self._host_out), self._stream())
             self._weights.mark_device_written()
+
+    #: clouds up to this size sum the update in np.sum's order unless tuning_parameters['strict_sums'] says otherwise
+    STRICT_SUMS_MAX = 4096
+
+    def _strict_sums(self):
+        mode = self.tuning_parameters.get("strict_sums", "auto")
+        return self.n_particles <= self.STRICT_SUMS_MAX if mode == "auto" else bool(mode)
+
+    def _unfused_update(self, lib, name, *args):
+        """One of the unfused update calls (obe_bayes_update_model / _y / _lik), in np.sum's order of additions
+        when this object asks for it (the library's switch is per thread: set for this call, cleared behind it)."""
+        if not self._strict_sums():
+            return lib.call(name, *args)
+        lib.cdll.obe_strict_sums(1)
+        try:
+            return lib.call(name, *args)
+        finally:
+            lib.cdll.obe_strict_sums(0)
 
     def _scratch_dims(self):
         """(n_settings, n_channels) the workspace must cover; OptBayesExpt overrides."""
@@ -261,8 +283,8 @@ class ParticlePDF:
             lik = torch.from_numpy(np.array(
                 np.broadcast_to(np.asarray(likelihood, dtype=np.float64), (self.n_particles,)))).to(self._device)
         w = self._weights.tensor()
-        self._lib.call("obe_bayes_update_lik", _ptr(lik), self.n_particles, _ptr(w), _ptr(self._ws),
-                       self._ws_bytes, _lib.host_ptr(self._host_out), self._stream())
+        self._unfused_update(self._lib, "obe_bayes_update_lik", _ptr(lik), self.n_particles, _ptr(w), _ptr(self._ws),
+                             self._ws_bytes, _lib.host_ptr(self._host_out), self._stream())
         self._after_weight_update(self._host_out[1])
 
     def _after_weight_update(self, sum_w2, moments_fresh=False):

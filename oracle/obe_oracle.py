@@ -17,7 +17,7 @@ import warnings
 import numpy as np
 
 __all__ = [
-    "normalized_product", "effective_particles", "weighted_mean",
+    "normalized_product", "numpy_pairwise_sum", "effective_particles", "weighted_mean",
     "weighted_covariance", "weighted_std", "weight_cdf", "choice_indices",
     "systematic_indices", "nudge_factor", "gauss_likelihood", "yvar_from_draws", "yvar_full_sweep",
     "utility_from_yvar", "mean_noise_variance", "flatten_settings",
@@ -38,6 +38,51 @@ def normalized_product(weights, likelihood):
     prod = np.nan_to_num(weights * likelihood)
     with np.errstate(invalid="ignore", divide="ignore"):
         return np.nan_to_num(prod / np.sum(prod))
+
+
+NUMPY_REDUCE_PIECE = 8192     # elements per inner-loop call of a ufunc reduction (np.getbufsize() default)
+
+
+def numpy_pairwise_sum(a):
+    """np.sum / np.add.reduce of a contiguous float64 vector, operation by operation — the ORDER in which NumPy
+    adds (numpy/_core/src/umath/loops_utils.h.src: pairwise_sum; reached from particlepdf.py:138 ``np.sum(tmp)`` and
+    :243 ``np.sum(wsquared)``): fewer than 8 elements one after the other from 0.0; up to 128 in eight interleaved
+    running sums r[j] += a[i + j], combined ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7)), the last n % 8 elements added one
+    by one; longer vectors split at n/2 rounded down to a multiple of 8, the halves summed recursively and added.
+    The reduction starts from the identity 0.0 and walks the vector in pieces of the ufunc buffer size (8192
+    elements, np.getbufsize()'s default): res = 0.0; res += pairwise(piece) for every piece — found by pinning this
+    restatement against np.sum, not from the source.  Pure-Python loops: what the device's
+    ``strict_sums`` mode (csrc/obe_update.hip: numpy_order_sum) is held to BIT FOR BIT; pinned against np.sum itself
+    for every length 0..5000 in tests/test_oracle_golden.py."""
+    a = np.ascontiguousarray(a, dtype=np.float64).reshape(-1)
+
+    def pw(lo, n):
+        if n < 8:
+            res = 0.0
+            for i in range(lo, lo + n):
+                res = res + a[i]
+            return res
+        if n <= 128:
+            r = [a[lo + j] for j in range(8)]
+            i = 8
+            while i < n - (n % 8):
+                for j in range(8):
+                    r[j] = r[j] + a[lo + i + j]
+                i += 8
+            res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))
+            while i < n:
+                res = res + a[lo + i]
+                i += 1
+            return res
+        n2 = n // 2
+        n2 -= n2 % 8
+        return pw(lo, n2) + pw(lo + n2, n - n2)
+
+    with np.errstate(all="ignore"):
+        res = np.float64(0.0)
+        for lo in range(0, a.size, NUMPY_REDUCE_PIECE):
+            res = res + pw(lo, min(NUMPY_REDUCE_PIECE, a.size - lo))
+        return res
 
 
 def effective_particles(weights):

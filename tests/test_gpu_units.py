@@ -388,7 +388,9 @@ def test_reference_optbayesexpt_literals(obe):
     assert_allclose(o.likelihood(ymodel, ((1,), (5.0,), 1.0)), np.exp(-(ymodel - 5.0) ** 2 / 2)[0], rtol=1e-15)
     lkl = np.exp(-(np.array((1, 4, 4, 7)) - 5.0) ** 2 / 2)
     parts, wts = o.pdf_update(((1,), 5.0, 1.0))
-    assert_allclose(o.particle_weights, lkl / np.sum(lkl), rtol=1e-15)
+    # the reference's own assertion, verbatim (tests/test_optbayesexpt.py:66-69): assert_array_equal — the update's
+    # sum is formed in np.sum's order on a cloud this small (tuning_parameters['strict_sums'])
+    assert_array_equal(lkl / np.sum(lkl), o.particle_weights, err_msg="incorrect updated weights")
     assert_array_equal(parts, o.particles)
     with pytest.raises(SyntaxError):
         obe.OptBayesExpt(obe.models.line_ab(), (np.array([0, 1, 2]),), pars, (), utility_method="nope")
@@ -397,6 +399,59 @@ def test_reference_optbayesexpt_literals(obe):
     with pytest.raises(RuntimeError):
         obe.OptBayesExptNoiseParameter(obe.models.line_ab(), (np.array([0, 1, 2]),), pars, (),
                                        noise_parameter_index=(0, 1))
+
+
+def test_strict_sums_are_np_sum_bit_for_bit(obe, hip):
+    """tuning_parameters['strict_sums'] / obe_strict_sums: the update's sum t and the resample test's sum
+    nan_to_num(w'^2) in the ORDER np.sum adds (oracle.numpy_pairwise_sum, pinned against np.sum on the CPU) — through
+    the C ABI for lengths on every branch of that order (< 8, <= 128, the 8-aligned splits, the 8192-element pieces)
+    and through the classes: weights == nan_to_num(t / np.sum(t)) and N_eff == 1 / np.sum(w^2) as BITS
+    (particlepdf.py:136-139, 243-244)."""
+    import torch
+    from optbayesexpt_amd import _lib
+    from optbayesexpt_amd.particlepdf import _ptr
+    g = np.random.default_rng(77)
+    out = _lib.pinned_array(4)
+    lengths = [1, 2, 7, 8, 9, 15, 16, 17, 127, 128, 129, 136, 143, 255, 256, 257, 1000, 2047, 4095, 4096, 4097, 4103,
+               4104, 4105, 5000, 8191, 8192, 8193, 16391, 70001] + [int(v) for v in g.integers(1, 9000, 40)]
+    assert hip.cdll.obe_strict_sums(1) == 0
+    try:
+        for n in lengths:
+            w = g.exponential(1.0, n) * 10.0 ** g.integers(-6, 6, n)
+            w /= w.sum()
+            lik = np.exp(-g.exponential(3.0, n) ** 2)
+            if n > 20:
+                lik[g.integers(0, n, 3)] = [np.nan, 0.0, np.inf][:3]          # nan_to_num on the way
+            wd, ld = torch.from_numpy(w.copy()).cuda(), torch.from_numpy(lik).cuda()
+            ws = torch.empty(hip.workspace_bytes(n, 1, 1, 1) // 8 + 1, dtype=torch.float64, device="cuda")
+            hip.call("obe_bayes_update_lik", _ptr(ld), n, _ptr(wd), _ptr(ws), ws.numel() * 8, _lib.host_ptr(out), None)
+            with np.errstate(all="ignore"):
+                t = np.nan_to_num(w * lik)
+                want = np.nan_to_num(t / np.sum(t))
+                want_w2 = np.sum(np.nan_to_num(want * want))
+            assert np.float64(out[0]).tobytes() == np.float64(np.sum(t)).tobytes(), (n, out[0], np.sum(t))
+            assert_array_equal(wd.cpu().numpy(), want, err_msg=f"n = {n}")
+            assert np.float64(out[1]).tobytes() == np.float64(want_w2).tobytes(), (n, out[1], want_w2)
+            assert np.float64(np.sum(t)).tobytes() == oracle.numpy_pairwise_sum(t).tobytes()
+    finally:
+        assert hip.cdll.obe_strict_sums(0) == 1
+    # through the classes: 'auto' is on up to 4096 particles, off above; forced either way
+    for n, mode, strict in ((3000, "auto", True), (5000, "auto", False), (5000, True, True), (3000, False, False)):
+        x = g.normal(size=(2, n))
+        pdf = obe.ParticlePDF(x, auto_resample=False)
+        pdf.tuning_parameters["strict_sums"] = mode
+        assert pdf._strict_sums() is strict
+        lik = np.exp(-0.5 * (x[0] - 0.3) ** 2 / 0.01)
+        pdf.bayesian_update(lik)
+        t = np.nan_to_num(np.ones(n) / n * lik)
+        same = np.array_equal(pdf.particle_weights, np.nan_to_num(t / np.sum(t)))
+        assert same or not strict, (n, mode)
+        assert_allclose(pdf.particle_weights, t / np.sum(t), rtol=1e-14)
+        pdf.resample_test()
+        if strict:
+            wv = np.array(pdf.particle_weights)
+            assert pdf.last_n_eff == 1 / np.sum(np.nan_to_num(wv * wv))
+    assert hip.cdll.obe_strict_sums(-1) == 0               # (every class call leaves the thread's switch off)
 
 
 # --------------------------------------------------- K1 full sweep (D1-ii) parity

@@ -274,3 +274,21 @@ def test_c_restatement_agrees_with_numpy_oracle_and_reference():
     assert_allclose(got, want, rtol=1e-12)
     assert_allclose(s2, np.sum(want * want), rtol=1e-12)
     assert csweep.threads() >= 1
+
+
+def test_numpy_pairwise_sum_restatement_is_np_sum_bit_for_bit():
+    """oracle.numpy_pairwise_sum (the order the device's strict_sums mode reproduces) against np.sum ITSELF — the
+    reference's particlepdf.py:138, 243 call exactly that —: every length 0..5000 plus a few long ones, values of
+    mixed magnitude and sign so that any other association shows in the last bits."""
+    g = np.random.default_rng(2024)
+    lengths = list(range(0, 1300)) + list(range(1300, 5001, 7)) + [8191, 8192, 8193, 16384, 16391, 65536 + 5, 70001]
+    diff = 0
+    for n in lengths:
+        a = g.normal(size=n) * 10.0 ** g.integers(-8, 8, size=n)
+        got, want = oracle.numpy_pairwise_sum(a), np.sum(a)
+        assert got.tobytes() == np.float64(want).tobytes(), (n, got, want)
+        diff += np.float64(np.sum(a[::-1])).tobytes() != np.float64(want).tobytes()
+    assert diff > len(lengths) // 2          # (the inputs do tell summation orders apart)
+    # the reference's own literal (tests/test_optbayesexpt.py:58-69): lkl / np.sum(lkl)
+    lkl = np.exp(-(np.array((1, 4, 4, 7)) - 5.0) ** 2 / 2)
+    assert oracle.numpy_pairwise_sum(0.25 * lkl).tobytes() == np.float64(np.sum(0.25 * lkl)).tobytes()
