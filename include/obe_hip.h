@@ -43,9 +43,18 @@ extern "C" {
  * limits raised.  A client compiled against another version must not call in: compare obe_abi_version(). */
 #define OBE_ABI_VERSION 2
 #define OBE_MAX_CONSTS 8
-#define OBE_MAX_CHANNELS 4
-#define OBE_MAX_SETDIMS 4
-#define OBE_MAX_DIMS 16
+#define OBE_MAX_CHANNELS 8   /* output channels of a device model / of one measurement record */
+#define OBE_MAX_SETDIMS 8    /* setting dimensions of a device model */
+#define OBE_MAX_DIMS 32      /* parameter rows a device model may be given (obe_model.n_params) */
+/* Up to OBE_FAST_DIMS parameter rows the cloud kernels (moments, the fused update, the pipelined resample) are
+ * compiled for the exact row count, all accumulators in registers.  The calls that work on the cloud alone —
+ * obe_moments, obe_resample_particles, obe_gather_columns, the masks, the unfused updates — take ANY number of rows
+ * (the reference has no limit: particlepdf.py:105): beyond OBE_FAST_DIMS they run tiled over 8 rows at a time (one
+ * pass over the cloud per tile, per tile pair for the covariance).  The fused / pipelined forms
+ * (obe_bayes_update_model_moments*, obe_resample_begin, obe_resample_particles_aos*, obe_mask_renorm_moments)
+ * refuse more than OBE_FAST_DIMS rows before anything is launched (-1); callers then use the plain forms. */
+#define OBE_FAST_DIMS 16
+#define OBE_CLOUD_MAX_DIMS 1024
 
 /* ---- device model registry (replaces the Python `model_function` callable,
  *      obe_base.py:50-72, for the model families the reference's demos use) ---- */
@@ -230,7 +239,10 @@ OBE_API int obe_bayes_update_y(const double* d_y, int64_t ld_y, int32_t n_channe
 OBE_API int obe_bayes_update_lik(const double* d_lik, int64_t n_particles, double* d_weights,
                          void* d_ws, int64_t ws_bytes, double* h_out, void* stream);
 
-/* OptBayesExpt.likelihood(y_model, record) as an array (obe_base.py:418-461). */
+/* OptBayesExpt.likelihood(y_model, record) as an array (obe_base.py:418-461).  ANY number of channels (the
+ * reference has no limit, obe_base.py:807-824): h_y_meas / h_sigma / h_noise_rows then hold n_lik_channels values
+ * and a record wider than OBE_MAX_CHANNELS is multiplied up in groups of that many, in channel order, the choke
+ * applied to the finished product. */
 OBE_API int obe_likelihood_y(const double* d_y, int64_t ld_y, int32_t n_channels,
                      const double* d_particles, int64_t ld_p, int64_t n_particles,
                      const double* h_y_meas, const double* h_sigma,
@@ -442,6 +454,7 @@ OBE_API int obe_power_normalize(const double* d_u, int64_t n, double exponent, d
  * enqueued behind an update, whose record a sharded caller all-gathers one host round trip later — is read
  * there.  The word behind it is OBE_WS_ABORT_WORD. */
 #define OBE_WS_RESULT_TAIL(d_ws, ws_bytes) ((double*)((char*)(d_ws) + ((ws_bytes) & ~(int64_t)7) - 48))
+/* (5 bits per channel, channel c's row at bit 5 c, up to OBE_MAX_CHANNELS channels; rows below 32) */
 #define OBE_NOISE_FROM_MOMENTS(r0, r1, r2, r3) \
     (-(int64_t)1 - ((int64_t)(r0) | ((int64_t)(r1) << 5) | ((int64_t)(r2) << 10) | ((int64_t)(r3) << 15)))
 /* bits of the `shifted` argument of obe_sweep_utility / obe_sweep_kernel_time.  A plugin

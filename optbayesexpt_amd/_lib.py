@@ -20,7 +20,7 @@ HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "obe_hip.h")
 def _header_constants(path=HEADER_PATH):
     """The #define'd integers of include/obe_hip.h (one source of truth for limits and the ABI version)."""
     text = open(path).read()
-    return {k: int(v) for k, v in re.findall(r"^#define\s+(OBE_[A-Z_]+)\s+(-?\d+)\s*$", text, flags=re.M)}
+    return {k: int(v) for k, v in re.findall(r"^#define\s+(OBE_[A-Z_]+)\s+(-?\d+)\s*(?:/\*.*)?$", text, flags=re.M)}
 
 
 _H = _header_constants()
@@ -29,6 +29,8 @@ OBE_MAX_CONSTS = _H["OBE_MAX_CONSTS"]
 OBE_MAX_CHANNELS = _H["OBE_MAX_CHANNELS"]
 OBE_MAX_SETDIMS = _H["OBE_MAX_SETDIMS"]
 OBE_MAX_DIMS = _H["OBE_MAX_DIMS"]
+OBE_FAST_DIMS = _H["OBE_FAST_DIMS"]                  # cloud kernels compiled for the exact row count up to here
+OBE_CLOUD_MAX_DIMS = _H["OBE_CLOUD_MAX_DIMS"]        # what the tiled cloud kernels take (ParticlePDF alone)
 OBE_WS_RESULT_OFFSET = 2      # doubles; include/obe_hip.h
 HOST_SENTINEL = 0x7ff8c0dec0dec0de     # the value of an armed host result word (csrc/obe_common.h: kHostSentinel)
 OBE_SWEEP_SHIFTED, OBE_SWEEP_SAFE, OBE_SWEEP_SPECULATIVE, OBE_SWEEP_NOWAIT = 1, 2, 8, 16      # bits of obe_sweep_utility's `shifted` argument

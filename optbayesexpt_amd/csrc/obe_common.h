@@ -17,6 +17,7 @@ namespace obe {
 constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kBlock = 256;        // 4 waves: one per SIMD of a CU
 constexpr int kMaxBlocks = 2048;   // 256 CUs x 8: grid cap for streaming kernels
+constexpr int kFastDims = OBE_FAST_DIMS;   // cloud kernels are templated on the row count up to here, tiled beyond
 constexpr double kDblMax = 1.7976931348623157e308;
 
 void set_error(const std::string& msg);

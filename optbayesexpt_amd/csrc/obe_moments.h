@@ -199,7 +199,7 @@ __device__ __forceinline__ void derive_covariance(const double* raw, int d, doub
     }
 }
 
-constexpr int kMaxMomentValues = OBE_MAX_DIMS * (OBE_MAX_DIMS + 1) / 2;     // >= 2 + 2 D
+constexpr int kMaxMomentValues = kFastDims * (kFastDims + 1) / 2;     // >= 2 + 2 D (the templated folds' LDS)
 
 // Thread i < d: mean, m1, m2, std of parameter i from the folded sums raw[] (2 + 2 d values), into the
 // K3 block `out` ([0]=W [1]=W2 [2..) mean [2+D..) m1 [2+2D..) m2 [2+3D..) std) and, if not NULL, `host`

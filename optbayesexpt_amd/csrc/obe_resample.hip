@@ -355,8 +355,8 @@ __global__ __launch_bounds__(kBlock) void gather_columns_kernel(const double* __
 }
 
 struct NudgeArgs {
-    double factor[OBE_MAX_DIMS * OBE_MAX_DIMS];   // F row-major (D x D)
-    double mean[OBE_MAX_DIMS];
+    double factor[kFastDims * kFastDims];   // F row-major (D x D)
+    double mean[kFastDims];
     double a, one_minus_a, uniform_w;
     int d, scale;
 };
@@ -463,6 +463,35 @@ __global__ __launch_bounds__(kBlock) void resample_kernel(NudgeArgs na, const do
             psum[blockIdx.x] = s;
             pcount[blockIdx.x] = c;
         }
+    }
+}
+
+// Wide clouds (D > OBE_FAST_DIMS; any D): the same gather + nudge with run-time loops — the D x D factor and the mean
+// in device memory (`fm`: F row-major, then the mean; every lane reads the same element: scalar loads), the gather
+// from the (D, N) array, the normals row from (N, D).  The same FMA chain per output as resample_kernel.
+__global__ __launch_bounds__(kBlock) void resample_wide_kernel(const double* __restrict__ fm, int d, double a,
+                                                               double one_minus_a, double uniform_w, int scale,
+                                                               const double* __restrict__ old, int64_t ld_old, int64_t n,
+                                                               const int64_t* __restrict__ idx,
+                                                               const double* __restrict__ z, double* __restrict__ out,
+                                                               int64_t ld_new, double* __restrict__ weights) {
+    const double* __restrict__ mean = fm + (int64_t)d * d;
+    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (int64_t)gridDim.x * kBlock) {
+        int64_t src = idx[p];
+        src = src < 0 ? 0 : (src >= n ? n - 1 : src);
+        const double* __restrict__ zr = z + p * d;
+        for (int i = 0; i < d; ++i) {
+            double nudge = 0.0;
+            for (int j = 0; j < d; ++j) nudge = fma(zr[j], fm[(int64_t)i * d + j], nudge);
+            double v = old[(int64_t)i * ld_old + src] + nudge;
+            if (scale) {
+                const double va = v * a;
+                const double mc = mean[i] * one_minus_a;
+                v = va + mc;
+            }
+            out[(int64_t)i * ld_new + p] = v;
+        }
+        weights[p] = uniform_w;
     }
 }
 
@@ -689,7 +718,8 @@ int obe_resample_particles_aos_masked(const double* d_old_aos, int32_t n_dims, i
                                       const double* h_mean, double a_param, int32_t scale, double* d_new,
                                       int64_t ld_new, double* d_weights, const int32_t* h_rows, int32_t n_rows,
                                       double* d_mask_partials, void* stream) {
-    if (!d_old_aos || d_old_aos == d_new || !h_rows || !d_mask_partials || n_rows < 1 || n_rows > OBE_MAX_DIMS)
+    if (!d_old_aos || d_old_aos == d_new || !h_rows || !d_mask_partials || n_rows < 1 || n_rows > kFastDims ||
+        n_dims > kFastDims)
         return bad_arg("obe_resample_particles_aos_masked: bad pointer/size");
     unsigned bits = 0u;
     for (int k = 0; k < n_rows; ++k) {
@@ -707,7 +737,22 @@ static int resample_particles(const double* d_old, int64_t ld_old, int32_t n_dim
                               double* d_mask_partials) {
     if (!d_idx || !d_normals || !h_factor || !h_mean || !d_new || !d_weights || n_particles <= 0)
         return bad_arg("obe_resample_particles: bad pointer/size");
-    if (n_dims < 1 || n_dims > OBE_MAX_DIMS) return bad_arg("obe_resample_particles: n_dims must be 1..16");
+    if (n_dims < 1 || n_dims > OBE_CLOUD_MAX_DIMS) return bad_arg("obe_resample_particles: n_dims must be 1..1024");
+    if (n_dims > kFastDims) {
+        // wide cloud: only the plain form (the (D, N) cloud, no mask); F and the mean travel through the workspace
+        if (!d_old || mask_bits) return bad_arg("obe_resample_particles_aos: more than OBE_FAST_DIMS parameters (use obe_resample_particles)");
+        const int64_t fm_doubles = (int64_t)n_dims * n_dims + n_dims;
+        if (!d_ws || ws_bytes < fm_doubles * (int64_t)sizeof(double)) return bad_arg("obe_resample_particles: workspace too small");
+        hipStream_t ws_st = as_stream(stream);
+        double* fm = static_cast<double*>(d_ws);
+        OBE_HIP_TRY(hipMemcpyAsync(fm, h_factor, sizeof(double) * n_dims * n_dims, hipMemcpyHostToDevice, ws_st));
+        OBE_HIP_TRY(hipMemcpyAsync(fm + (int64_t)n_dims * n_dims, h_mean, sizeof(double) * n_dims, hipMemcpyHostToDevice, ws_st));
+        resample_wide_kernel<<<stream_blocks(n_particles, kBlock), kBlock, 0, ws_st>>>(
+            fm, n_dims, a_param, 1 - a_param, 1.0 / (double)n_particles, scale, d_old, ld_old, n_particles, d_idx, d_normals,
+            d_new, ld_new, d_weights);
+        OBE_CHECK_LAUNCH("resample_wide_kernel");
+        return 0;
+    }
     NudgeArgs na{};
     na.d = n_dims;
     na.scale = scale;
@@ -752,7 +797,7 @@ int obe_resample_begin(const double* d_particles, int64_t ld_p, int32_t n_dims, 
     if (!d_particles || !d_weights || !h_pcg_state4 || !d_cdf || !d_uniforms || !d_idx || !d_zig_tables ||
         !d_normals || !d_zig_ws || !d_moments || !h_f64 || !h_i64 || n_particles <= 0)
         return bad_arg("obe_resample_begin: bad pointer/size");
-    if (n_dims < 1 || n_dims > OBE_MAX_DIMS) return bad_arg("obe_resample_begin: n_dims must be 1..16");
+    if (n_dims < 1 || n_dims > kFastDims) return bad_arg("obe_resample_begin: n_dims must be 1..16 (OBE_FAST_DIMS)");
     const int64_t n = n_particles, n_normal = n * n_dims;
     if (n_raw < n + n_normal + 4096) return bad_arg("obe_resample_begin: fewer raw values than the draws need");
     if (!device_view_of_host(h_f64) || !device_view_of_host(h_i64))

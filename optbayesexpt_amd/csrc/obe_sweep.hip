@@ -76,7 +76,7 @@ struct SweepPlan {
 // 4096 x 262 144 of the one-peak model but runs 1.1 ms: with 1536 items (two rounds of 0.55 ms workgroups) the
 // uneven tail costs 5 % — 1.145 / 1.146 ms against 1.093 / 1.083 ms with 4096 (same box, in cycles; 6144 and
 // 8192 no better); the one-peak 4096 x 262 144 is indifferent (0.252 vs 0.250-0.254 ms).
-static SweepPlan plan_sweep(int64_t ns, int64_t nd, int cost = 1) {
+static SweepPlan plan_sweep(int64_t ns, int64_t nd, int cost = 1, int max_spt = 8) {
     static const int force_spt = getenv("OBE_SWEEP_SPT") ? atoi(getenv("OBE_SWEEP_SPT")) : 0;         // tuning aids
     static const int force_blocks = getenv("OBE_SWEEP_BLOCKS") ? atoi(getenv("OBE_SWEEP_BLOCKS")) : 0;
     SweepPlan p;
@@ -84,6 +84,9 @@ static SweepPlan plan_sweep(int64_t ns, int64_t nd, int cost = 1) {
     // rank's 2048 x 524 288 slice of the 10-parameter config: 1.118 vs 1.133 ms, 1.126 vs 1.146 ms, same box)
     p.spt = ns >= 4096 || (ns >= 2048 && nd >= 131072) ? 8 : (ns >= 1024 ? 4 : (ns >= 512 ? 2 : 1));
     if (force_spt == 1 || force_spt == 2 || force_spt == 4 || force_spt == 8) p.spt = force_spt;
+    // (a lane keeps 4 running values per setting and channel in registers: models with more than 4 channels get at
+    // most 2 settings per lane)
+    if (p.spt > max_spt) p.spt = max_spt;
     p.tiles_x = static_cast<int>((ns + (int64_t)kWave * p.spt - 1) / ((int64_t)kWave * p.spt));
     const int64_t by_work = static_cast<int64_t>((double)ns * (double)nd * (double)cost / 1.25e6);
     const int64_t target_blocks = force_blocks > 0 ? force_blocks : std::max<int64_t>(1536, std::min<int64_t>(4608, by_work));
@@ -388,7 +391,7 @@ struct UtilArgs {
 // the update and every sweep of a noise-parameter object) less, the same bits.
 static int make_util_args(UtilArgs& ua, const double* d_noise_var, int64_t noise_ld, const double* d_cost, double cost_scalar,
                           int n_channels, int n_params) {
-    ua = UtilArgs{d_noise_var, noise_ld, d_cost, cost_scalar, 0, {0, 0, 0, 0}};
+    ua = UtilArgs{d_noise_var, noise_ld, d_cost, cost_scalar, 0, {}};
     if (noise_ld >= 0) return 0;
     const int64_t code = -noise_ld - 1;
     ua.mom_dims = n_params;
@@ -530,13 +533,18 @@ __global__ __launch_bounds__(FG * WS) void sweep_finalize(const double* __restri
                                                              int64_t* __restrict__ bi, double* __restrict__ bk,
                                                              const unsigned* abort) {
     static_assert(WS == 64 || WS == 16, "a wavefront holds one or four chunk groups");
-    __shared__ double acc1[OBE_MAX_CHANNELS][FG][WS];
-    __shared__ double acc2[OBE_MAX_CHANNELS][FG][WS];
+    // (one channel's group sums at a time: OBE_MAX_CHANNELS = 8 of them would not fit the 64 KB of static LDS at
+    // FG = 16, WS = 64.  Wavefront 0 turns channel c's sums into its variance before channel c + 1 overwrites them;
+    // the sums themselves, their order and the arithmetic on them are what they were: the same bits.)
+    __shared__ double acc1[FG][WS];
+    __shared__ double acc2[FG][WS];
     if (sweep_aborted(abort)) return;
     const double W = full_mode ? moments[0] : 1.0;
     const int wlane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const int lane = wlane % WS, grp = wave * (kWave / WS) + wlane / WS;      // setting within the tile, chunk group
     const int64_t s = (int64_t)blockIdx.x * WS + lane;
+    double var[OBE_MAX_CHANNELS];
+    double kappa = 0.0;     // worst (mean of y')^2 / var: the cancellation an UNSHIFTED sweep would suffer
     for (int c = 0; c < nc; ++c) {
         double a1 = 0.0, a2 = 0.0;
         if (s < ns) {
@@ -575,21 +583,17 @@ __global__ __launch_bounds__(FG * WS) void sweep_finalize(const double* __restri
                 }
             }
         }
-        acc1[c][grp][lane] = a1;
-        acc2[c][grp][lane] = a2;
-    }
-    __syncthreads();
-    if (wave != 0) return;
-    Best best{-INFINITY, INT64_MAX};
-    double kappa = 0.0;     // worst (mean of y')^2 / var: the cancellation an UNSHIFTED sweep would suffer
-    if (grp == 0 && s < ns) {
-        double var[OBE_MAX_CHANNELS];
-        for (int c = 0; c < nc; ++c) {
-            double a1 = 0.0, a2 = 0.0;
+        if (c > 0) __syncthreads();          // wavefront 0 has consumed the previous channel's sums
+        acc1[grp][lane] = a1;
+        acc2[grp][lane] = a2;
+        __syncthreads();
+        if (wave == 0 && grp == 0 && s < ns) {
+            a1 = 0.0;
+            a2 = 0.0;
 #pragma unroll
             for (int g = 0; g < FG; ++g) {
-                a1 += acc1[c][g][lane];
-                a2 += acc2[c][g][lane];
+                a1 += acc1[g][lane];
+                a2 += acc2[g][lane];
             }
             // (Measured alternative: chunk partials combined with TwoSum and S1*(S1/W) formed exactly
             // with FMAs, plus per-tile flushing of the running sums, lowers the error of the
@@ -605,6 +609,10 @@ __global__ __launch_bounds__(FG * WS) void sweep_finalize(const double* __restri
             const double k = v != v ? v : (v > 0.0 ? (m * m) / v : (m == 0.0 ? 0.0 : INFINITY));
             kappa = kappa_worst(kappa, k);                 // a NaN variance is reported as kappa = NaN
         }
+    }
+    if (wave != 0) return;
+    Best best{-INFINITY, INT64_MAX};
+    if (grp == 0 && s < ns) {
         const double u = utility_of(var, nc, s, ua);
         utility[s] = u;
         best = Best{u, s};
@@ -622,9 +630,13 @@ __global__ __launch_bounds__(kBlock) void utility_kernel(const double* __restric
                                                          double* __restrict__ bv, int64_t* __restrict__ bi) {
     Best best{-INFINITY, INT64_MAX};
     for (int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x; s < ns; s += (int64_t)gridDim.x * kBlock) {
-        double var[OBE_MAX_CHANNELS];
-        for (int c = 0; c < nc; ++c) var[c] = yvar[(int64_t)c * ns + s];
-        const double u = utility_of(var, nc, s, ua);
+        // np.sum(var_p / var_n, axis=0) / cost over ANY number of channels (obe_base.py:654-655; noise_ld >= 0 here)
+        double acc = 0.0;
+        for (int c = 0; c < nc; ++c) {
+            const double nv = ua.noise_ld > 0 ? ua.noise_var[(int64_t)c * ua.noise_ld + s] : ua.noise_var[c];
+            acc = acc + yvar[(int64_t)c * ns + s] / nv;
+        }
+        const double u = acc / (ua.cost ? ua.cost[s] : ua.cost_scalar);
         utility[s] = u;
         Best cand{u, s};
         if (better(cand, best)) best = cand;
@@ -968,7 +980,7 @@ static int prepare_sweep(const obe_model* m, obe_model& mm, const double* d_sett
             return 0;
         }))
         return rc;
-    plan = plan_sweep(ns, nd, cost);
+    plan = plan_sweep(ns, nd, cost, mm.n_channels > 4 ? 2 : 8);
     const int64_t part = (int64_t)plan.nchunks * mm.n_channels * ns;
     if (int rc = carve_sweep_ws(d_ws, ws_bytes, part, (int64_t)mm.n_channels * ns, w, argmax_slots(ns), nd * packed_w))
         return rc;
@@ -1232,14 +1244,14 @@ int obe_yspace_variance(const double* d_yspace, int64_t n_draws, int32_t n_chann
 int obe_utility_argmax(const double* d_yvar, int32_t n_channels, int64_t n_settings, const double* d_noise_var,
                        int64_t noise_ld, const double* d_cost, double cost_scalar, double* d_utility,
                        double* h_best, int64_t* h_best_idx, void* d_ws, int64_t ws_bytes, void* stream) {
-    if (!d_yvar || !d_noise_var || !d_utility || n_settings <= 0 || n_channels < 1 || n_channels > OBE_MAX_CHANNELS)
+    if (!d_yvar || !d_noise_var || !d_utility || n_settings <= 0 || n_channels < 1)
         return bad_arg("obe_utility_argmax: bad pointer/size");
     SweepWs w;
     if (int rc = carve_sweep_ws(d_ws, ws_bytes, 0, 0, w)) return rc;
     hipStream_t st = as_stream(stream);
     if (noise_ld < 0) return bad_arg("obe_utility_argmax: noise_ld < 0 (noise variance from a K3 block) is for obe_sweep_utility");
     UtilArgs ua;
-    if (int rc = make_util_args(ua, d_noise_var, noise_ld, d_cost, cost_scalar, n_channels, 0)) return rc;
+    if (int rc = make_util_args(ua, d_noise_var, noise_ld, d_cost, cost_scalar, 0, 0)) return rc;
     const int nb = stream_blocks(n_settings, kBlock);
     utility_kernel<<<nb, kBlock, 0, st>>>(d_yvar, n_channels, n_settings, ua, d_utility, w.bv, w.bi);
     OBE_CHECK_LAUNCH("utility_kernel");

@@ -493,15 +493,24 @@ __global__ __launch_bounds__(kBlock) void weight_sums_kernel(const double* __res
     }
 }
 
+// (accumulate: this launch handles one group of <= OBE_MAX_CHANNELS channels of a wider record and multiplies its
+// product onto the groups before it — lky *= ... in channel order, obe_base.py:453-456)
 __global__ __launch_bounds__(kBlock) void likelihood_y_kernel(LikArgs la, int n_channels,
                                                               const double* __restrict__ yv, int64_t ld_y,
                                                               const double* __restrict__ particles, int64_t ld,
-                                                              int64_t n, double* __restrict__ out) {
+                                                              int64_t n, double* __restrict__ out, int accumulate = 0) {
     for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (int64_t)gridDim.x * kBlock) {
         double y[OBE_MAX_CHANNELS];
         for (int c = 0; c < n_channels; ++c) y[c] = yv[(int64_t)c * ld_y + p];
-        out[p] = likelihood_of(y, la, particles, ld, p);
+        const double lk = likelihood_of(y, la, particles, ld, p);
+        out[p] = accumulate ? out[p] * lk : lk;
     }
+}
+
+// np.power(lky, choke) over the finished product of a record wider than one group (obe_base.py:458-459)
+__global__ __launch_bounds__(kBlock) void choke_kernel(double* __restrict__ lk, int64_t n, double choke) {
+    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (int64_t)gridDim.x * kBlock)
+        lk[p] = pow(lk[p], choke);
 }
 
 template <class M>
@@ -954,7 +963,7 @@ static int update_model_moments(const obe_model* m, const double* d_particles, i
     if (int rc = obe_model_validate(&mm)) return rc;
     if (n_lik_channels > mm.n_channels) return bad_arg("n_lik_channels exceeds model channels");
     const int d = mm.n_params;
-    if (d < 1 || d > OBE_MAX_DIMS) return bad_arg("obe_bayes_update_model_moments: n_params must be 1..16");
+    if (d < 1 || d > kFastDims) return bad_arg("obe_bayes_update_model_moments: n_params must be 1..16 (OBE_FAST_DIMS)");
     LikArgs la;
     if (int rc = fill_lik_args(la, h_y_meas, h_sigma, h_noise_rows, n_lik_channels, choke, mm.n_params)) return rc;
     UpdateWs w;
@@ -991,7 +1000,7 @@ static int update_model_moments(const obe_model* m, const double* d_particles, i
             using Model = decltype(M);
             if (d == Model::NREAD)
                 return try_onepass<Model, Model::NREAD>(mm, sa, la, d_particles, ld_p, n_particles, d_weights, w, nb, fold, st);
-            if constexpr (Model::NREAD + 1 <= OBE_MAX_DIMS) {
+            if constexpr (Model::NREAD + 1 <= kFastDims) {
                 if (d == Model::NREAD + 1)
                     return try_onepass<Model, Model::NREAD + 1>(mm, sa, la, d_particles, ld_p, n_particles, d_weights, w,
                                                                  nb, fold, st);
@@ -1136,7 +1145,7 @@ int obe_bayes_update_y(const double* d_y, int64_t ld_y, int32_t n_channels, cons
     if (n_channels < 1 || n_channels > OBE_MAX_CHANNELS || n_lik_channels > n_channels) return bad_arg("bad channel count");
     if (h_noise_rows && !d_particles) return bad_arg("noise rows need d_particles");
     LikArgs la;
-    if (int rc = fill_lik_args(la, h_y_meas, h_sigma, h_noise_rows, n_lik_channels, choke, OBE_MAX_DIMS)) return rc;
+    if (int rc = fill_lik_args(la, h_y_meas, h_sigma, h_noise_rows, n_lik_channels, choke, OBE_CLOUD_MAX_DIMS)) return rc;
     UpdateWs w;
     if (int rc = carve_update_ws(d_ws, ws_bytes, w)) return rc;
     hipStream_t st = as_stream(stream);
@@ -1163,14 +1172,33 @@ int obe_likelihood_y(const double* d_y, int64_t ld_y, int32_t n_channels, const 
                      const int32_t* h_noise_rows, int32_t n_lik_channels, double choke, double* d_lik_out,
                      void* stream) {
     if (!d_y || !d_lik_out || n_particles <= 0) return bad_arg("obe_likelihood_y: bad pointer/size");
-    if (n_channels < 1 || n_channels > OBE_MAX_CHANNELS || n_lik_channels > n_channels) return bad_arg("bad channel count");
+    if (n_channels < 1 || n_lik_channels > n_channels || n_lik_channels < 0) return bad_arg("bad channel count");
     if (h_noise_rows && !d_particles) return bad_arg("noise rows need d_particles");
-    LikArgs la;
-    if (int rc = fill_lik_args(la, h_y_meas, h_sigma, h_noise_rows, n_lik_channels, choke, OBE_MAX_DIMS)) return rc;
     hipStream_t st = as_stream(stream);
-    likelihood_y_kernel<<<stream_blocks(n_particles, kBlock), kBlock, 0, st>>>(la, n_channels, d_y, ld_y, d_particles,
-                                                                                ld_p, n_particles, d_lik_out);
-    OBE_CHECK_LAUNCH("likelihood_y_kernel");
+    const int nb = stream_blocks(n_particles, kBlock);
+    if (n_lik_channels <= OBE_MAX_CHANNELS) {
+        LikArgs la;
+        if (int rc = fill_lik_args(la, h_y_meas, h_sigma, h_noise_rows, n_lik_channels, choke, OBE_CLOUD_MAX_DIMS)) return rc;
+        likelihood_y_kernel<<<nb, kBlock, 0, st>>>(la, n_lik_channels, d_y, ld_y, d_particles, ld_p, n_particles, d_lik_out);
+        OBE_CHECK_LAUNCH("likelihood_y_kernel");
+        return 0;
+    }
+    // a record of more channels than one launch takes (the reference has no limit: obe_base.py:807-824): groups of
+    // OBE_MAX_CHANNELS in channel order, each multiplied onto the product so far; the choke at the end
+    for (int c0 = 0; c0 < n_lik_channels; c0 += OBE_MAX_CHANNELS) {
+        const int nc = n_lik_channels - c0 < OBE_MAX_CHANNELS ? n_lik_channels - c0 : OBE_MAX_CHANNELS;
+        LikArgs la;
+        if (int rc = fill_lik_args(la, h_y_meas + c0, h_sigma ? h_sigma + c0 : nullptr,
+                                   h_noise_rows ? h_noise_rows + c0 : nullptr, nc, NAN, OBE_CLOUD_MAX_DIMS))
+            return rc;
+        likelihood_y_kernel<<<nb, kBlock, 0, st>>>(la, nc, d_y + (int64_t)c0 * ld_y, ld_y, d_particles, ld_p, n_particles,
+                                                   d_lik_out, c0 > 0);
+        OBE_CHECK_LAUNCH("likelihood_y_kernel");
+    }
+    if (!(choke != choke)) {
+        choke_kernel<<<nb, kBlock, 0, st>>>(d_lik_out, n_particles, choke);
+        OBE_CHECK_LAUNCH("choke_kernel");
+    }
     return 0;
 }
 
@@ -1265,7 +1293,7 @@ int obe_mask_renorm_moments(const double* d_particles, int64_t ld_p, int32_t n_d
                             int64_t* h_changed, void* d_ws, int64_t ws_bytes, void* stream) {
     if (!d_particles || !d_weights || !d_mask_partials || !d_moments || n_particles <= 0)
         return bad_arg("obe_mask_renorm_moments: bad pointer/size");
-    if (n_dims < 1 || n_dims > OBE_MAX_DIMS) return bad_arg("obe_mask_renorm_moments: n_dims must be 1..16");
+    if (n_dims < 1 || n_dims > kFastDims) return bad_arg("obe_mask_renorm_moments: n_dims must be 1..16 (OBE_FAST_DIMS)");
     hipStream_t st = as_stream(stream);
     unsigned* counter = stream_control_words(st);
     int64_t* hc = static_cast<int64_t*>(device_view_of_host(h_changed));
@@ -1286,13 +1314,14 @@ int obe_mask_nonpositive_moments(const double* d_particles, int64_t ld_p, int32_
                                  double* h_moments, int64_t* h_changed, void* d_ws, int64_t ws_bytes, void* stream) {
     if (!d_particles || !d_weights || !h_rows || !d_moments || n_rows < 1 || n_rows > OBE_MAX_DIMS || n_particles <= 0)
         return bad_arg("obe_mask_nonpositive_moments: bad pointer/size");
-    if (n_dims < 1 || n_dims > OBE_MAX_DIMS) return bad_arg("obe_mask_nonpositive_moments: n_dims must be 1..16");
+    if (n_dims < 1 || n_dims > OBE_CLOUD_MAX_DIMS) return bad_arg("obe_mask_nonpositive_moments: n_dims must be 1..1024");
     hipStream_t st = as_stream(stream);
     unsigned* counter = stream_control_words(st);
     int64_t* hc = static_cast<int64_t*>(device_view_of_host(h_changed));
     double* hm = static_cast<double*>(device_view_of_host(h_moments));
-    if (!counter || (h_changed && !hc) || (h_moments && !hm)) {
-        // no arrival counter for this stream / pageable host buffers: the two separate calls (synchronous)
+    if (!counter || (h_changed && !hc) || (h_moments && !hm) || n_dims > kFastDims) {
+        // no arrival counter for this stream / pageable host buffers / a cloud wider than the fused kernels are
+        // compiled for: the two separate calls (synchronous)
         if (int rc = obe_mask_nonpositive(d_particles, ld_p, n_particles, h_rows, n_rows, d_weights, h_changed, d_ws,
                                           ws_bytes, stream))
             return rc;
@@ -1356,7 +1385,7 @@ int obe_power_normalize(const double* d_u, int64_t n, double exponent, double* d
 
 int obe_noise_var_from_moments(const double* d_moments, int32_t n_dims, const int32_t* h_rows, int32_t n_rows,
                                double* d_out, void* stream) {
-    if (!d_moments || !h_rows || !d_out || n_rows < 1 || n_rows > OBE_MAX_CHANNELS)
+    if (!d_moments || !h_rows || !d_out || n_rows < 1 || n_rows > OBE_MAX_DIMS)
         return bad_arg("obe_noise_var_from_moments: bad pointer/size");
     RowsArg ra{};
     ra.n = n_rows;

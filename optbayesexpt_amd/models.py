@@ -197,9 +197,33 @@ def from_expression(expression, settings, parameters, constants=(), name=None):
     from . import _exprmodel, build
     header, numpy_form, digest = _exprmodel.translate(expression, settings, parameters, constants)
     n_channels = 1 if isinstance(expression, str) else len(expression)
+    beyond = _beyond_device_limits(len(parameters), len(settings), n_channels, len(constants))
+    if beyond:
+        # the reference takes any number of settings, parameters and channels (obe_base.py:174-176, 807-824): a model
+        # beyond what the device functions are compiled for runs as a host-callable model — the formula's NumPy form
+        # is evaluated on the host, everything around it stays on the device
+        import warnings
+        warnings.warn(f"expression model kept on the host ({beyond})", RuntimeWarning)
+        numpy_form.__name__ = name or f"expression[{digest}]"
+        return numpy_form
     lib = build.build_plugin(header, digest)
     return DeviceModel(name or f"expression[{digest}]", MODEL_PLUGIN, 0, len(parameters), len(settings),
                        n_channels, len(constants), numpy_form, plugin_path=lib)
+
+
+def _beyond_device_limits(n_parameters, n_settings, n_channels, n_consts):
+    """'' if a generated model of this shape fits the device interface (include/obe_hip.h), else what does not."""
+    from . import _lib
+    over = []
+    if n_parameters > _lib.OBE_MAX_DIMS:
+        over.append(f"{n_parameters} parameters > {_lib.OBE_MAX_DIMS}")
+    if n_settings > _lib.OBE_MAX_SETDIMS:
+        over.append(f"{n_settings} setting dimensions > {_lib.OBE_MAX_SETDIMS}")
+    if n_channels > _lib.OBE_MAX_CHANNELS:
+        over.append(f"{n_channels} channels > {_lib.OBE_MAX_CHANNELS}")
+    if n_consts > _lib.OBE_MAX_CONSTS:
+        over.append(f"{n_consts} constants > {_lib.OBE_MAX_CONSTS}")
+    return ", ".join(over)
 
 
 #: When True (or the environment has OBE_AUTO_DEVICE_MODEL=1), ``OptBayesExpt`` tries
@@ -222,6 +246,9 @@ def from_function(model_function, name=None):
     exprs, settings, parameters, constants = _fnmodel.expressions_from_function(model_function)
     header, numpy_form, digest = _exprmodel.translate(exprs, settings, parameters, constants)
     _fnmodel.check_against_function(model_function, numpy_form, len(settings), len(parameters), len(constants))
+    beyond = _beyond_device_limits(len(parameters), len(settings), len(exprs), len(constants))
+    if beyond:
+        raise ValueError(f"beyond the device limits ({beyond})")      # (the caller keeps the function on the host)
     lib = build.build_plugin(header, digest)
     label = name or f"function[{getattr(model_function, '__name__', 'model')}:{digest}]"
     dm = DeviceModel(label, MODEL_PLUGIN, 0, len(parameters), len(settings), len(exprs), len(constants),

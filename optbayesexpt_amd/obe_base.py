@@ -169,6 +169,12 @@ class OptBayesExpt(ParticlePDF):
                 warnings.warn(f"model function kept on the host ({exc})", RuntimeWarning)
         self.model_function = measurement_model
         self._device_model = measurement_model if isinstance(measurement_model, DeviceModel) else None
+        if self._device_model is not None and self.n_dims > _lib.OBE_MAX_DIMS:
+            # more parameter rows than a device model may be given (include/obe_hip.h: OBE_MAX_DIMS): the model's
+            # NumPy form is evaluated on the host, as any plain callable is; everything else stays on the device
+            warnings.warn(f"{self._device_model.name}: {self.n_dims} parameters exceed the device models' limit of "
+                          f"{_lib.OBE_MAX_DIMS}; the model function is evaluated on the host", RuntimeWarning)
+            self._device_model = None
         self._mlib = self._lib          # model-dependent entry points; an expression model brings its own
         self.setting_values = setting_values
         #: (S, N_s) all setting combinations, meshgrid indexing='ij' (obe_base.py:174-176)
@@ -196,8 +202,9 @@ class OptBayesExpt(ParticlePDF):
         else:
             self._model_struct = None
             self.n_channels = self._model_output_len()
-        if self.n_channels > _lib.OBE_MAX_CHANNELS:
-            raise ValueError(f"at most {_lib.OBE_MAX_CHANNELS} channels are supported on the device")
+        #: a host-callable model with more output channels than one kernel launch takes: the likelihood is formed
+        #: in groups of channels (obe_likelihood_y), the update takes it as an array
+        self._wide_channels = self.n_channels > _lib.OBE_MAX_CHANNELS
 
         if self.n_channels == 1:
             def wrapped_function(s, p, c):
@@ -213,8 +220,8 @@ class OptBayesExpt(ParticlePDF):
         # the record of a measurement as the library takes it (filled in place, addresses made once)
         self._hargs = _lib.HostArgs()
         self._rec_x = self._hargs.keep(np.zeros(_lib.OBE_MAX_SETDIMS))
-        self._rec_y = self._hargs.keep(np.zeros(_lib.OBE_MAX_CHANNELS))
-        self._rec_s = self._hargs.keep(np.ones(_lib.OBE_MAX_CHANNELS))
+        self._rec_y = self._hargs.keep(np.zeros(max(_lib.OBE_MAX_CHANNELS, self.n_channels)))
+        self._rec_s = self._hargs.keep(np.ones(max(_lib.OBE_MAX_CHANNELS, self.n_channels)))
         self._hargs.keep(self._host_out)
         # which form / shift the next sweep uses, and the sweep pdf_update() enqueues ahead (_sweepstate.py)
         self._sweeps = SweepState(_SweepIO(self), self)
@@ -374,7 +381,7 @@ class OptBayesExpt(ParticlePDF):
         th = _lib.f64(np.asarray(oneparamset, dtype=np.float64).reshape(-1)[:self.n_dims], None)
         if th.size < self._device_model.n_read:
             raise ValueError("parameter set is shorter than the model's parameter list")
-        thp = np.zeros(_lib.OBE_MAX_DIMS)
+        thp = np.zeros(max(_lib.OBE_MAX_DIMS, th.size))
         thp[:th.size] = th
         y = torch.empty((self.n_channels, self._n_settings), dtype=torch.float64, device=self._device)
         self._mlib.call("obe_eval_over_settings", self._model_struct, _ptr(self._settings_dev),
@@ -452,7 +459,7 @@ class OptBayesExpt(ParticlePDF):
                     hp(yy), None if s is None else hp(s),
                     None if rows is None else hp(rows), n, self._choke_value())
             if self._parameters is self._particles and self.tuning_parameters.get("fused_moments", True) \
-                    and not self._strict_sums():
+                    and not self._strict_sums() and self.n_dims <= _lib.OBE_FAST_DIMS:
                 # ... and the first moments of the posterior in the same pass over the cloud: the next
                 # sweep's shift, mean(), std() and the noise-parameter variance need no launch of their own
                 self._drop_speculative_sweep()
@@ -478,6 +485,10 @@ class OptBayesExpt(ParticlePDF):
             if self._likelihood_overridden():
                 likyhd = self.likelihood(y_model_data, measurement_record)   # user NumPy code
                 self.bayesian_update(likyhd)
+            elif self._wide_channels:
+                # more channels than one launch of the fused y-update takes: the likelihood in groups of channels
+                # (a device array), then the update from it
+                self.bayesian_update(self._likelihood_device(y_model_data, measurement_record))
             else:
                 y_dev = self._y_to_device(y_model_data)
                 n, yy, s, rows = self._likelihood_inputs(measurement_record)
@@ -647,6 +658,9 @@ class OptBayesExpt(ParticlePDF):
     def likelihood(self, y_model, measurement_record):
         """Gaussian likelihood of the measurement for every parameter sample
         (obe_base.py:418-461), computed on the device from ``y_model`` (C x N_p)."""
+        return self._likelihood_device(y_model, measurement_record).cpu().numpy()
+
+    def _likelihood_device(self, y_model, measurement_record):
         y_dev = self._y_to_device(y_model)
         n, yy, s, rows = self._likelihood_inputs(measurement_record)
         par = self._parameters.tensor()
@@ -656,7 +670,7 @@ class OptBayesExpt(ParticlePDF):
                        None if s is None else _lib.host_ptr(s),
                        None if rows is None else _lib.host_ptr(rows), n, self._choke_value(), _ptr(out),
                        self._stream())
-        return out.cpu().numpy()
+        return out
 
     # ----------------------------------------------------------------- utility
     def yvar_noise_model(self):

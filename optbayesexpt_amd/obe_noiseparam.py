@@ -25,7 +25,7 @@ class OptBayesExptNoiseParameter(OptBayesExpt):
         if len(self.noise_parameter_index) != self.n_channels:
             raise RuntimeError(f"noise_parameter_index is not compatible with"
                                f" {self.n_channels} measurement channels")
-        self._noise_rows = np.zeros(_lib.OBE_MAX_DIMS, dtype=np.int32)
+        self._noise_rows = np.zeros(max(_lib.OBE_MAX_DIMS, self.n_channels), dtype=np.int32)
         rows = np.asarray(self.noise_parameter_index, dtype=np.int64)
         rows = np.where(rows < 0, rows + self.n_dims, rows)          # NumPy negative indexing
         if np.any(rows < 0) or np.any(rows >= self.n_dims):
@@ -161,9 +161,15 @@ class OptBayesExptNoiseParameter(OptBayesExpt):
             if not values and self._device_model is not None:
                 code = self.__dict__.get("_noise_ld_code")
                 if code is None:
-                    rows = [int(r) for r in self._noise_rows[:self.n_channels]] + [0] * 4
-                    code = self._noise_ld_code = -1 - (rows[0] | rows[1] << 5 | rows[2] << 10 | rows[3] << 15)
-                return mom, code
+                    # (5 bits per channel, OBE_MAX_CHANNELS channels: rows below 32 — any other object hands the
+                    # sweep the variances as values instead)
+                    rows = [int(r) for r in self._noise_rows[:self.n_channels]]
+                    if max(rows) < 32 and len(rows) <= _lib.OBE_MAX_CHANNELS:
+                        code = self._noise_ld_code = -1 - sum(r << (5 * c) for c, r in enumerate(rows))
+                    else:
+                        code = self._noise_ld_code = 0
+                if code:
+                    return mom, code
         else:
             # stale alias after set_pdf(): the reference averages the rows of
             # ``parameters`` (old samples) with the current weights

@@ -80,8 +80,8 @@ class ParticlePDF:
         self._particles = Mirror(self._device, host=host)
         self.n_particles = host.shape[-1]
         self.n_dims = host.shape[0]
-        if self.n_dims > _lib.OBE_MAX_DIMS:
-            raise ValueError(f"at most {_lib.OBE_MAX_DIMS} parameters are supported on the device")
+        if self.n_dims > _lib.OBE_CLOUD_MAX_DIMS:
+            raise ValueError(f"at most {_lib.OBE_CLOUD_MAX_DIMS} parameters are supported on the device")
         self._weights = Mirror(self._device, host=np.ones(self.n_particles) / self.n_particles)
         self._alloc_scratch()
         if weights is not None:
@@ -178,8 +178,8 @@ class ParticlePDF:
         if resized:
             # the workspace, CDF and moment blocks are sized for the cloud; the weights keep their
             # length (as in the reference) and a mismatch is reported by the next kernel call
-            if self.n_dims > _lib.OBE_MAX_DIMS:
-                raise ValueError(f"at most {_lib.OBE_MAX_DIMS} parameters are supported on the device")
+            if self.n_dims > _lib.OBE_CLOUD_MAX_DIMS:
+                raise ValueError(f"at most {_lib.OBE_CLOUD_MAX_DIMS} parameters are supported on the device")
             self._alloc_scratch()
 
     @property
@@ -476,7 +476,9 @@ class ParticlePDF:
         method = self.tuning_parameters.get("resample_method", "multinomial")
         if method == "multinomial":                       # the reference: N i.i.d. uniforms
             state = self._device_rng_state(n, n * d)
-            if state is not None and self.tuning_parameters.get("pipelined_resample", True):
+            # (the one-call pipeline exists for the widths its kernels are compiled for; a wider cloud takes the
+            # step-by-step path, whose kernels tile over the rows: include/obe_hip.h, OBE_FAST_DIMS)
+            if state is not None and self.tuning_parameters.get("pipelined_resample", True) and d <= _lib.OBE_FAST_DIMS:
                 return self._resample_pipelined(state)
             rstream = self._device_stream(n, n * d)       # exact continuation of self.rng, or None
             idx = self._draw_indices(n, rstream)

@@ -17,8 +17,14 @@ def expression_models():
          "p11*s3 + p0*p1 - p2"),
         settings=("s0", "s1", "s2", "s3"), parameters=pn, name="limits_4x16x4")
     import _fn_models
+    # beyond the widths the fused cloud kernels are compiled for (OBE_FAST_DIMS = 16) and the old channel limit: 20
+    # parameters, 5 channels — channel c is the cubic p[4c] + p[4c+1] x + p[4c+2] x^2 + p[4c+3] x^3
+    wide = models.from_expression(
+        tuple(f"p{4 * c} + p{4 * c + 1}*x + p{4 * c + 2}*x*x + p{4 * c + 3}*x*x*x" for c in range(5)),
+        settings=("x",), parameters=tuple(f"p{i}" for i in range(20)), name="wide_20x5")
     return {
         "limits": big,
+        "wide": wide,
         # translated from the source of plain reference-style functions (models.from_function)
         "fn_lorentzian": models.from_function(_fn_models.lorentzian),
         "fn_rabi": models.from_function(_fn_models.rabi),
