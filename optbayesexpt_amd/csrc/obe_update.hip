@@ -877,11 +877,14 @@ __device__ __forceinline__ double np_staged_sum(const double* __restrict__ a, in
     return threadIdx.x == 0 ? np_combine(leaf, n) : 0.0;
 }
 
+// (stop: a sweep batch whose earlier point asked for a resample — every later launch of the batch returns at once)
 template <bool SQUARE>
 __global__ __launch_bounds__(kBlock) void numpy_order_sum_kernel(const double* __restrict__ a, int64_t n,
-                                                                 double* __restrict__ out) {
+                                                                 double* __restrict__ out,
+                                                                 const double* __restrict__ stop = nullptr) {
     __shared__ double stage[kNpStage];
     __shared__ double leaf[kNpStage / 64 + 8];           // (a leaf holds at least 64 elements unless it is the whole run)
+    if (stop && stop[0] != 0.0) return;
     double res = 0.0;
     for (int64_t lo = 0; lo < n; lo += kNpPiece) {
         const int m = (int)(n - lo < kNpPiece ? n - lo : kNpPiece);
@@ -1110,6 +1113,9 @@ int obe_bayes_update_sweep(const obe_model* m, const double* d_particles, int64_
     sweep_state_reset_kernel<<<1, 1, 0, st>>>(w.scalars);
     OBE_CHECK_LAUNCH("sweep_state_reset_kernel");
     const double* stop = w.scalars + 2;
+    // (obe_strict_sums: every point's sum t and sum w'^2 in np.sum's order, as the point-by-point calls form them)
+    const bool strict = g_strict_sums != 0;
+    const int nfold = strict ? 1 : nb;
     for (int64_t k = 0; k < n_points; ++k) {
         LikArgs la;
         if (int rc = fill_lik_args(la, h_y_meas + k * OBE_MAX_CHANNELS, h_sigma, h_noise_rows, n_lik_channels, choke,
@@ -1117,7 +1123,7 @@ int obe_bayes_update_sweep(const obe_model* m, const double* d_particles, int64_
             return rc;
         SettingArg sa{};
         for (int j = 0; j < mm.n_setdims; ++j) sa.x[j] = h_settings ? h_settings[k * OBE_MAX_SETDIMS + j] : 0.0;
-        const SweepCtl ctl{w.scalars, w.pa, w.pb, nb, (int)k, auto_resample, resample_threshold, (double)n_particles};
+        const SweepCtl ctl{w.scalars, w.pa, w.pb, nfold, (int)k, auto_resample, resample_threshold, (double)n_particles};
         int rc = dispatch_model(mm, [&](auto M) -> int {
             using Model = decltype(M);
             update_model_kernel<Model><<<nb, kBlock, 0, st>>>(mm, sa, la, d_particles, ld_p, n_particles, d_weights,
@@ -1126,10 +1132,18 @@ int obe_bayes_update_sweep(const obe_model* m, const double* d_particles, int64_
             return 0;
         });
         if (rc) return rc;
-        normalize_kernel<<<nb, kBlock, 0, st>>>(w.pa, nb, n_particles, d_weights, w.pb, stop);
+        if (strict) {
+            numpy_order_sum_kernel<false><<<1, kBlock, 0, st>>>(d_weights, n_particles, w.pa, stop);
+            OBE_CHECK_LAUNCH("numpy_order_sum_kernel");
+        }
+        normalize_kernel<<<nb, kBlock, 0, st>>>(w.pa, nfold, n_particles, d_weights, w.pb, stop);
         OBE_CHECK_LAUNCH("normalize_kernel");
+        if (strict) {
+            numpy_order_sum_kernel<true><<<1, kBlock, 0, st>>>(d_weights, n_particles, w.pb, stop);
+            OBE_CHECK_LAUNCH("numpy_order_sum_kernel");
+        }
     }
-    fold2_stop_kernel<<<1, kBlock, 0, st>>>(w.pa, w.pb, nb, w.scalars, (double)n_particles, auto_resample,
+    fold2_stop_kernel<<<1, kBlock, 0, st>>>(w.pa, w.pb, nfold, w.scalars, (double)n_particles, auto_resample,
                                             resample_threshold, (int)n_points);
     OBE_CHECK_LAUNCH("fold2_stop_kernel");
     OBE_HIP_TRY(hipMemcpyAsync(h_out, w.scalars, 4 * sizeof(double), hipMemcpyDeviceToHost, st));

@@ -78,7 +78,7 @@ class OptBayesExptSweeper(OptBayesExptNoiseParameter):
         while pos < len(points):
             k = min(chunk, len(points) - pos)
             par, w = self._parameters.tensor(), self._weights.tensor()
-            self._mlib.call("obe_bayes_update_sweep", self._model_struct, _ptr(par), par.shape[1], self.n_particles,
+            self._unfused_update(self._mlib, "obe_bayes_update_sweep", self._model_struct, _ptr(par), par.shape[1], self.n_particles,
                             _ptr(w), _lib.host_ptr(xs[pos:]), _lib.host_ptr(ys[pos:]), None,
                             _lib.host_ptr(self._noise_rows), n_lik, self._choke_value(), k,
                             1 if self.tuning_parameters["auto_resample"] else 0,
