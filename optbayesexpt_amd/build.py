@@ -152,6 +152,9 @@ def library_is_stale():
 #: where generated models are compiled to; OBE_PLUGIN_DIR overrides (e.g. a read-only installation)
 PLUGIN_DIR = os.environ.get("OBE_PLUGIN_DIR", os.path.join(OUT_DIR, "plugins"))
 PLUGIN_SOURCES = ["obe_capi.hip", "obe_update.hip", "obe_sweep.hip", "obe_yspace.hip"]   # model-dependent
+#: linked into every plugin as well, but the same for every model: the object the LIBRARY build left in lib/obj is
+#: reused (its ~45 kernel instantiations took 9 of the 10 s of a formula's first use when each plugin recompiled them)
+PLUGIN_COMMON_SOURCES = ["obe_update_common.hip"]
 
 
 def _source_fingerprint():
@@ -221,8 +224,15 @@ def build_plugin(header_text, model_digest, verbose=False):
                     raise RuntimeError(f"hipcc failed for the generated model ({src}):\n{r.stdout}\n{r.stderr}")
                 return obj
 
-            with concurrent.futures.ThreadPoolExecutor(max_workers=4) as ex:
-                objs = list(ex.map(one, PLUGIN_SOURCES))
+            prebuilt, to_compile = [], list(PLUGIN_SOURCES)
+            for src in PLUGIN_COMMON_SOURCES:
+                obj = os.path.join(OBJ_DIR, src[:-4] + ".o")
+                if os.path.exists(obj) and not library_is_stale() and not _stale(obj, [os.path.join(CSRC, src)] + headers()):
+                    prebuilt.append(obj)
+                else:                        # (a library that was not built on this box / with these sources)
+                    to_compile.append(src)
+            with concurrent.futures.ThreadPoolExecutor(max_workers=len(to_compile)) as ex:
+                objs = list(ex.map(one, to_compile)) + prebuilt
             # -Bsymbolic: the entry points call one another (obe_model_validate from every model-dependent
             # call, ...) and those calls must stay inside the plugin: libobe_hip.so, loaded RTLD_GLOBAL
             # before it, exports the same names.  (Everything that is not an entry point is hidden.)
