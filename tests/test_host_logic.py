@@ -236,6 +236,7 @@ build.PLUGIN_DIR = {pdir!r}
 build.HIPCC = {hipcc!r}
 build.FLAGS = []
 build.PLUGIN_SOURCES = ["obe_capi.hip"]
+build.PLUGIN_COMMON_SOURCES = []
 lib = build.build_plugin("// header\n", "d" * 16)
 assert os.path.getsize(lib) > 0
 print(open(lib).read().count("linked"))
