@@ -48,6 +48,7 @@ def run(cfg, shard, log, steps, warmup, events=True):
     fn = obe.model_function
     noise_rec = bench.CONFIGS[cfg][2] == "lorentzian"
     if not os.environ.get("OBE_NO_CLOCK_WARM_UP"):
+        bench.warm_resample_path(cfg, settings, prior, cons)      # (as bench.py does: the resample kernels' code objects)
         bench.warm_clocks(obe)         # (as bench.py does: the chip's clocks ramp for ~35 ms after an idle second)
     times, res = [], []
     record = log is None
