@@ -1645,12 +1645,18 @@ def test_cloud_of_40_parameters_every_particlepdf_method(obe):
     assert_array_equal(a.covariance(), a.covariance().T)
     a.rng, b.rng = np.random.default_rng(41), np.random.default_rng(41)
     assert_array_equal(a.randdraw(7), b.randdraw(7))
-    a.resample()
-    b.resample()
-    assert_array_equal(a.last_draw_indices, b.last_draw_indices)
     floor = 256 * 2.3e-16 * np.sqrt(np.max(np.linalg.eigvalsh(np.cov(x))))
-    assert_allclose(a.particles, b.particles, rtol=RTOL, atol=floor)
-    assert_array_equal(a.particle_weights, b.particle_weights)
+    for scale in (False, True):          # particlepdf.py:303-306: the contraction towards the mean
+        for o in (a, b):
+            o.tuning_parameters["scale"] = scale
+            o.bayesian_update(lik if not scale else np.exp(-0.5 * ((np.asarray(o.particles)[7] - 7.1) / 0.9) ** 2))
+        assert_allclose(a.particle_weights, b.particle_weights, rtol=1e-9)
+        a.resample()
+        b.resample()
+        assert_array_equal(a.last_draw_indices, b.last_draw_indices)
+        assert_allclose(a.particles, b.particles, rtol=RTOL, atol=floor, err_msg=f"scale={scale}")
+        assert_array_equal(a.particle_weights, b.particle_weights)
+        floor *= 40.0                    # (the second resample starts from particles that agree to the first one's floor)
     assert a.rng.bit_generator.state == b.rng.bit_generator.state
 
 
@@ -1688,6 +1694,27 @@ def test_models_beyond_the_device_limits_run_as_host_callable_models(obe):
         if not a.just_resampled:
             _replay.close_weights(a.particle_weights, b.particle_weights, RTOL, f"nine channels, weights, cycle {cyc}")
         assert_allclose(a.mean(), b.mean(), rtol=RTOL)
+    # nine channels whose noise levels are nine parameter rows (obe_noiseparam.py:81-136): the likelihood takes its
+    # sigma from the particles, group by group; the constraint mask over nine rows
+    prior12 = np.vstack([g.normal(1.0, 0.5, (3, n)), g.exponential(0.5, (9, n)) + 0.01])
+    kw = dict(scale=False, noise_parameter_index=tuple(range(3, 12)))
+    a = obe.OptBayesExptNoiseParameter(nine, sv, prior12.copy(), (), **kw)
+    b = oracle.OracleOptBayesExptNoiseParameter(nine, sv, prior12.copy(), (), n_channels=9, **kw)
+    a.rng, b.rng = np.random.default_rng(15), np.random.default_rng(15)
+    for cyc in range(4):
+        xa, xb = a.opt_setting(), b.opt_setting()
+        assert a.last_setting_index == b.last_setting_index, cyc
+        assert_rel(np.asarray(a.last_utility).reshape(-1), b.last_utility, RTOL, f"nine noise rows, utility, cycle {cyc}")
+        y = nine(xb, (1.2, 0.8, 1.1), ()) + 0.5 * sim.standard_normal(9)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            a.pdf_update((xa, tuple(y)))
+            b.pdf_update((xb, tuple(y)))
+        assert a.just_resampled == b.just_resampled, cyc
+        if a.just_resampled:
+            assert_array_equal(np.array(a.particle_weights) == 0.0, np.array(b.particle_weights) == 0.0)
+        else:
+            _replay.close_weights(a.particle_weights, b.particle_weights, RTOL, f"nine noise rows, weights, cycle {cyc}")
     # a built-in device model over a cloud of 33 rows (the model reads 3 of them): OBE_MAX_DIMS = 32 rows is what a
     # device model may be given — the 34th makes it a host-callable model, with a warning
     prior33 = np.vstack([g.uniform(2, 4, (1, n)), g.uniform(-2000, -400, (1, n)), g.normal(50000, 1000, (1, n)),
