@@ -221,6 +221,14 @@ def test_server_command_surface_is_json_serialisable(hip):
     # 'newrun' builds a fresh engine from the stored constructor arguments (obe_server.py:72-94)
     engine2 = obe.OptBayesExpt(obe.models.lorentzian(), sets, prior, (0.1,), scale=False)
     assert_allclose(engine2.particle_weights, 1.0 / n)
+    # the reference's own server test, its literals and its assert_array_equal (tests/test_server.py:111-131;
+    # the engine of tests/server_script_61983.py): 'getwgt' before and after a 'newdat'
+    eng = obe.OptBayesExpt(obe.models.line_ab(), (np.array([0, 1, 2]),), (np.array([0, 1, 2, 3]), np.array([1, 3, 2, 4])), ())
+    assert_array_equal(np.ones(4) / 4.0, send(eng.particle_weights.tolist()), err_msg="weights not echoed correctly")
+    msg = send({"command": "newdat", "x": (1,), "y": 5.0, "s": 1.0})
+    eng.pdf_update((msg["x"], msg["y"], msg["s"]))
+    lkl = np.exp(-(np.array((1, 4, 4, 7)) - 5.0) ** 2 / 2)
+    assert_array_equal(lkl / np.sum(lkl), send(eng.particle_weights.tolist()), err_msg="incorrect updated weights")
 
 
 @pytest.mark.parametrize("call", ["opt_setting", "good_setting", "sweep_utility"])
