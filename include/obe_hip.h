@@ -357,6 +357,17 @@ OBE_API int obe_resample_particles_aos_masked(const double* d_old_aos, int32_t n
                                       double* d_new, int64_t ld_new, double* d_weights,
                                       const int32_t* h_rows, int32_t n_rows, double* d_mask_partials, void* stream);
 
+/* The random numbers of a resample, enqueued AHEAD of it (round 6): the N uniforms and N x D normals that resample()
+ * takes from the caller's generator (particlepdf.py:272, 296-301) depend only on the generator state and the cloud's
+ * shape, and their chain is what a resample's gather ends up waiting for.  Enqueued here — on the library's side stream of
+ * `stream`, typically when pdf_update() starts — it runs beside the update and the host round trips;
+ * obe_resample_begin(h_pcg_state4 = NULL, the same d_uniforms / d_normals / d_zig_ws / h_i64, the same stream) then
+ * launches only the cloud's chains and waits for this one.  The caller compares generator states itself and may keep
+ * the numbers across updates that do not resample.  h_i64[0..1] (page-locked) are armed here; wait for them as after
+ * obe_resample_begin.  -1 before anything is launched: no side streams, h_i64 not page-locked, n_dims > OBE_FAST_DIMS. */
+OBE_API int obe_resample_randoms_enqueue(const uint64_t* h_pcg_state4, int64_t n_particles, int32_t n_dims, int64_t n_raw,
+                                 double* d_uniforms, const void* d_zig_tables, double* d_normals, void* d_zig_ws,
+                                 int64_t zig_ws_bytes, int64_t* h_i64, void* stream);
 /* resample(), the device side up to the host's factorisation of the covariance, enqueued by ONE call
  * (particlepdf.py:260-301; RNG order as there: N uniforms for rng.choice, then N x D normals): the caller's
  * PCG64 stream continued on the device (h_pcg_state4 = {state hi, lo, increment hi, lo}; n_raw >= N + N D +

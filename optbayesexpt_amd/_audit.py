@@ -235,7 +235,8 @@ def _rule_resample_begin(a, args):
     else:
         a._mark(f64, 1, False)                           # (written by the host: 1.0)
     a._mark(f64 + 8 * (1 + lo), mlen - lo, True)
-    a._mark(_addr(args[19]), 2, True)
+    if _addr(args[5]) is not None:                       # (NULL state: the randoms were enqueued ahead, h_i64 armed then)
+        a._mark(_addr(args[19]), 2, True)
 
 
 def _rule_draw_indices(a, args):
@@ -267,6 +268,7 @@ _RULES = {
     "obe_sweep_utility": _rule_sweep,
     "obe_resample_begin": _rule_resample_begin,
     "obe_draw_indices": _rule_draw_indices,
+    "obe_resample_randoms_enqueue": lambda a, args: a._mark(_addr(args[9]), 2, True),
     "obe_mask_nonpositive_moments": _rule_mask_moments(8, 9, 2),
     "obe_mask_renorm_moments": _rule_mask_moments(7, 8, 2),
     # synchronous forms: they wait for their own words before they return

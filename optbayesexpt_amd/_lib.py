@@ -109,6 +109,7 @@ _SIGNATURES = {
                                              _P]),
     "obe_resample_begin": (c_int, [_P, c_int64, c_int32, c_int64, _P, _P, c_int32, c_int32, c_int32, c_int64,
                                    _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, c_int64, _P]),
+    "obe_resample_randoms_enqueue": (c_int, [_P, c_int64, c_int32, c_int64, _P, _P, _P, _P, c_int64, _P, _P]),
     "obe_resample_particles_aos": (c_int, [_P, c_int32, c_int64, _P, _P, _P, _P, c_double, c_int32, _P, c_int64, _P, _P]),
     "obe_resample_particles_aos_masked": (c_int, [_P, c_int32, c_int64, _P, _P, _P, _P, c_double, c_int32, _P, c_int64, _P,
                                                   _P, c_int32, _P, _P]),

@@ -161,7 +161,8 @@ bool side_stream_of(hipStream_t st, SideStream* out) {
     ok = ok && hipEventCreateWithFlags(&s.entry, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&s.mid, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&s.done, hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&s.done2, hipEventDisableTiming) == hipSuccess;
+         hipEventCreateWithFlags(&s.done2, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&s.pre, hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         (void)hipGetLastError();
         s = SideStream{};                 // remembered: not tried again for this stream

@@ -102,6 +102,7 @@ struct SideStream {
     hipEvent_t entry, mid, done;
     hipStream_t stream2;         // a third chain (round 5: the covariance + the (N, D) copy of a resample)
     hipEvent_t done2;
+    hipEvent_t pre;              // round 6: the end of a random-number chain enqueued AHEAD of its resample
 };
 bool side_stream_of(hipStream_t st, SideStream* out);      // obe_capi.hip
 

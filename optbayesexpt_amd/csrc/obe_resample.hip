@@ -774,6 +774,44 @@ static int resample_particles(const double* d_old, int64_t ld_old, int32_t n_dim
     return bad_arg("obe_resample_particles: n_dims must be 1..16");
 }
 
+// The random numbers of a resample, enqueued AHEAD of it (round 6).  The uniforms and normals of resample() depend on
+// nothing but the caller's generator state and the cloud's shape (particlepdf.py:272, 296-301), and their chain —
+// 92 us for 524 288 x 10 — is what the gather of a resample ends up waiting for.  Enqueued when pdf_update() starts,
+// on the library's side stream of `stream`, it runs beside the update's own (latency-bound) kernels and the host round
+// trips that follow; obe_resample_begin(h_pcg_state4 = NULL, the same buffers) then launches only the cloud's chains
+// and waits for the end of this one.  The caller keeps the numbers for as long as its generator has not moved (a
+// cycle that does not resample leaves them for the next one) and compares the state itself: nothing here knows
+// whether they will be used.  h_i64[0..1] = {raw values consumed, normals found} are armed here.
+// Refused (-1) before anything is launched without the library's side streams or page-locked h_i64.
+int obe_resample_randoms_enqueue(const uint64_t* h_pcg_state4, int64_t n_particles, int32_t n_dims, int64_t n_raw,
+                                 double* d_uniforms, const void* d_zig_tables, double* d_normals, void* d_zig_ws,
+                                 int64_t zig_ws_bytes, int64_t* h_i64, void* stream) {
+    if (!h_pcg_state4 || !d_uniforms || !d_zig_tables || !d_normals || !d_zig_ws || !h_i64 || n_particles <= 0 ||
+        n_dims < 1 || n_dims > kFastDims)
+        return bad_arg("obe_resample_randoms_enqueue: bad pointer/size");
+    const int64_t n = n_particles, n_normal = n * n_dims;
+    if (n_raw < n + n_normal + 4096) return bad_arg("obe_resample_randoms_enqueue: fewer raw values than the draws need");
+    if (!device_view_of_host(h_i64)) return bad_arg("obe_resample_randoms_enqueue: h_i64 must be page-locked");
+    hipStream_t st = as_stream(stream);
+    SideStream side{};
+    if (!side_stream_of(st, &side)) return bad_arg("obe_resample_randoms_enqueue: no side stream for this stream");
+    auto ev = [](hipError_t e) { return e == hipSuccess ? 0 : fail(e, "obe_resample_randoms_enqueue: stream / event call"); };
+    const int prev = obe_defer_host_sync(1);
+    int rc = 0;
+    do {
+        // (the buffers may still be read by earlier work of the caller's stream: the previous resample's search and gather)
+        if ((rc = ev(hipEventRecord(side.entry, st)))) break;
+        if ((rc = ev(hipStreamWaitEvent(side.stream, side.entry, 0)))) break;
+        if ((rc = obe_pcg64_uniforms_classify(h_pcg_state4, n, n_raw - n, d_uniforms, d_zig_tables, d_zig_ws, zig_ws_bytes,
+                                              side.stream)))
+            break;
+        if ((rc = obe_ziggurat_finish(n_raw - n, n_normal, d_normals, h_i64, d_zig_ws, zig_ws_bytes, side.stream))) break;
+        if ((rc = ev(hipEventRecord(side.pre, side.stream)))) break;
+    } while (false);
+    obe_defer_host_sync(prev);
+    return rc;
+}
+
 // The device side of ParticlePDF.resample() up to the point where the host must factorise the covariance
 // (particlepdf.py:260-301), enqueued by ONE call: the caller's PCG64 stream continued on the device (the N
 // uniforms and the classification of the n_raw - N raw positions behind them, in one launch, straight from
@@ -794,9 +832,13 @@ int obe_resample_begin(const double* d_particles, int64_t ld_p, int32_t n_dims, 
                        double* d_uniforms, int64_t* d_idx, const void* d_zig_tables, double* d_normals,
                        void* d_zig_ws, int64_t zig_ws_bytes, double* d_moments, double* h_f64, int64_t* h_i64,
                        double* d_aos, void* d_ws, int64_t ws_bytes, void* stream) {
-    if (!d_particles || !d_weights || !h_pcg_state4 || !d_cdf || !d_uniforms || !d_idx || !d_zig_tables ||
+    if (!d_particles || !d_weights || !d_cdf || !d_uniforms || !d_idx || !d_zig_tables ||
         !d_normals || !d_zig_ws || !d_moments || !h_f64 || !h_i64 || n_particles <= 0)
         return bad_arg("obe_resample_begin: bad pointer/size");
+    // h_pcg_state4 == NULL: the uniforms and normals of THIS resample were enqueued ahead of it
+    // (obe_resample_randoms_enqueue on this stream, into these d_uniforms / d_normals / d_zig_ws / h_i64): nothing of
+    // the random chain is launched here, the caller's stream waits for the end of that chain instead
+    const bool randoms_ahead = h_pcg_state4 == nullptr;
     if (n_dims < 1 || n_dims > kFastDims) return bad_arg("obe_resample_begin: n_dims must be 1..16 (OBE_FAST_DIMS)");
     const int64_t n = n_particles, n_normal = n * n_dims;
     if (n_raw < n + n_normal + 4096) return bad_arg("obe_resample_begin: fewer raw values than the draws need");
@@ -818,8 +860,9 @@ int obe_resample_begin(const double* d_particles, int64_t ld_p, int32_t n_dims, 
     // 0.50 / 0.54); 524 288 x 10 (5.2 M normals) 1.518 / 1.494 ms.  OBE_RESAMPLE_STREAMS=2 forces it (tests).
     static const int streams_env = getenv("OBE_RESAMPLE_STREAMS") ? atoi(getenv("OBE_RESAMPLE_STREAMS")) : 0;
     SideStream side{};
-    const bool split = (streams_env == 2 || (streams_env != 1 && n_normal >= ((int64_t)1 << 21))) &&
+    const bool split = (randoms_ahead || streams_env == 2 || (streams_env != 1 && n_normal >= ((int64_t)1 << 21))) &&
                        side_stream_of(st, &side);
+    if (randoms_ahead && !split) return bad_arg("obe_resample_begin: randoms enqueued ahead need the library's side streams");
     void* rs = split ? static_cast<void*>(side.stream) : stream;
     const int64_t lo = have_first_moments ? 2 + 4 * (int64_t)n_dims : 0;
     auto ev = [](hipError_t e) { return e == hipSuccess ? 0 : fail(e, "obe_resample_begin: stream / event call"); };
@@ -853,13 +896,15 @@ int obe_resample_begin(const double* d_particles, int64_t ld_p, int32_t n_dims, 
             // search on the caller's stream: every launch costs the host 2-4 us, and with the cloud's chains first
             // the random chain used to start 20-45 us after the others.
             if ((rc = ev(hipEventRecord(side.entry, st)))) break;
-            if ((rc = ev(hipStreamWaitEvent(side.stream, side.entry, 0)))) break;
-            if ((rc = obe_pcg64_uniforms_classify(h_pcg_state4, n, n_raw - n, d_uniforms, d_zig_tables, d_zig_ws,
-                                                  zig_ws_bytes, rs)))
-                break;
-            if ((rc = ev(hipEventRecord(side.mid, side.stream)))) break;
-            if ((rc = obe_ziggurat_finish(n_raw - n, n_normal, d_normals, h_i64, d_zig_ws, zig_ws_bytes, rs))) break;
-            if ((rc = ev(hipEventRecord(side.done, side.stream)))) break;
+            if (!randoms_ahead) {
+                if ((rc = ev(hipStreamWaitEvent(side.stream, side.entry, 0)))) break;
+                if ((rc = obe_pcg64_uniforms_classify(h_pcg_state4, n, n_raw - n, d_uniforms, d_zig_tables, d_zig_ws,
+                                                      zig_ws_bytes, rs)))
+                    break;
+                if ((rc = ev(hipEventRecord(side.mid, side.stream)))) break;
+                if ((rc = obe_ziggurat_finish(n_raw - n, n_normal, d_normals, h_i64, d_zig_ws, zig_ws_bytes, rs))) break;
+                if ((rc = ev(hipEventRecord(side.done, side.stream)))) break;
+            }
             if ((rc = ev(hipStreamWaitEvent(side.stream2, side.entry, 0)))) break;
             arm_host_words(h_f64 + 1 + lo, obe_moments_len(n_dims) - lo);
             bool host_written = false;
@@ -874,9 +919,9 @@ int obe_resample_begin(const double* d_particles, int64_t ld_p, int32_t n_dims, 
             } else {
                 h_f64[0] = 1.0;
             }
-            if ((rc = ev(hipStreamWaitEvent(st, side.mid, 0)))) break;
+            if ((rc = ev(hipStreamWaitEvent(st, randoms_ahead ? side.pre : side.mid, 0)))) break;
             if ((rc = obe_cdf_search(d_cdf, n, d_uniforms, n, d_idx, d_ws, ws_bytes, stream))) break;
-            if ((rc = ev(hipStreamWaitEvent(st, side.done, 0)))) break;
+            if (!randoms_ahead && (rc = ev(hipStreamWaitEvent(st, side.done, 0)))) break;
             if ((rc = ev(hipStreamWaitEvent(st, side.done2, 0)))) break;
             break;
         }
@@ -898,6 +943,12 @@ int obe_resample_begin(const double* d_particles, int64_t ld_p, int32_t n_dims, 
         };
         if (split && (rc = cdf_and_covariance())) break;
         // the buffers of the random chain may still be read by earlier work of the caller's stream
+        if (randoms_ahead) {             // (always split: the chain that ran ahead ends in side.pre)
+            if ((rc = ev(hipStreamWaitEvent(st, side.pre, 0)))) break;
+            if ((rc = obe_cdf_search(d_cdf, n, d_uniforms, n, d_idx, d_ws, ws_bytes, stream))) break;
+            if (copy_here && (rc = make_aos(st))) break;
+            break;
+        }
         if (split && (rc = ev(hipStreamWaitEvent(side.stream, side.entry, 0)))) break;
         // uniforms + the classification of every raw position behind them, straight from the generator state
         if ((rc = obe_pcg64_uniforms_classify(h_pcg_state4, n, n_raw - n, d_uniforms, d_zig_tables, d_zig_ws,

@@ -55,6 +55,12 @@ _OVERRIDDEN = {}
 _SPECULATIVE_DEFAULT = {"0": False, "1": True}.get(os.environ.get("OBE_SPECULATIVE_SWEEP", "auto"), "auto")
 
 
+# default of tuning_parameters['randoms_ahead'] (A/B measurements: OBE_RANDOMS_AHEAD=0 / 1 / auto).  OFF: measured on
+# one box (profiles/r06_randoms_ahead.txt), one rank's c5 cycle 1.270-1.288 ms without, 1.302-1.309 ms with 'auto' —
+# a cycle that does not resample pays ~50 us (the chain runs into the sweep, which has no idle capacity to give), a
+# cycle that does gains ~5 us (with the random chain out of the way the host's SVD of the covariance bounds the gather).
+_RANDOMS_AHEAD_DEFAULT = {"0": False, "1": True, "auto": "auto"}.get(os.environ.get("OBE_RANDOMS_AHEAD", "0"), False)
+
 _SCALARS = (float, int, np.floating, np.integer)
 
 
@@ -471,6 +477,10 @@ class OptBayesExpt(ParticlePDF):
                 # (the calls below arm the page-locked block that an un-awaited constraint mask — two updates in
                 # a row on a noise-parameter object, no sweep in between — may still be delivering into)
                 self._await_host_moments()
+                if self._randoms_ahead_wanted():
+                    # the random numbers this update's resample would take, enqueued beside the update itself
+                    # (kept for the next resample if this update does not resample: particlepdf.py, "randoms ahead")
+                    self._randoms_ahead_enqueue()
                 if self.utility_method == "variance_full" and not self._sweeps.unavailable \
                         and self.tuning_parameters.get("speculative_sweep", _SPECULATIVE_DEFAULT) is not False:
                     self._update_then_speculate(args)       # (enqueued; what goes behind it is decided while it runs)
@@ -549,6 +559,19 @@ class OptBayesExpt(ParticlePDF):
                 and self._noise_token() is not None
                 and self._sweeps.form is Form.FAST
                 and self.N_DRAWS <= self._ws_draws)
+
+    def _randoms_ahead_wanted(self):
+        """tuning_parameters['randoms_ahead']: False (default: measured, no gain — see _RANDOMS_AHEAD_DEFAULT), True,
+        or 'auto': only where nothing else draws from self.rng between two resamples — the full sweep chosen by
+        opt_setting() (the reference-semantics sweep takes N_DRAWS uniforms per cycle, good_setting() one) — and
+        once the experiment has shown that it resamples at all."""
+        mode = self.tuning_parameters.get("randoms_ahead", _RANDOMS_AHEAD_DEFAULT)
+        if mode is False or not self.tuning_parameters["auto_resample"]:
+            return False
+        if mode is True:
+            return True
+        return (self.utility_method == "variance_full" and self._sweeps.resample_rate >= 0.1
+                and getattr(self.get_setting, "__func__", None) is OptBayesExpt.opt_setting)
 
     def sweep_state(self):
         """A snapshot of what steers this object's sweeps (diagnostic): the kernel form in use, the shift

@@ -21,6 +21,14 @@ _P = ctypes.c_void_p
 
 SQRT_EPS = float(np.sqrt(np.finfo(np.float64).eps))   # numpy's tolerance on sum(p) in choice()
 
+#: buffer sets of random chains enqueued ahead (ParticlePDF._randoms_ahead_enqueue) whose kernels may still run
+_AHEAD_IN_FLIGHT = []
+
+
+def _still_armed(pin_i):
+    words = _lib.audit.raw(pin_i).view(np.int64)           # (a poll of armed words, on purpose)
+    return bool(words[0] == _lib.HOST_SENTINEL or words[1] == _lib.HOST_SENTINEL)
+
 
 def _ptr(t):
     return _P(t.data_ptr())
@@ -591,6 +599,63 @@ class ParticlePDF:
             flip=0)
         return b
 
+    # ---- the random numbers of the NEXT resample, enqueued ahead of it (round 6) ----------------------------------
+    # resample() takes N uniforms and N x D normals from self.rng (particlepdf.py:272, 296-301): numbers that depend
+    # on the generator state and the cloud's shape alone, and whose chain (92 us at 524 288 x 10) is what the gather
+    # of a pipelined resample ends up waiting for.  pdf_update() therefore enqueues that chain when it STARTS — beside
+    # the update's own latency-bound kernels and the host round trips — and a resample that finds the generator
+    # exactly where the chain was started from uses its output; the numbers are kept through cycles that do not
+    # resample, and thrown away (and the habit dropped after two misses) as soon as anything else has moved the
+    # generator.  The same kernels on the same state: the same bits, the same generator bookkeeping.
+    # tuning_parameters['randoms_ahead']: False (the default — built, bit-identical, measured and NOT a gain at the
+    # BASELINE sizes: profiles/r06_randoms_ahead.txt), True, 'auto' (where nothing else draws from self.rng between
+    # resamples: OptBayesExpt with the full sweep and opt_setting).
+    def _randoms_ahead_enqueue(self):
+        """Enqueue the random chain of the next resample from the generator's PRESENT state, unless one is already
+        waiting for exactly that state.  Never raises: any refusal switches the feature off for this object."""
+        n, d = self.n_particles, self.n_dims
+        if d > _lib.OBE_FAST_DIMS or not self.tuning_parameters.get("pipelined_resample", True) \
+                or self.tuning_parameters.get("resample_method", "multinomial") != "multinomial" \
+                or self.__dict__.get("_ahead_misses", 0) >= 2:
+            return False
+        state = self._device_rng_state(n, n * d)
+        if state is None:
+            return False
+        _, h_state = state
+        pre = self.__dict__.get("_ahead")
+        if pre is not None:
+            if pre["shape"] == (n, d) and np.array_equal(pre["h_state"], h_state):
+                return True                              # still good: the generator has not moved
+            self._randoms_ahead_drop(miss=True)
+            if self._ahead_misses >= 2:
+                return False
+        b = self._resample_buffers(n, d)
+        try:
+            self._lib.call("obe_resample_randoms_enqueue", _lib.host_ptr(h_state), n, d, b["n_raw"], _ptr(b["uni"]),
+                           _ptr(b["tables"]), _ptr(b["normals"]), _ptr(b["zig_ws"]), b["zig_ws"].numel() * 8, b["p_i"],
+                           self._stream())
+        except _lib.ObeHipError as exc:
+            if not exc.refused_before_launch:
+                raise
+            self._ahead_misses = 2                       # (no side streams: never again for this object)
+            return False
+        self._ahead = dict(shape=(n, d), h_state=h_state.copy(), bufs=b, stream=self._stream())
+        # (the chain runs on a stream torch knows nothing about: its buffers must not go back to the allocator — with
+        # this object, say — before it has ended; the module keeps them until their result words have arrived)
+        _AHEAD_IN_FLIGHT[:] = [e for e in _AHEAD_IN_FLIGHT if _still_armed(e["pin_i"])] + [b]
+        return True
+
+    def _randoms_ahead_drop(self, miss=False):
+        """Forget the chain enqueued ahead (the generator moved, the cloud changed shape): its kernels are waited
+        for — they deliver {consumed, found} when they end — before anything arms those words or reuses the buffers."""
+        pre = self.__dict__.get("_ahead")
+        if pre is None:
+            return
+        self._ahead = None
+        self._lib.call("obe_host_words_wait", pre["bufs"]["p_i"], 2, pre["stream"])
+        if miss:
+            self._ahead_misses = self.__dict__.get("_ahead_misses", 0) + 1
+
     def _resample_pipelined(self, state=None):
         """resample() with the caller's generator continued on the device.  ONE library call
         (obe_resample_begin) enqueues CDF, uniforms, search, covariance and the ziggurat normals back to
@@ -610,6 +675,15 @@ class ParticlePDF:
             self._cdf_dev = torch.empty(n, dtype=torch.float64, device=self._device)
             self._cdf_key = None
         b = self._resample_buffers(n, d)
+        # the chain enqueued ahead, if it started from exactly this generator state (and wrote these buffers)
+        pre = self.__dict__.get("_ahead")
+        ahead = pre is not None and pre["bufs"] is b and pre["shape"] == (n, d) and np.array_equal(pre["h_state"], h_state) \
+            and pre["stream"].value == self._stream().value
+        if pre is not None and not ahead:
+            self._randoms_ahead_drop(miss=True)
+        elif ahead:
+            self._ahead, self._ahead_misses = None, 0
+            self._ahead_hits = self.__dict__.get("_ahead_hits", 0) + 1        # (diagnostic)
         mlen = self._lib.moments_len(d)
         b["flip"] ^= 1
         idx = b["idx"][b["flip"]]
@@ -618,7 +692,7 @@ class ParticlePDF:
             and self._mom_dev_key is not None and self._mom_dev_key[:2] == mkey
         self._await_host_moments()
         stream = self._stream()
-        self._lib.call("obe_resample_begin", _ptr(p), p.shape[1], d, n, _ptr(w), _lib.host_ptr(h_state),
+        self._lib.call("obe_resample_begin", _ptr(p), p.shape[1], d, n, _ptr(w), None if ahead else _lib.host_ptr(h_state),
                        1 if strict else 0, 1 if self._cdf_key == key else 0, 1 if have_first else 0,
                        b["n_raw"], _ptr(self._cdf_dev), _ptr(b["uni"]), _ptr(idx), _ptr(b["tables"]),
                        _ptr(b["normals"]), _ptr(b["zig_ws"]), b["zig_ws"].numel() * 8, _ptr(self._moments_dev),

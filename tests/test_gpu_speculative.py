@@ -1,6 +1,8 @@
 """The sweep that pdf_update() enqueues behind its update without waiting (obe_base.py: _speculation_wanted)
 changes WHEN the kernels run, never what they compute: every cycle of a run with it must equal, bit for bit,
 the cycle of a run without it — whatever the caller does between the update and the next sweep (GPU)."""
+import warnings
+
 import numpy as np
 import pytest
 
@@ -443,3 +445,69 @@ print('SLOTS OK')
     env = dict(os.environ, OBE_CONTROL_SLOTS="2")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "SLOTS OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_randoms_enqueued_ahead_are_the_resamples_own(hip):
+    """Round 6: pdf_update() enqueues the uniforms and normals of the NEXT resample beside the update
+    (tuning_parameters['randoms_ahead']; obe_resample_randoms_enqueue) and a resample that finds the generator where
+    that chain started from uses them.  Same kernels on the same generator state: two objects, one with the chain
+    enqueued ahead from the first update on, one never, through 40 cycles of a resample-heavy experiment — chosen
+    settings, resample decisions, resample indices, particles, weights and the generator state BIT FOR BIT in every
+    cycle; numbers kept through cycles that do not resample; a generator moved by the caller in between is a miss
+    (thrown away, regenerated), two misses in a row end the habit."""
+    import bench
+    import optbayesexpt_amd as obe
+    settings, prior, cons, true, sigma = bench.make_workload("c2")
+    sv = (np.ascontiguousarray(settings[0][::16]),)
+
+    def build(ahead):
+        o = obe.OptBayesExpt(obe.models.lorentzian(), sv, prior.copy(), cons, scale=False, utility_method="variance_full",
+                             default_noise_std=sigma)
+        o.tuning_parameters["randoms_ahead"] = ahead
+        o.tuning_parameters["resample_threshold"] = 0.9        # resample in most cycles, not in all
+        o.rng = np.random.default_rng(2026)
+        return o
+
+    a, b = build(True), build(False)
+    sim = np.random.default_rng(7)
+    resamples, kept = 0, 0
+    for cyc in range(40):
+        xa, xb = a.opt_setting(), b.opt_setting()
+        assert a.last_setting_index == b.last_setting_index, cyc
+        y = float(a.model_function(xa, true, cons)) + sigma * sim.standard_normal()
+        if cyc in (25, 26, 31):
+            for o in (a, b):
+                o.rng.random()                       # the caller draws from the generator between two cycles
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            a.pdf_update((xa, y, sigma))
+            b.pdf_update((xb, y, sigma))
+        assert a.just_resampled == b.just_resampled, cyc
+        resamples += a.just_resampled
+        kept += (not a.just_resampled) and a.__dict__.get("_ahead") is not None
+        if a.just_resampled:
+            np.testing.assert_array_equal(a.last_resample_indices_device.cpu().numpy(),
+                                          b.last_resample_indices_device.cpu().numpy(), err_msg=f"cycle {cyc}")
+            np.testing.assert_array_equal(np.array(a.particles), np.array(b.particles), err_msg=f"cycle {cyc}")
+        np.testing.assert_array_equal(np.array(a.particle_weights), np.array(b.particle_weights), err_msg=f"cycle {cyc}")
+        assert a.rng.bit_generator.state == b.rng.bit_generator.state, cyc
+    hits = a.__dict__.get("_ahead_hits", 0)
+    print(f"randoms ahead: {resamples} resamples in 40 cycles, {hits} of them took the numbers enqueued ahead, "
+          f"{kept} cycles kept them for later, misses in a row at the end: {a.__dict__.get('_ahead_misses', 0)}")
+    assert resamples >= 10 and hits >= resamples - 6 and kept >= 1
+    assert b.__dict__.get("_ahead_hits", 0) == 0 and b.__dict__.get("_ahead") is None
+    # 'auto' (the default): only once the experiment has resampled, and only for the full sweep + opt_setting
+    c = build("auto")
+    assert not c._randoms_ahead_wanted()
+    c._sweeps.resample_rate = 0.3
+    assert c._randoms_ahead_wanted()
+    d = obe.OptBayesExpt(obe.models.lorentzian(), sv, prior.copy(), cons, scale=False, default_noise_std=sigma)
+    d.tuning_parameters["randoms_ahead"] = "auto"
+    d._sweeps.resample_rate = 0.3
+    assert not d._randoms_ahead_wanted()             # reference semantics: every sweep draws from the generator
+    # ... and the default is OFF (measured: no gain at the BASELINE sizes, profiles/r06_randoms_ahead.txt)
+    e = obe.OptBayesExpt(obe.models.lorentzian(), sv, prior.copy(), cons, scale=False, utility_method="variance_full",
+                         default_noise_std=sigma)
+    e._sweeps.resample_rate = 0.3
+    import os
+    assert not e._randoms_ahead_wanted() or os.environ.get("OBE_RANDOMS_AHEAD", "0") != "0"
