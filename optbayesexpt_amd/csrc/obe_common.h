@@ -208,9 +208,13 @@ __device__ __forceinline__ double block_sum_all(double v, double* red) {
 // (four elements per thread and trip, their loads issued together and added in the order i, i + nt, ... of the
 // one-at-a-time loop — the same bits: the 768 partial sums of the update's first pass used to be three dependent
 // round trips at the start of EVERY workgroup of its second pass)
-__device__ __forceinline__ double block_sum_array(const double* a, int n, double* red) {
+// (nt_part: the threads that take part, the first nt_part of the workgroup — a workgroup of more threads than kBlock
+// that must reproduce the sum a kBlock-thread workgroup forms, e.g. the total the unfused normalisation divides by:
+// the other threads contribute +0.0 behind everybody else's partial sums, which changes nothing)
+__device__ __forceinline__ double block_sum_array(const double* a, int n, double* red, int nt_part = 0) {
     double v = 0.0;
-    const int nt = blockDim.x;
+    const int nt = nt_part > 0 ? nt_part : (int)blockDim.x;
+    const bool part = (int)threadIdx.x < nt;
     for (int base = 0; base < n; base += 4 * nt) {
         double x[4];
 #pragma unroll
@@ -222,7 +226,7 @@ __device__ __forceinline__ double block_sum_array(const double* a, int n, double
         for (int r = 0; r < 4; ++r) {
             const int i = base + r * nt + (int)threadIdx.x;
             const double t = v + x[r];
-            v = i < n ? t : v;
+            v = i < n && part ? t : v;
         }
     }
     return block_sum_all(v, red);

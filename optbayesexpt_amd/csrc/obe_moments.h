@@ -18,6 +18,15 @@ namespace obe {
 // (12-15 us at D = 10, 524 288 particles either way), but every workgroup ends with a block
 // reduction of up to 136 values and leaves a row of partials for the single-workgroup fold.
 constexpr int kMomBlocks = OBE_MOM_BLOCKS;
+// Threads per workgroup of the passes that accumulate FIRST moments (moments_pass1, the update's normalisation pass, the
+// constraint mask's second half — one grid and one block shape for all three, so that whichever fills the K3 block
+// leaves the same bits).  The grid is one workgroup per CU (the fold of the rows is what the last one pays for), so the
+// waves in flight per SIMD are set by the block size: see profiles/r06_update_moments.txt for the measurement.
+#ifndef OBE_MOM_THREADS
+#define OBE_MOM_THREADS 256
+#endif
+constexpr int kMomThreads = OBE_MOM_THREADS;
+static_assert(kMomThreads % kWave == 0 && kMomThreads >= kBlock && kMomThreads <= 1024, "whole wavefronts, 256..1024 threads");
 #ifndef OBE_MOM_UNROLL
 #define OBE_MOM_UNROLL 1
 #endif
@@ -79,14 +88,14 @@ __device__ __forceinline__ void reduce_value_groups(const double (&v)[NV], doubl
 
 // PUBLISHED: the row is read by another workgroup of the same launch (the last one to arrive folds,
 // obe_common.h: arrive_last) and is therefore stored write-through.
-template <int NV, bool PUBLISHED = false>
+template <int NV, bool PUBLISHED = false, int NT = kBlock>
 __device__ __forceinline__ void store_block_partials(double (&v)[NV], double* __restrict__ partials) {
-    constexpr int NW = kBlock / kWave;
+    constexpr int NW = NT / kWave;
     __shared__ double red[NW][NV];
     const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
     reduce_value_groups<NV, 0>(v, red[wid], lane);
     __syncthreads();
-    for (int k = threadIdx.x; k < NV; k += kBlock) {
+    for (int k = threadIdx.x; k < NV; k += NT) {
         double s = 0.0;
 #pragma unroll
         for (int i = 0; i < NW; ++i) s += red[i][k];
@@ -264,8 +273,12 @@ inline int first_moment_blocks(int64_t n, int d) {
         const int v = e ? atoi(e) : OBE_FIRST_MOM_PER_CU_DEFAULT;
         return v >= 1 && v <= 3 ? v : 0;
     }();
-    if (per_cu == 0) return moment_blocks(n, d);
-    return static_cast<int>(std::min<int64_t>((int64_t)per_cu * kMomBlocks, (n + kBlock - 1) / kBlock));
+    if (per_cu == 0) {
+        if (kMomThreads == kBlock) return moment_blocks(n, d);
+        const int nb = moment_blocks(n, d);           // (the same count of workgroups, of more threads each)
+        return static_cast<int>(std::min<int64_t>(nb, (n + kMomThreads - 1) / kMomThreads));
+    }
+    return static_cast<int>(std::min<int64_t>((int64_t)per_cu * kMomBlocks, (n + kMomThreads - 1) / kMomThreads));
 }
 
 }  // namespace obe

@@ -20,7 +20,7 @@ namespace obe {
 // partials more slowly than the 16-wave fold kernel, and every workgroup drains its write-through stores
 // before it can take its ticket.  The update's normalisation pass, whose fold is 8-22 values, keeps it.)
 template <int D>
-__global__ __launch_bounds__(kBlock) void moments_pass1(const double* __restrict__ x, int64_t ld, int64_t n,
+__global__ __launch_bounds__(kMomThreads) void moments_pass1(const double* __restrict__ x, int64_t ld, int64_t n,
                                                         const double* __restrict__ w,
                                                         double* __restrict__ partials) {
     double v[2 + 2 * D];
@@ -29,8 +29,8 @@ __global__ __launch_bounds__(kBlock) void moments_pass1(const double* __restrict
     // OBE_MOM_UNROLL particles per trip (a compile-time tuning aid, 1 in the product build: with 256
     // workgroups of waves already keeping (D + 1) loads each in flight, two per trip measured no
     // faster); any value adds in the same order per accumulator as one at a time
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += OBE_MOM_UNROLL * stride) {
+    const int64_t stride = (int64_t)gridDim.x * kMomThreads;
+    for (int64_t p = (int64_t)blockIdx.x * kMomThreads + threadIdx.x; p < n; p += OBE_MOM_UNROLL * stride) {
         double wp[OBE_MOM_UNROLL], xi[OBE_MOM_UNROLL][D];
 #pragma unroll
         for (int u = 0; u < OBE_MOM_UNROLL; ++u) {
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(kBlock) void moments_pass1(const double* __restrict
             if (p + u * stride < n) accumulate_first_moments<D>(v, wp[u], xi[u]);
         }
     }
-    store_block_partials<2 + 2 * D>(v, partials);
+    store_block_partials<2 + 2 * D, false, kMomThreads>(v, partials);
 }
 
 // values: upper triangle (i <= j) of sum (x_i - mu_i) * ((x_j - mu_j) * w), row-major
@@ -255,7 +255,7 @@ static int launch_moments(const double* x, int64_t ld, int64_t n, const double* 
     const int nb = moment_blocks(n, D);
     if (want_cov != 2) {            // (2: `out` already holds the first moments of these weights)
         const int nb1 = first_moment_blocks(n, D);
-        moments_pass1<D><<<nb1, kBlock, 0, st>>>(x, ld, n, w, partials);
+        moments_pass1<D><<<nb1, kMomThreads, 0, st>>>(x, ld, n, w, partials);
         OBE_CHECK_LAUNCH("moments_pass1");
         fold_derive_pass1<<<1, kFoldThreads, 0, st>>>(partials, nb1, D, mo);
         OBE_CHECK_LAUNCH("fold_derive_pass1");

@@ -120,15 +120,15 @@ struct UpdateFold {
 // partial sums (v[2 + 2 D] = sum w'^2 rides along), the one that arrives last folds all rows in a fixed order
 // and delivers {sum t, sum w'^2}, the K3 block and (enqueue form) the resample decision.  One definition for
 // the two-launch and the one-launch update: the same bits.
-template <int D>
+template <int D, int NT = kBlock>
 __device__ __forceinline__ void publish_and_fold_update(double (&v)[3 + 2 * D], double total, double* partials_mom,
                                                         const UpdateFold& fold) {
     constexpr int NV = 3 + 2 * D;
-    store_block_partials<NV, true>(v, partials_mom);
+    store_block_partials<NV, true, NT>(v, partials_mom);
     __shared__ int last;
     if (!arrive_last<false>(fold.counter, &last)) return;
     __shared__ double raw[kMaxMomentValues + 1];
-    fold_values_block<kBlock, true, (NV + kBlock / kWave - 1) / (kBlock / kWave)>(partials_mom, gridDim.x, NV, raw);
+    fold_values_block<NT, true, (NV + NT / kWave - 1) / (NT / kWave)>(partials_mom, gridDim.x, NV, raw);
     // delivery by ONE wave: K3 block to the device copy and to the host, one system-scope fence, then the
     // word the host watches (wait_host_word) — [0] sum t, [1] sum w'^2, [2..) K3 block
     if (threadIdx.x < kWave) {

@@ -59,13 +59,13 @@ __global__ __launch_bounds__(kBlock) void normalize_kernel(const double* __restr
 }
 
 template <int D, bool FOLD>
-__global__ __launch_bounds__(kBlock) void normalize_moments_kernel(const double* __restrict__ partials_in,
+__global__ __launch_bounds__(kMomThreads) void normalize_moments_kernel(const double* __restrict__ partials_in,
                                                                    int n_partials, const double* __restrict__ x,
                                                                    int64_t ld, int64_t n, double* __restrict__ weights,
                                                                    double* partials_w2, double* partials_mom,
                                                                    UpdateFold fold) {
-    __shared__ double red[kBlock / kWave];
-    const double total = block_sum_array(partials_in, n_partials, red);
+    __shared__ double red[kMomThreads / kWave];
+    const double total = block_sum_array(partials_in, n_partials, red, kBlock);      // (normalize_kernel's total, bit for bit)
     // FOLD: sum nan_to_num(w'^2) travels as one more column of the moment rows (one round of loads in the fold)
     constexpr int NV = 2 + 2 * D + (FOLD ? 1 : 0);
     double v[NV];
@@ -76,8 +76,8 @@ __global__ __launch_bounds__(kBlock) void normalize_moments_kernel(const double*
     // grid otherwise has D + 1 loads in flight and ~50 dependent FP64 instructions between two round trips to
     // HBM); they are accumulated in the order p, p + stride, ... of the one-at-a-time loop: the same bits.
     constexpr int U = OBE_NORM_UNROLL;
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += U * stride) {
+    const int64_t stride = (int64_t)gridDim.x * kMomThreads;
+    for (int64_t p = (int64_t)blockIdx.x * kMomThreads + threadIdx.x; p < n; p += U * stride) {
         double xi[U][D], t[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -101,10 +101,10 @@ __global__ __launch_bounds__(kBlock) void normalize_moments_kernel(const double*
     if constexpr (!FOLD) {
         const double s = block_sum(acc, red);
         if (threadIdx.x == 0) partials_w2[blockIdx.x] = s;
-        store_block_partials<NV>(v, partials_mom);
+        store_block_partials<NV, false, kMomThreads>(v, partials_mom);
     } else {
         v[NV - 1] = acc;
-        publish_and_fold_update<D>(reinterpret_cast<double(&)[3 + 2 * D]>(v), total, partials_mom, fold);
+        publish_and_fold_update<D, kMomThreads>(reinterpret_cast<double(&)[3 + 2 * D]>(v), total, partials_mom, fold);
     }
 }
 
@@ -287,22 +287,22 @@ struct MaskFold {
 };
 
 template <int D>
-__global__ __launch_bounds__(kBlock) void mask_renorm_moments_kernel(const double* __restrict__ psum,
+__global__ __launch_bounds__(kMomThreads) void mask_renorm_moments_kernel(const double* __restrict__ psum,
                                                                      const double* __restrict__ pcount, int nb_in,
                                                                      const double* __restrict__ x, int64_t ld,
                                                                      int64_t n, double* __restrict__ weights,
                                                                      double* partials_mom, MaskFold mf) {
-    __shared__ double red[kBlock / kWave];
-    const double total = block_sum_array(psum, nb_in, red);
+    __shared__ double red[kMomThreads / kWave];
+    const double total = block_sum_array(psum, nb_in, red, kBlock);
     __syncthreads();
-    const double count = block_sum_array(pcount, nb_in, red);
+    const double count = block_sum_array(pcount, nb_in, red, kBlock);
     const bool renorm = count != 0.0;
     double v[2 + 2 * D];
 #pragma unroll
     for (int k = 0; k < 2 + 2 * D; ++k) v[k] = 0.0;
     constexpr int U = OBE_NORM_UNROLL;       // (as in normalize_moments_kernel)
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += U * stride) {
+    const int64_t stride = (int64_t)gridDim.x * kMomThreads;
+    for (int64_t p = (int64_t)blockIdx.x * kMomThreads + threadIdx.x; p < n; p += U * stride) {
         double xi[U][D], t[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -325,11 +325,11 @@ __global__ __launch_bounds__(kBlock) void mask_renorm_moments_kernel(const doubl
             }
         }
     }
-    store_block_partials<2 + 2 * D, true>(v, partials_mom);
+    store_block_partials<2 + 2 * D, true, kMomThreads>(v, partials_mom);
     __shared__ int last;
     if (!arrive_last<false>(mf.counter, &last)) return;
     __shared__ double raw[kMaxMomentValues];
-    fold_values_block<kBlock, true, (2 + 2 * D + kBlock / kWave - 1) / (kBlock / kWave)>(partials_mom, gridDim.x, 2 + 2 * D, raw);
+    fold_values_block<kMomThreads, true, (2 + 2 * D + kMomThreads / kWave - 1) / (kMomThreads / kWave)>(partials_mom, gridDim.x, 2 + 2 * D, raw);
     if (threadIdx.x < kWave) {
         derive_first_moments(raw, D, mf.mom_out, mf.host_mom);
         if (mf.host_changed) {
@@ -568,10 +568,10 @@ int launch_normalize_moments(int d, const UpdateWs& w, int nb, int nm, const dou
 #define OBE_UPD_MOM_CASE(DD)                                                                                           \
     case DD:                                                                                                           \
         if (counter)                                                                                                   \
-            normalize_moments_kernel<DD, true><<<nm, kBlock, 0, st>>>(w.pa, nb, d_particles, ld_p, n_particles,       \
+            normalize_moments_kernel<DD, true><<<nm, kMomThreads, 0, st>>>(w.pa, nb, d_particles, ld_p, n_particles,       \
                                                                       d_weights, w.pb, w.mom, fold);                   \
         else                                                                                                           \
-            normalize_moments_kernel<DD, false><<<nm, kBlock, 0, st>>>(w.pa, nb, d_particles, ld_p, n_particles,      \
+            normalize_moments_kernel<DD, false><<<nm, kMomThreads, 0, st>>>(w.pa, nb, d_particles, ld_p, n_particles,      \
                                                                        d_weights, w.pb, w.mom, fold);                  \
         break;
     switch (d) {
@@ -815,7 +815,7 @@ static int mask_renorm_moments(const double* d_particles, int64_t ld_p, int32_t 
     const int nm = first_moment_blocks(n_particles, n_dims);
 #define OBE_MASK_MOM_CASE(DD)                                                                                       \
     case DD:                                                                                                        \
-        mask_renorm_moments_kernel<DD><<<nm, kBlock, 0, st>>>(psum, pcount, nb, d_particles, ld_p, n_particles,    \
+        mask_renorm_moments_kernel<DD><<<nm, kMomThreads, 0, st>>>(psum, pcount, nb, d_particles, ld_p, n_particles,    \
                                                               d_weights, partials_mom, mf);                         \
         break;
     switch (n_dims) {
