@@ -594,3 +594,40 @@ def test_released_landing_zones_wait_in_limbo(monkeypatch):
     keep = _lib.pinned_array(2, device=5)
     assert len(_lib._LIMBO) == 0 and keep.shape == (2,)
     assert synced == [3, 5]                    # the devices of the parked blocks, each once — and no other
+
+
+def test_bench_finds_the_cores_of_a_gpus_numa_node_from_sysfs(tmp_path, monkeypatch):
+    """bench.py pins every rank of an N > 1 run to the cores of its GPU's NUMA node before torch is imported; the
+    lookup is sysfs only (KFD topology order = HIP device order -> DRM render node -> local_cpulist).  A fake tree:
+    two CPU nodes, three GPUs on two NUMA nodes; visibility lists remap the device index; anything missing -> None."""
+    import bench
+    sysfs = tmp_path / "sys"
+    nodes = sysfs / "class/kfd/kfd/topology/nodes"
+    layout = {0: (0, None), 1: (0, None), 2: (256, 128), 3: (256, 130), 4: (256, 129)}     # node -> (simd_count, render minor)
+    for k, (simd, minor) in layout.items():
+        (nodes / str(k)).mkdir(parents=True)
+        text = f"cpu_cores_count {0 if simd else 64}\nsimd_count {simd}\n"
+        if minor is not None:
+            text += f"drm_render_minor {minor}\nlocation_id 1234\n"
+        (nodes / str(k) / "properties").write_text(text)
+    for minor, (cpus, numa) in {128: ("0-31,128-159", 0), 130: ("32-63,160-191", 1), 129: ("0-31,128-159", 0)}.items():
+        dev = sysfs / f"class/drm/renderD{minor}/device"
+        dev.mkdir(parents=True)
+        (dev / "local_cpulist").write_text(cpus + "\n")
+        (dev / "numa_node").write_text(f"{numa}\n")
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    cpus, numa = bench.gpu_local_cpus(0, sysfs=str(sysfs))
+    assert numa == 0 and cpus == list(range(0, 32)) + list(range(128, 160))
+    assert bench.gpu_local_cpus(1, sysfs=str(sysfs))[1] == 1                       # KFD order, not minor order
+    assert bench.gpu_local_cpus(2, sysfs=str(sysfs))[1] == 0
+    assert bench.gpu_local_cpus(3, sysfs=str(sysfs)) is None                       # no such device
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1,2")
+    assert bench.gpu_local_cpus(0, sysfs=str(sysfs))[1] == 1                       # device 0 of this process is GPU 1
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "2,1,0")
+    assert bench.gpu_local_cpus(0, sysfs=str(sysfs))[1] == 1                       # ROCR first ([2,1,0]), then HIP picks [1,2] of it -> GPU 1
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "GPU-abcdef")
+    assert bench.gpu_local_cpus(0, sysfs=str(sysfs)) is None                       # UUID lists: nothing is pinned
+    assert bench.gpu_local_cpus(0, sysfs=str(tmp_path / "nowhere")) is None
+    assert bench.format_cpulist(bench.parse_cpulist("0-3,8,10-11\n")) == "0-3,8,10-11"
+    assert bench.parse_cpulist("") == []
