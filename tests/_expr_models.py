@@ -22,8 +22,13 @@ def expression_models():
     wide = models.from_expression(
         tuple(f"p{4 * c} + p{4 * c + 1}*x + p{4 * c + 2}*x*x + p{4 * c + 3}*x*x*x" for c in range(5)),
         settings=("x",), parameters=tuple(f"p{i}" for i in range(20)), name="wide_20x5")
+    # the round-6 limits at once: 8 setting dimensions, 8 channels, 24 named parameters (+ 8 noise rows in the test = 32)
+    limits8 = models.from_expression(
+        tuple(f"p{3 * c} + p{3 * c + 1}*s{c} + p{3 * c + 2}*s{(c + 1) % 8}*s{(c + 3) % 8}" for c in range(8)),
+        settings=tuple(f"s{i}" for i in range(8)), parameters=tuple(f"p{i}" for i in range(24)), name="limits_8x32x8")
     return {
         "limits": big,
+        "limits8": limits8,
         "wide": wide,
         # translated from the source of plain reference-style functions (models.from_function)
         "fn_lorentzian": models.from_function(_fn_models.lorentzian),

@@ -1626,6 +1626,64 @@ def test_wide_model_20_parameters_5_channels_matches_the_oracle(obe):
         assert a.rng.bit_generator.state == b.rng.bit_generator.state
 
 
+def test_device_limits_8_settings_32_parameters_8_channels(obe):
+    """OBE_MAX_SETDIMS = 8, OBE_MAX_DIMS = 32, OBE_MAX_CHANNELS = 8 together (round 6): a compiled model of 8 setting
+    dimensions (3^8 = 6561 settings) and 8 channels over a cloud of 32 rows — 24 model parameters + one noise
+    parameter per channel (the noise rows 24..31 travel to the sweep in the 40 bits of OBE_NOISE_FROM_MOMENTS) —
+    through reference-semantics and full sweeps, 8-channel updates with per-particle sigmas, a resample of the
+    32-row cloud (tiled moments, run-time-loop gather) and the constraint mask, against the oracle class."""
+    import _expr_models
+    from optbayesexpt_amd import _lib
+    model = _expr_models.expression_models()["limits8"]
+    assert (model.n_setdims, model.n_channels, model.n_read) == (_lib.OBE_MAX_SETDIMS, _lib.OBE_MAX_CHANNELS, 24)
+
+    def numpy_model(sets, pars, cons):
+        return np.array([pars[3 * c] + pars[3 * c + 1] * sets[c] + pars[3 * c + 2] * sets[(c + 1) % 8] * sets[(c + 3) % 8]
+                         for c in range(8)])
+
+    g = np.random.default_rng(808)
+    n = 5000
+    prior = np.vstack([g.normal(0.5, 1.0, (24, n)), g.exponential(0.8, (8, n)) + 0.02])
+    sv = tuple(np.linspace(-1.0 + 0.1 * k, 1.0, 3) for k in range(8))
+    true = g.normal(0.5, 1.0, 24)
+    for method in ("variance_approx", "variance_full"):
+        kw = dict(scale=False, utility_method=method, noise_parameter_index=tuple(range(24, 32)))
+        a = obe.OptBayesExptNoiseParameter(model, sv, prior.copy(), (), **kw)
+        b = oracle.OracleOptBayesExptNoiseParameter(numpy_model, sv, prior.copy(), (), n_channels=8, **kw)
+        assert a._device_model is model and a.n_dims == 32 == _lib.OBE_MAX_DIMS and a.allsettings.shape == (8, 6561)
+        a.rng, b.rng = np.random.default_rng(61), np.random.default_rng(61)
+        sim = np.random.default_rng(62)
+        resamples = 0
+        for cyc in range(5):
+            xa, xb = a.opt_setting(), b.opt_setting()
+            if method == "variance_approx":
+                assert_array_equal(a.last_draw_indices, b.last_draw_indices)
+            assert a.last_setting_index == b.last_setting_index and tuple(xa) == tuple(xb), (method, cyc)
+            assert_rel(a._utility_dev.cpu().numpy(), b.last_utility, RTOL, f"{method} utility, cycle {cyc}")
+            y = numpy_model(xb, true, ()) + 0.8 * sim.standard_normal(8)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", RuntimeWarning)
+                a.pdf_update((xa, tuple(y)))
+                b.pdf_update((xb, tuple(y)))
+            assert a.just_resampled == b.just_resampled, (method, cyc)
+            resamples += a.just_resampled
+            wa, wb = np.array(a.particle_weights), np.array(b.particle_weights)
+            assert_array_equal(wa == 0.0, wb == 0.0)
+            if a.just_resampled:
+                assert_array_equal(a.last_resample_indices_device.cpu().numpy(), b.last_draw_indices)
+                # (the nudge of a 32-row cloud is a 32-term product with the factors of a 32 x 32 LAPACK SVD: its
+                # absolute round-off floor is taken at 2048 units, as for the 10-parameter cloud of c5; measured 720)
+                floor = 2048 * 2.3e-16 * np.sqrt(np.max(np.linalg.eigvalsh(np.cov(prior))))
+                assert_allclose(np.array(a.particles), np.array(b.particles), rtol=RTOL, atol=floor)
+                assert_allclose(wa, wb, rtol=RTOL)
+            else:
+                _replay.close_weights(wa, wb, RTOL, f"weights, cycle {cyc}")
+            assert_allclose(a.mean(), b.mean(), rtol=RTOL, atol=1e-12)
+            assert_allclose(a.yvar_noise_model(), b.yvar_noise_model(), rtol=1e-11)
+        assert resamples >= 1, method
+        assert a.rng.bit_generator.state == b.rng.bit_generator.state
+
+
 def test_cloud_of_40_parameters_every_particlepdf_method(obe):
     """ParticlePDF alone has no model and no width limit (particlepdf.py:105): 40 rows — mean, std, covariance
     (55 tile pairs), update, randdraw and resample against NumPy / the oracle class."""
