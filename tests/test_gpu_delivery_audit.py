@@ -6,7 +6,7 @@ construction instead of by soak runs.
      for, no landing zone released with armed words.
 (ii) The three races of rounds 4-5 as DETERMINISTIC failures of the mode.  Each script below issues the call pattern of
      the code BEFORE its fix and the audit must refuse it (the fixed pattern is what (i) runs):
-       * round 4, fixed in ba933f8 (the code before it: ba933f8^ = 50fd66b): a result block that spans several 128-byte lines was
+       * round 4, fixed in ba933f8 (the code before it: ba933f8^ = 394e0ce): a result block that spans several 128-byte lines was
          waited for by watching ONE flag word stored behind a fence; about once in 3000 resamples the host read
          covariance entries of another line that had not arrived;
        * round 5, fixed in 6bc2b8f (the code before it: 6bc2b8f^): good_setting()'s sum(p) and a small draw's sum(w)
