@@ -622,7 +622,10 @@ def main():
     affinity = {"pinned": False, "why": "one rank: the CPU baselines of an N = 1 line use every core"}
     if world > 1 or os.environ.get("OBE_BENCH_PIN") == "1":
         # BEFORE torch / HIP are imported (threads started later inherit the mask; nothing here touches the GPU)
-        affinity = pin_to_gpu_numa_node(0 if os.environ.get("OBE_BENCH_ONE_DEVICE") else local_rank)
+        try:
+            affinity = pin_to_gpu_numa_node(0 if os.environ.get("OBE_BENCH_ONE_DEVICE") else local_rank)
+        except Exception as exc:          # (placement is an optimisation: never a reason for a rank to die)
+            affinity = {"pinned": False, "why": f"{type(exc).__name__}: {exc}"}
     import torch
     import torch.distributed as dist
     if world != args.gpus:
@@ -899,8 +902,11 @@ def main():
     if rccl is not None:
         out["rccl"] = rccl
         if world > 1:
-            out["projection"] = projection_from_one_rank(cfg, world, 1e3 * elapsed / args.steps,
-                                                         rccl["combine_us_idle_median"]["max"])
+            try:
+                out["projection"] = projection_from_one_rank(cfg, world, 1e3 * elapsed / args.steps,
+                                                             rccl["combine_us_idle_median"]["max"])
+            except Exception as exc:
+                out["projection"] = {"available": False, "why": f"{type(exc).__name__}: {exc}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # (before the CPU legs: the 128-thread OpenMP run leaves the host busy for a while, and this loop is
         # ~25 us of host time per cycle)
