@@ -252,7 +252,10 @@ def gpu_local_cpus(index, sysfs="/sys"):
         nodes = os.path.join(sysfs, "class/kfd/kfd/topology/nodes")
         gpus = []
         for name in sorted(os.listdir(nodes), key=int):
-            props = dict(line.split()[:2] for line in open(os.path.join(nodes, name, "properties")) if len(line.split()) >= 2)
+            try:
+                props = dict(line.split()[:2] for line in open(os.path.join(nodes, name, "properties")) if len(line.split()) >= 2)
+            except OSError:
+                continue        # (a GPU of the node that this container was not given: EPERM — the runtime does not see it either)
             if int(props.get("simd_count", "0")) > 0:
                 gpus.append(int(props["drm_render_minor"]))
         order = list(range(len(gpus)))

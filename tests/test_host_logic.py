@@ -615,6 +615,10 @@ def test_bench_finds_the_cores_of_a_gpus_numa_node_from_sysfs(tmp_path, monkeypa
         dev.mkdir(parents=True)
         (dev / "local_cpulist").write_text(cpus + "\n")
         (dev / "numa_node").write_text(f"{numa}\n")
+    # a GPU of the node that this container was not given: its properties cannot be read (EPERM on the pool's boxes;
+    # here: a directory in the file's place) — skipped, as the runtime skips it
+    (nodes / "9").mkdir()
+    (nodes / "9" / "properties").mkdir()
     for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         monkeypatch.delenv(var, raising=False)
     cpus, numa = bench.gpu_local_cpus(0, sysfs=str(sysfs))
