@@ -622,8 +622,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    affinity = {"pinned": False, "why": "one rank: the CPU baselines of an N = 1 line use every core"}
-    if world > 1 or os.environ.get("OBE_BENCH_PIN") == "1":
+    # (N = 1 too: the GPU part of the run — c1's cycle is mostly host time — runs on the GPU's own socket; the full mask is
+    # restored before the CPU legs, which use every core)
+    all_cpus = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    affinity = {"pinned": False, "why": "switched off"}
+    if os.environ.get("OBE_BENCH_PIN", "1") != "0":
         # BEFORE torch / HIP are imported (threads started later inherit the mask; nothing here touches the GPU)
         try:
             affinity = pin_to_gpu_numa_node(0 if os.environ.get("OBE_BENCH_ONE_DEVICE") else local_rank)
@@ -929,6 +932,12 @@ def main():
             except Exception as exc:
                 others[name] = {"error": str(exc)[:200]}
         out["other_configs"] = others
+    out["config"]["cpu_affinity_of_the_gpu_part"] = affinity
+    if all_cpus is not None and affinity.get("pinned"):
+        try:
+            os.sched_setaffinity(0, all_cpus)          # the CPU legs below use every core of the host
+        except OSError:
+            pass
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, settings, prior, cons, true, sigma)
         # ... and a short leg of the same kind next to every other config's throughput (north_star: the NumPy path
