@@ -275,12 +275,41 @@ _RULES = {
     "obe_bayes_update_model": _delivered(13, 2),
     "obe_bayes_update_model_moments": _delivered(14, lambda args: 4 + 4 * int(args[0].n_params)),
     "obe_bayes_update_lik": _delivered(5, 2),
+    "obe_bayes_update_y": _delivered(14, 2),
+    "obe_mask_nonpositive": _delivered(6, 1),
     "obe_weight_sums": _delivered(4, 2),
     "obe_weight_cdf": _delivered(4, 1),
     "obe_utility_argmax": lambda a, args: (a._mark(_addr(args[8]), 1, False), a._mark(_addr(args[9]), 1, False)),
     "obe_argmax": lambda a, args: (a._mark(_addr(args[2]), 1, False), a._mark(_addr(args[3]), 1, False)),
 }
 
+
+# The argument positions the rules above rely on, by the parameter names of include/obe_hip.h
+# (tests/test_capi_symbols.py::test_audit_rules_address_the_parameters_they_name holds the two together: a changed
+# signature fails there instead of silently auditing the wrong argument).
+RULE_PARAMETERS = {
+    "obe_host_word_arm": {0: "h_pinned_word"},
+    "obe_host_words_arm": {0: "h_pinned_words", 1: "n_words"},
+    "obe_host_word_wait": {0: "h_pinned_word"},
+    "obe_host_words_wait": {0: "h_pinned_words", 1: "n_words"},
+    "obe_bayes_update_model_moments_enqueue": {0: "m", 14: "h_pinned_out"},
+    "obe_sweep_utility": {11: "shifted", 18: "h_best", 19: "h_best_idx", 20: "h_kappa"},
+    "obe_resample_begin": {2: "n_dims", 5: "h_pcg_state4", 7: "cdf_is_fresh", 8: "have_first_moments", 18: "h_f64",
+                           19: "h_i64"},
+    "obe_draw_indices": {3: "cdf_is_fresh", 6: "n_draws", 7: "d_idx", 8: "h_total_pinned"},
+    "obe_resample_randoms_enqueue": {9: "h_i64"},
+    "obe_mask_nonpositive_moments": {2: "n_dims", 8: "h_moments", 9: "h_changed"},
+    "obe_mask_renorm_moments": {2: "n_dims", 7: "h_moments", 8: "h_changed"},
+    "obe_bayes_update_model": {13: "h_out"},
+    "obe_bayes_update_model_moments": {0: "m", 14: "h_out"},
+    "obe_bayes_update_lik": {5: "h_out"},
+    "obe_bayes_update_y": {14: "h_out"},
+    "obe_mask_nonpositive": {6: "h_changed"},
+    "obe_weight_sums": {4: "h_out"},
+    "obe_weight_cdf": {4: "h_total"},
+    "obe_utility_argmax": {8: "h_best", 9: "h_best_idx"},
+    "obe_argmax": {2: "h_best", 3: "h_best_idx"},
+}
 
 audit = _Audit() if os.environ.get("OBE_CHECK_DELIVERY") == "1" else _NoAudit()
 

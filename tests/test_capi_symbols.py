@@ -73,6 +73,33 @@ def test_plugin_exports_nothing_but_the_declared_entry_points(lib):
     assert set(syms) <= set(_lib.declared_symbols()), sorted(set(syms) - set(_lib.declared_symbols()))
 
 
+def _header_parameter_names():
+    text = re.sub(r"/\*.*?\*/", "", open(_lib.HEADER_PATH).read(), flags=re.S)
+    names = {}
+    for m in re.finditer(r"\b(?:int|int64_t|const char\*)\s+(obe_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        args = m.group(2).strip()
+        names[m.group(1)] = [] if args in ("", "void") else [a.strip().split()[-1].lstrip("*") for a in args.split(",")]
+    return names
+
+
+def test_audit_rules_address_the_parameters_they_name():
+    """OBE_CHECK_DELIVERY's rules (optbayesexpt_amd/_audit.py) pick host-word pointers and counts out of a call's
+    argument tuple by POSITION; the positions are pinned here to the parameter names of include/obe_hip.h, and every
+    entry point that has a page-locked result parameter has a rule (or is listed as waiting for nothing new)."""
+    from optbayesexpt_amd import _audit
+    names = _header_parameter_names()
+    assert set(_audit._RULES) == set(_audit.RULE_PARAMETERS)
+    for fn, expect in _audit.RULE_PARAMETERS.items():
+        for index, name in expect.items():
+            assert names[fn][index] == name, (fn, index, names[fn][index], name)
+    # every entry point with a host result parameter is covered by a rule
+    host_results = ("h_out", "h_pinned_out", "h_pinned_word", "h_pinned_words", "h_best", "h_best_idx", "h_kappa", "h_f64",
+                    "h_i64", "h_total", "h_total_pinned", "h_moments", "h_changed")
+    unruled = {fn for fn, ps in names.items() if any(p in host_results for p in ps)} - set(_audit._RULES)
+    # (these deliver by a synchronous copy or wait before they return, into memory the audit does not track as armed)
+    assert unruled <= {"obe_moments", "obe_bayes_update_sweep", "obe_likelihood_y"}, sorted(unruled)
+
+
 def test_ctypes_argument_counts_match_header():
     protos = _header_prototypes()
     assert set(protos) == set(_lib._SIGNATURES)
