@@ -10,7 +10,7 @@ done
 for f in $S/rXX_*; do cp $f profiles/${R}_$(basename ${f#$S/rXX_}); done
 sed "s/rXX_/${R}_/g" $S/pmc_traffic.json > profiles/pmc_traffic.json
 for c in c2 c3 c5; do
-  { echo "# kernels between two sweep launches of three real cycles of: rocprofv3 --kernel-trace -- python3 bench.py --config $c --steps 5 --warmup 2 (tools/trace_cycle.py)"
+  { echo "# kernels between two sweep launches of three real cycles of: rocprofv3 --kernel-trace -- python3 bench.py --config $c --steps 5 --warmup 2 (tools/trace_cycle.py); host gaps are inflated by the profiler (every API call costs more under it): the unprofiled cycles are in ${R}_bench_$c.json and ${R}_shard_cycle_c{4,5}.txt"
     grep -v "^+" $S/cycle_timeline_$c.txt; } > profiles/${R}_cycle_timeline_$c.txt
 done
 echo "installed; shard cycles of this run (append to profiles/${R}_shard_cycle_c{4,5}.txt by hand, with the box's letter):"
