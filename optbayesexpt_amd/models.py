@@ -192,7 +192,7 @@ def from_expression(expression, settings, parameters, constants=(), name=None):
     exp/log/log1p/expm1/sqrt/sin/cos/tan/tanh/sinh/cosh/arctan/arctan2/hypot/abs/minimum/maximum.
     The particle array may carry extra trailing rows (e.g. a noise parameter) that the
     formula does not name.  The first use compiles the kernels for this model with hipcc
-    (tens of seconds) into ``optbayesexpt_amd/lib/plugins/``; later uses load the cached
+    (1.6 s on an MI355X host, 4.4 s on 8 cores: profiles/r06_plugin_build_*.txt) into ``optbayesexpt_amd/lib/plugins/``; later uses load the cached
     library.  The returned object is also callable as ``model(sets, pars, cons)`` (NumPy)."""
     from . import _exprmodel, build
     header, numpy_form, digest = _exprmodel.translate(expression, settings, parameters, constants)
@@ -228,7 +228,7 @@ def _beyond_device_limits(n_parameters, n_settings, n_channels, n_consts):
 
 #: When True (or the environment has OBE_AUTO_DEVICE_MODEL=1), ``OptBayesExpt`` tries
 #: ``from_function`` on a plain Python ``model_function`` before settling for host-callable mode.
-#: Off by default: the first use of a model compiles its kernels with hipcc (tens of seconds).
+#: Off by default: the first use of a model compiles its kernels with hipcc (seconds; needs hipcc on the box).
 AUTO_TRANSLATE = False
 
 
